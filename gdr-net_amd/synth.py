@@ -1,0 +1,262 @@
+"""Deterministic synthetic inputs and weights for the GDR-Net hot path.
+
+Everything here is produced by a repo-owned counter-based integer hash (splitmix64
+finaliser) evaluated with numpy, so that the container that generated the golden
+fixtures (``tests/golden/make_golden.py``) and the GPU box regenerate *bit-identical*
+weights and RoI batches without torch's RNG, datasets or checkpoints.
+
+* ``param_schema()``  -- the reference's state_dict key/shape schema
+  (keys from core/gdrn_modeling/models/resnet_backbone.py:17-51,
+  cdpn_rot_head_region.py:80-136, conv_pnp_net.py:76-92).
+* ``make_state_dict(seed)`` -- Kaiming-scaled deterministic weights (default init
+  N(0, 0.001^2) + eval BN gives degenerate activations, SURVEY.md section 7 "hard parts").
+* ``make_batch(bs, seed)`` -- a synthetic RoI batch with exactly the keys / dtypes / shapes
+  ``batch_data`` emits (core/gdrn_modeling/engine_utils.py:6-60).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(x):
+    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = x.astype(np.uint64)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def _stream_key(seed, name):
+    with np.errstate(over="ignore"):
+        h = np.uint64(seed) * _GOLD + np.uint64(0x1234567)
+        for ch in name.encode():
+            h = _mix64(np.array([h ^ np.uint64(ch)], dtype=np.uint64))[0] + _GOLD
+    return h
+
+
+def hash_uniform(seed, name, shape):
+    """U[0,1) float64 array of ``shape``; value i depends only on (seed, name, i)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    key = _stream_key(seed, name)
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64) * _GOLD + key
+    h = _mix64(idx)
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return u.reshape(shape)
+
+
+def hash_normal(seed, name, shape):
+    """N(0,1) float64 array (Box-Muller on two hash streams)."""
+    u1 = hash_uniform(seed, name + "/u1", shape)
+    u2 = hash_uniform(seed, name + "/u2", shape)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def hash_randint(seed, name, shape, lo, hi):
+    return (lo + np.floor(hash_uniform(seed, name, shape) * (hi - lo))).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# state-dict schema
+# ----------------------------------------------------------------------------------------------
+RESNET34_LAYERS = (3, 4, 6, 3)
+RESNET34_PLANES = (64, 128, 256, 512)
+HEAD_CONV_IDX = (3, 6, 10, 13, 17, 20)  # features.N conv 3x3 256->256
+HEAD_BN_IDX = (1, 4, 7, 11, 14, 18, 21)
+HEAD_UP_BEFORE = (10, 17)  # UpsamplingBilinear2d sits right before these convs (features.9 / .16)
+PNP_CONV_IDX = (0, 3, 6)
+PNP_GN_IDX = (1, 4, 7)
+
+
+def param_schema(num_regions=64, pnp_in=69, rot_dim=6):
+    """OrderedDict name -> (shape, kind).  kind in conv|convT|bn_w|bn_b|bn_rm|bn_rv|bn_nbt|gn_w|gn_b|fc_w|fc_b|bias."""
+    s = OrderedDict()
+
+    def bn(prefix, c):
+        s[prefix + ".weight"] = ((c,), "bn_w")
+        s[prefix + ".bias"] = ((c,), "bn_b")
+        s[prefix + ".running_mean"] = ((c,), "bn_rm")
+        s[prefix + ".running_var"] = ((c,), "bn_rv")
+        s[prefix + ".num_batches_tracked"] = ((), "bn_nbt")
+
+    s["backbone.conv1.weight"] = ((64, 3, 7, 7), "conv")
+    bn("backbone.bn1", 64)
+    inpl = 64
+    for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
+        for b in range(nb):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f"backbone.layer{li}.{b}"
+            s[p + ".conv1.weight"] = ((pl, inpl, 3, 3), "conv")
+            bn(p + ".bn1", pl)
+            s[p + ".conv2.weight"] = ((pl, pl, 3, 3), "conv")
+            bn(p + ".bn2", pl)
+            if stride != 1 or inpl != pl:
+                s[p + ".downsample.0.weight"] = ((pl, inpl, 1, 1), "conv")
+                bn(p + ".downsample.1", pl)
+            inpl = pl
+    s["rot_head_net.features.0.weight"] = ((512, 256, 3, 3), "convT")
+    bn("rot_head_net.features.1", 256)
+    for ci, bi in zip(HEAD_CONV_IDX, HEAD_BN_IDX[1:]):
+        s[f"rot_head_net.features.{ci}.weight"] = ((256, 256, 3, 3), "conv")
+        bn(f"rot_head_net.features.{bi}", 256)
+    out_c = 1 + 3 + (num_regions + 1)
+    s["rot_head_net.features.23.weight"] = ((out_c, 256, 1, 1), "conv")
+    s["rot_head_net.features.23.bias"] = ((out_c,), "bias")
+    cin = pnp_in
+    for ci, gi in zip(PNP_CONV_IDX, PNP_GN_IDX):
+        s[f"pnp_net.features.{ci}.weight"] = ((128, cin, 3, 3), "conv")
+        s[f"pnp_net.features.{gi}.weight"] = ((128,), "gn_w")
+        s[f"pnp_net.features.{gi}.bias"] = ((128,), "gn_b")
+        cin = 128
+    s["pnp_net.fc1.weight"] = ((1024, 128 * 8 * 8), "fc_w")
+    s["pnp_net.fc1.bias"] = ((1024,), "fc_b")
+    s["pnp_net.fc2.weight"] = ((256, 1024), "fc_w")
+    s["pnp_net.fc2.bias"] = ((256,), "fc_b")
+    s["pnp_net.fc_r.weight"] = ((rot_dim, 256), "fc_w")
+    s["pnp_net.fc_r.bias"] = ((rot_dim,), "fc_b")
+    s["pnp_net.fc_t.weight"] = ((3, 256), "fc_w")
+    s["pnp_net.fc_t.bias"] = ((3,), "fc_b")
+    return s
+
+
+def make_state_dict(seed=0, as_torch=True):
+    """Deterministic, well-conditioned weights keyed by the reference's state_dict names."""
+    sd = OrderedDict()
+    for name, (shape, kind) in param_schema().items():
+        if kind == "conv":
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = hash_normal(seed, name, shape) * math.sqrt(2.0 / fan_in)
+        elif kind == "convT":
+            fan_in = shape[0] * shape[2] * shape[3] / 4.0  # stride 2: 9/4 taps hit per output pixel
+            v = hash_normal(seed, name, shape) * math.sqrt(2.0 / fan_in)
+        elif kind in ("bn_w", "gn_w"):
+            v = 0.5 + hash_uniform(seed, name, shape)
+        elif kind in ("bn_b", "gn_b"):
+            v = 0.4 * hash_uniform(seed, name, shape) - 0.2
+        elif kind == "bn_rm":
+            v = np.zeros(shape)
+        elif kind == "bn_rv":
+            v = np.ones(shape)
+        elif kind == "bn_nbt":
+            v = np.zeros(shape, dtype=np.int64)
+        elif kind == "fc_w":
+            v = hash_normal(seed, name, shape) * math.sqrt(1.0 / shape[1])
+            if name.endswith("fc_t.weight"):
+                v = v * 0.3
+        elif kind in ("fc_b", "bias"):
+            v = 0.2 * hash_uniform(seed, name, shape) - 0.1
+            if name.endswith("fc_t.bias"):
+                v = np.array([0.05, -0.03, 1.0])
+        else:
+            raise KeyError(kind)
+        if kind != "bn_nbt":
+            v = np.asarray(v, dtype=np.float32)
+        sd[name] = v
+    if as_torch:
+        import torch
+
+        sd = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items())
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic RoI batch
+# ----------------------------------------------------------------------------------------------
+LM_K = np.array([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]], dtype=np.float32)
+# ^ LineMOD intrinsics, ref/lm_full.py:106 (dataset constant)
+YCBV_K = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]], dtype=np.float32)
+# ^ YCB-V intrinsics, ref/ycbv.py:89 (dataset constant)
+
+
+def _random_rotations(seed, name, n):
+    q = hash_normal(seed, name, (n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack(
+        [
+            1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y),
+        ],
+        axis=1,
+    ).reshape(n, 3, 3)
+    return R
+
+
+def make_batch(bs, seed=1, num_classes=13, num_points=3000, cam="lm", with_sym=False, as_torch=True, device=None):
+    """Synthetic batch with the keys of ``batch_data`` (engine_utils.py:6-60)."""
+    K = LM_K if cam == "lm" else YCBV_K
+    b = OrderedDict()
+    b["roi_img"] = hash_uniform(seed, "roi_img", (bs, 3, 256, 256)).astype(np.float32)
+    b["roi_coord_2d"] = hash_uniform(seed, "roi_coord_2d", (bs, 2, 64, 64)).astype(np.float32)
+    b["roi_cls"] = hash_randint(seed, "roi_cls", (bs,), 0, num_classes)
+    b["roi_cam"] = np.broadcast_to(K, (bs, 3, 3)).copy()
+    cx = 100 + 440 * hash_uniform(seed, "cx", (bs,))
+    cy = 100 + 280 * hash_uniform(seed, "cy", (bs,))
+    b["roi_center"] = np.stack([cx, cy], 1).astype(np.float32)
+    wh = 40 + 160 * hash_uniform(seed, "wh", (bs, 2))
+    b["roi_wh"] = wh.astype(np.float32)
+    scale = 1.5 * wh.max(1)  # data_loader.py:417,423 (DZI_PAD_SCALE * max(bw, bh))
+    b["resize_ratio"] = (64.0 / scale).astype(np.float32)
+    b["roi_extent"] = (0.05 + 0.25 * hash_uniform(seed, "extent", (bs, 3))).astype(np.float32)
+    b["roi_xyz"] = hash_uniform(seed, "roi_xyz", (bs, 3, 64, 64)).astype(np.float32)
+    for mk in ("trunc", "visib", "obj"):
+        b["roi_mask_" + mk] = (hash_uniform(seed, "mask_" + mk, (bs, 64, 64)) < 0.5).astype(np.float32)
+    b["roi_region"] = hash_randint(seed, "roi_region", (bs, 64, 64), 0, 65)
+    b["ego_rot"] = _random_rotations(seed, "ego_rot", bs).astype(np.float32)
+    t = hash_uniform(seed, "trans", (bs, 3))
+    b["trans"] = np.stack([-0.2 + 0.4 * t[:, 0], -0.2 + 0.4 * t[:, 1], 0.5 + t[:, 2]], 1).astype(np.float32)
+    tr = hash_uniform(seed, "trans_ratio", (bs, 3))
+    b["roi_trans_ratio"] = np.stack([tr[:, 0] - 0.5, tr[:, 1] - 0.5, 0.5 + 1.5 * tr[:, 2]], 1).astype(np.float32)
+    b["roi_points"] = (-0.1 + 0.2 * hash_uniform(seed, "roi_points", (bs, num_points, 3))).astype(np.float32)
+    sym = [None] * bs
+    if with_sym:
+        rz = np.diag([-1.0, -1.0, 1.0]).astype(np.float32)  # pi about z
+        for i in range(bs):
+            if int(b["roi_cls"][i]) % 4 == 0:
+                sym[i] = np.stack([np.eye(3, dtype=np.float32), rz])
+    if as_torch:
+        import torch
+
+        for k in list(b.keys()):
+            tt = torch.from_numpy(np.ascontiguousarray(b[k]))
+            b[k] = tt.to(device) if device is not None else tt
+        sym = [None if s is None else (torch.from_numpy(s).to(device) if device is not None else torch.from_numpy(s)) for s in sym]
+    b["sym_info"] = sym
+    return b
+
+
+def model_kwargs(batch, do_loss=True):
+    """Map a ``batch_data`` batch to the keyword arguments of ``GDRN.forward`` exactly as
+    the reference trainer does (core/gdrn_modeling/engine.py:244-269)."""
+    kw = dict(
+        roi_classes=batch["roi_cls"],
+        roi_cams=batch["roi_cam"],
+        roi_whs=batch["roi_wh"],
+        roi_centers=batch["roi_center"],
+        resize_ratios=batch["resize_ratio"],
+        roi_coord_2d=batch.get("roi_coord_2d", None),
+        roi_extents=batch.get("roi_extent", None),
+        do_loss=do_loss,
+    )
+    if do_loss:
+        kw.update(
+            gt_xyz=batch.get("roi_xyz", None),
+            gt_xyz_bin=batch.get("roi_xyz_bin", None),
+            gt_mask_trunc=batch["roi_mask_trunc"],
+            gt_mask_visib=batch["roi_mask_visib"],
+            gt_mask_obj=batch["roi_mask_obj"],
+            gt_region=batch.get("roi_region", None),
+            gt_ego_rot=batch.get("ego_rot", None),
+            gt_trans=batch.get("trans", None),
+            gt_trans_ratio=batch["roi_trans_ratio"],
+            gt_points=batch.get("roi_points", None),
+            sym_infos=batch.get("sym_info", None),
+        )
+    return kw

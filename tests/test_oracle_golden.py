@@ -1,0 +1,135 @@
+"""Pin the oracle (oracle/gdrn_oracle.py) against outputs of the reference itself.
+
+The fixtures in tests/golden/*.npz were produced by tests/golden/make_golden.py, which imports
+the reference (core/gdrn_modeling/models/GDRN.py etc.) on CPU.  Inputs/weights are regenerated
+here from the hash RNG, so only reference *outputs* are stored.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gdrnet_amd import synth
+from oracle import gdrn_oracle as O
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def stats(t):
+    t = t.detach().double().flatten()
+    idx = torch.linspace(0, t.numel() - 1, 64).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item(), t.norm().item()], t[idx].numpy()])
+
+
+@pytest.fixture(scope="module")
+def g5(golden_dir):
+    return np.load(os.path.join(golden_dir, "g5_e2e.npz"))
+
+
+@pytest.mark.parametrize("B,tag", [(2, "b2"), (4, "b4")])
+def test_forward_loss_backward_vs_reference(g5, B, tag):
+    torch.set_num_threads(8)
+    sd = synth.make_state_dict(0)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    batch = synth.make_batch(B, seed=1)
+    bufs = {}
+    out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs=bufs)
+    # fp32 oracle vs fp32 reference: same ATen kernels, same op order -> tight
+    assert rel(out["rot6d"].detach(), g5[f"{tag}/rot6d"]) < 2e-5
+    assert rel(out["t_"].detach(), g5[f"{tag}/t_"]) < 2e-5
+    assert rel(out["rot_allo"].detach(), g5[f"{tag}/rot_allo"]) < 2e-5
+    assert rel(out["rot"].detach(), g5[f"{tag}/rot_train"]) < 2e-5
+    assert rel(out["trans"].detach(), g5[f"{tag}/trans"]) < 2e-5
+    assert rel(stats(out["mask"]), g5[f"{tag}/mask_stats"]) < 2e-5
+    assert rel(stats(out["coor_x"]), g5[f"{tag}/coor_x_stats"]) < 2e-5
+    assert rel(stats(out["region"]), g5[f"{tag}/region_stats"]) < 2e-5
+    names = list(g5[f"{tag}/loss_names"])
+    vals = np.array([out["loss_dict"][k].item() for k in names])
+    np.testing.assert_allclose(vals, g5[f"{tag}/loss_values"], rtol=2e-5)
+    re, te = O.mean_re_te(out["trans"], out["rot"], batch["trans"], batch["ego_rot"])
+    assert abs(re - g5[f"{tag}/vis_error_R"]) < 1e-2 and abs(te * 100 - g5[f"{tag}/vis_error_t"]) < 1e-3
+    if tag == "b2":
+        full = torch.cat([out["mask"], out["coor_x"], out["coor_y"], out["coor_z"], out["region"]], 1)
+        assert rel(full.detach(), g5["b2/head_out_full"]) < 2e-5
+    sum(out["loss_dict"].values()).backward()
+    gn = dict(zip(g5[f"{tag}/grad_names"], g5[f"{tag}/grad_norms"]))
+    worst = 0.0
+    for k, v in sd.items():
+        if k in gn:
+            worst = max(worst, abs(v.grad.double().norm().item() - gn[k]) / max(gn[k], 1e-12))
+    assert worst < 5e-3, worst  # BN backward at tiny batch is ill-conditioned
+    for key in g5.files:
+        if key.startswith(f"{tag}/grad/"):
+            n = key[len(f"{tag}/grad/"):]
+            assert rel(sd[n].grad, g5[key]) < 5e-3, n
+    for key in g5.files:
+        if key.startswith(f"{tag}/buf/") and not key.endswith("nbt"):
+            n = key[len(f"{tag}/buf/"):]
+            assert rel(bufs[n], g5[key]) < 1e-5, n
+    assert int(bufs["backbone.bn1.num_batches_tracked"]) == int(g5[f"{tag}/buf/nbt"])
+
+
+@pytest.mark.parametrize("B,tag", [(2, "b2"), (4, "b4")])
+def test_inference_vs_reference(g5, B, tag):
+    sd = synth.make_state_dict(0)
+    batch = synth.make_batch(B, seed=1)
+    with torch.no_grad():
+        out = O.gdrn_forward(sd, batch, do_loss=False, training=False)
+    assert rel(out["rot"], g5[f"{tag}/eval_rot"]) < 2e-5
+    assert rel(out["trans"], g5[f"{tag}/eval_trans"]) < 2e-5
+
+
+def test_fp64_noise_floor(g5):
+    """The reference's own fp32 path sits ~4e-5 (rel. L2) from an fp64 evaluation of the same graph
+    (SURVEY.md section 0); the 1e-4 target is judged with that headroom in mind."""
+    sd = O.to_dtype(synth.make_state_dict(0), torch.float64)
+    batch = O.to_dtype(synth.make_batch(2, seed=1), torch.float64)
+    with torch.no_grad():
+        out = O.gdrn_forward(sd, batch, do_loss=True, training=True)
+    assert rel(out["rot6d"], g5["b2/rot6d"]) < 2e-4
+    assert rel(out["trans"], g5["b2/trans"]) < 2e-4
+
+
+def test_losses_edge_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_loss.npz"))
+    B = 4
+    batch = synth.make_batch(B, seed=7, num_classes=21, cam="ycbv", with_sym=True)
+    mk = lambda name, shape, s=1.0: torch.from_numpy((synth.hash_normal(11, name, shape) * s).astype(np.float32))
+    m, x, y, z = mk("m", (B, 1, 64, 64)), mk("x", (B, 1, 64, 64)), mk("y", (B, 1, 64, 64)), mk("z", (B, 1, 64, 64))
+    region = mk("r", (B, 65, 64, 64), 2.0)
+    rot6d = mk("r6", (B, 6))
+    t_ = mk("t", (B, 3), 0.3) + torch.tensor([0.0, 0.0, 1.0])
+    rot, trans = O.pose_decode_train(
+        O.ortho6d_to_mat_batch(rot6d), t_, batch["roi_cam"], batch["roi_center"], batch["resize_ratio"], batch["roi_wh"]
+    )
+    for case in ("normal", "zero_visib"):
+        b2 = dict(batch)
+        if case == "zero_visib":
+            b2["roi_mask_visib"] = torch.zeros_like(batch["roi_mask_visib"])
+        for tag, sym in (("nosym", False), ("sym", True)):
+            L = O.gdrn_loss(m, x, y, z, region, rot, t_, b2, sym=sym)
+            names = list(g[f"{case}/{tag}/names"])
+            vals = np.array([L[k].item() for k in names])
+            np.testing.assert_allclose(vals, g[f"{case}/{tag}/values"], rtol=1e-5, atol=1e-7)
+
+
+def test_pose_decode(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_pose.npz"))
+    N = g["rot6d"].shape[0]
+    pb = synth.make_batch(N, seed=21)
+    center = torch.from_numpy(g["center"])
+    r6, t_ = torch.from_numpy(g["rot6d"]), torch.from_numpy(g["t_"])
+    R = O.ortho6d_to_mat_batch(r6)
+    assert rel(R, g["R_allo"]) < 1e-6
+    rtr, ttr = O.pose_decode_train(R, t_, pb["roi_cam"], center, pb["resize_ratio"], pb["roi_wh"])
+    np.testing.assert_allclose(ttr.numpy(), g["trans_train"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rtr.numpy(), g["rot_train"], rtol=0, atol=2e-6)
+    rte, tte = O.pose_decode_test(R, t_, pb["roi_cam"], center, pb["resize_ratio"], pb["roi_wh"])
+    np.testing.assert_allclose(rte.numpy(), g["rot_test"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tte.numpy(), g["trans_test"], rtol=1e-6, atol=1e-7)
