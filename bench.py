@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- RoI crops/s of GDR-Net's per-RoI training step (forward + losses + backward + fused Ranger
+step) on MI355X: ResNet-34 + geometric head + Patch-PnP, 256x256 RoIs, bs=64 per GPU (BASELINE.json
+configs[1] = LM-13 `a6_cPnP_lm13`, bf16 operands / fp32 accumulate), synthetic seeded RoI batch resident
+in HBM, random-init (deterministic Kaiming-scaled) weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on rank 0.  `roofline`: the dominant kernel (bf16 implicit-GEMM conv, 128x128 tile) --
+every launch of it in one step is bracketed by HIP events on the launch stream; achieved =
+sum(algorithmic FLOPs) / sum(durations) against the 2.5 PFLOP/s dense bf16 MFMA peak.
+`cpu_baseline`: the CPU oracle (a port of the reference path on stock PyTorch CPU kernels) timed on
+this box's host cores on a bounded sample (B=8, fwd+bwd).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_ROI_TRAIN = 68.16e9  # 34.08 GMAC fwd+bwd per 256x256 RoI
+PEAK_BF16 = 2.5e15            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32 = 157.3e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=64, help="RoIs per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="inference throughput (eval BN, test-mode pose decode)")
+    return ap.parse_args()
+
+
+def cpu_baseline(bs=8, iters=2):
+    """Oracle fwd+bwd on the host cores (reported baseline, not a target)."""
+    import torch
+
+    from gdrnet_amd import synth
+    from oracle import gdrn_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.make_state_dict(0)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    batch = synth.make_batch(bs, seed=1)
+
+    def step():
+        out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})
+        sum(out["loss_dict"].values()).backward()
+        for v in sd.values():
+            v.grad = None
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(bs / dt, 3), "unit": "RoI/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch CPU fp32) fwd+bwd, bs={bs}, {iters} timed steps after 1 warm-up, no optimizer step"}
+
+
+def measure_roofline(model, plan, kctx, dtype):
+    """Bracket every launch of the dominant conv kernel in one forward+backward with HIP events."""
+    import torch
+
+    dom = f"conv_gemm_kernel<{'bf16' if dtype == 'bf16' else 'f32'},128,128>"
+    st = plan.e._stream()
+    ev = []
+
+    def run(ops):
+        for op in ops:
+            meta = getattr(op, "meta", None)
+            if meta is not None and meta["kernel"] == dom:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                op(st, kctx)
+                b.record()
+                ev.append((a, b, meta))
+            else:
+                op(st, kctx)
+
+    plan.e.dwp_flat.zero_()
+    run(plan.fwd)
+    plan.gw.fill_(1.0)
+    run(plan.bwd)
+    torch.cuda.synchronize()
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+    flops = sum(m["flops"] for _, _, m in ev)
+    achieved = flops / (tot_ms * 1e-3) / 1e12
+    peak = (PEAK_BF16 if dtype == "bf16" else PEAK_F32) / 1e12
+    return {"bound": "mfma", "kernel": dom, "launches_per_step": len(ev), "avg_launch_us": round(tot_ms * 1e3 / max(len(ev), 1), 2),
+            "algorithmic_gflop_per_launch": round(flops / max(len(ev), 1) / 1e9, 3), "achieved": round(achieved, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from gdrnet_amd import GDRN, synth
+    from gdrnet_amd import dist as gdist
+    from gdrnet_amd.cfg import lm13_cfg
+    from gdrnet_amd.engine import LOSS_NAMES
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    cfg = lm13_cfg(device=dev)
+    cfg.MODEL.CDPN.HIP_DTYPE = args.dtype
+    model, opt = GDRN.build_model_optimizer(cfg)
+    model.load_state_dict(synth.make_state_dict(0))
+    B = args.bs
+    batch = synth.make_batch(B, seed=1 + rank)  # each rank its own RoIs (weak scaling)
+    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    kw = synth.model_kwargs(batch, do_loss=not args.fwd_only)
+    kw.pop("do_loss")
+    if world > 1:
+        gdist.broadcast_parameters(model)
+        model.train()
+        gdist.attach(model)
+
+    if args.fwd_only:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                return model(batch["roi_img"], do_loss=False, **kw)
+    else:
+        model.train()
+
+        def step():
+            return model.train_step(batch["roi_img"], optimizer=opt, **kw)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not args.fwd_only:
+        assert torch.isfinite(out).all(), out
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        flop_roi = FLOP_PER_ROI_TRAIN if not args.fwd_only else 22.823e9
+        res = {
+            "metric": "RoI crops/sec (fwd+bwd+optimizer step) at 256x256 bs=64 per GPU" if not args.fwd_only else "RoI crops/sec (fwd, inference)",
+            "value": round(value, 2), "unit": "RoI/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "LM-13 a6_cPnP_lm13 graph: ResNet-34 + RotWithRegionHead + ConvPnPNet, 256x256 RoIs, "
+                                   f"bs={B}/GPU, {'train step fwd+loss+bwd+Ranger' if not args.fwd_only else 'inference fwd'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "whole_step_tflops": round(value * flop_roi / 1e12, 2)},
+        }
+        if not args.no_roofline and not args.fwd_only:
+            eng = model.engine()
+            plan = eng.plan(B, True, True)
+            a = {k: kw.get(k) for k in ("gt_xyz", "gt_mask_trunc", "gt_mask_visib", "gt_region", "gt_ego_rot", "gt_points", "sym_infos",
+                                        "gt_trans", "gt_trans_ratio", "roi_coord_2d", "roi_cams", "roi_centers", "roi_whs", "roi_extents",
+                                        "resize_ratios")}
+            _, plan, kctx = model._prepare(batch["roi_img"], True, a)
+            res["roofline"] = measure_roofline(model, plan, kctx, args.dtype)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

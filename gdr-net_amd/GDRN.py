@@ -1,0 +1,495 @@
+"""Drop-in for the reference's ``core/gdrn_modeling/models/GDRN.py`` on MI355X.
+
+Keeps the reference's model-construction / forward / loss API surface:
+
+* ``build_model_optimizer(cfg) -> (model, optimizer)``                     (GDRN.py:550-724)
+* ``GDRN.forward(x, gt_xyz=..., ..., roi_extents=..., resize_ratios=..., do_loss=False)``
+  returning ``out_dict`` or ``(out_dict, loss_dict)``                       (GDRN.py:83-306)
+* ``get_xyz_mask_region_out_dim(cfg)``                                      (GDRN.py:524-547)
+* sub-modules ``backbone`` / ``rot_head_net`` / ``pnp_net`` whose parameters and buffers carry the
+  reference's state_dict names and logical shapes, so released checkpoints load.
+
+The sub-modules are *parameter containers*: the whole path (forward, losses, backward) runs as one
+autograd node on the hand-written HIP kernels of ``libgdrn_hip.so`` (engine.py); there is no ATen
+compute fallback -- without the library or a GPU, forward raises ``GdrnHipError``.
+
+Only the branches the shipped configs enable are implemented: ResNet-34, non-concat
+region head (class-agnostic, L1 xyz / L1 mask / CE region), ConvPnPNet with 2D coords + region
+attention, ``allo_rot6d`` + ``centroid_z`` (REL), PM_R (L1, norm-by-extent, optional symmetry), L1
+centroid / z.  Any other setting raises ``NotImplementedError`` at construction.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import cabi
+from .engine import LOSS_NAMES, Engine
+
+logger = logging.getLogger(__name__)
+
+try:  # the reference pushes vis/* scalars into detectron2's EventStorage from inside forward (GDRN.py:302-303)
+    from detectron2.utils.events import get_event_storage as _d2_get_event_storage
+except Exception:  # detectron2 is not a dependency of this package
+    _d2_get_event_storage = None
+
+
+class _ScalarSink:
+    def __init__(self):
+        self.scalars = {}
+
+    def put_scalars(self, **kw):
+        self.scalars.update(kw)
+
+
+_fallback_storage = _ScalarSink()
+
+
+def get_event_storage():
+    if _d2_get_event_storage is not None:
+        try:
+            return _d2_get_event_storage()
+        except Exception:
+            pass
+    return _fallback_storage
+
+
+# resnet_backbone.py:8-14 (only BasicBlock depths are on the path)
+resnet_spec = {
+    18: ("BasicBlock", [2, 2, 2, 2], [64, 64, 128, 256, 512], "resnet18"),
+    34: ("BasicBlock", [3, 4, 6, 3], [64, 64, 128, 256, 512], "resnet34"),
+}
+
+
+def _normal_init(m, std):
+    nn.init.normal_(m.weight, 0.0, std)
+    if getattr(m, "bias", None) is not None:
+        nn.init.constant_(m.bias, 0.0)
+
+
+class _Container(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError(
+            f"{type(self).__name__} is a parameter container; the path runs fused through GDRN.forward on the HIP engine"
+        )
+
+
+class BasicBlock(_Container):
+    """Parameter layout of torchvision BasicBlock (resnet_backbone.py:3)."""
+
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNetBackboneNet(_Container):
+    """resnet_backbone.py:17-51 (ResNet-34: BasicBlock, [3,4,6,3]); init: normal std 0.001, BN weight 1."""
+
+    def __init__(self, layers=(3, 4, 6, 3), in_channel=3, freeze=False, rot_concat=False):
+        super().__init__()
+        if freeze or rot_concat:
+            raise NotImplementedError("BACKBONE.FREEZE / ROT_CONCAT are not on the hot path (SURVEY.md section 8)")
+        self.freeze, self.rot_concat = freeze, rot_concat
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channel, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                _normal_init(m, 0.001)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        ds = None
+        if stride != 1 or self.inplanes != planes:
+            ds = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        blks = [BasicBlock(self.inplanes, planes, stride, ds)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            blks.append(BasicBlock(planes, planes))
+        return nn.Sequential(*blks)
+
+
+class RotWithRegionHead(_Container):
+    """cdpn_rot_head_region.py:9-143, non-concat branch: features.0 ConvT, .1 BN, then (conv, BN) pairs at
+    (3,4) (6,7) (10,11) (13,14) (17,18) (20,21) with bilinear x2 at .9/.16, .23 the 1x1 output conv."""
+
+    def __init__(self, in_channels=512, num_filters=256, rot_output_dim=3, mask_output_dim=1, num_regions=64):
+        super().__init__()
+        f = nn.ModuleList()
+        f.append(nn.ConvTranspose2d(in_channels, num_filters, 3, 2, 1, 1, bias=False))
+        f.append(nn.BatchNorm2d(num_filters))
+        f.append(nn.Identity())  # ReLU
+        for i in range(3):
+            if i >= 1:
+                f.append(nn.Identity())  # UpsamplingBilinear2d(scale_factor=2)
+            for _ in range(2):
+                f.append(nn.Conv2d(num_filters, num_filters, 3, 1, 1, bias=False))
+                f.append(nn.BatchNorm2d(num_filters))
+                f.append(nn.Identity())  # ReLU
+        self.rot_output_dim, self.mask_output_dim, self.region_output_dim = rot_output_dim, mask_output_dim, num_regions + 1
+        f.append(nn.Conv2d(num_filters, mask_output_dim + rot_output_dim + num_regions + 1, 1, bias=True))
+        self.features = f
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                _normal_init(m, 0.001)
+
+
+class ConvPnPNet(_Container):
+    """conv_pnp_net.py:41-109: 3 x (conv3x3 s2, GN(32), ReLU), fc1 8192->1024, fc2 ->256, fc_r, fc_t."""
+
+    def __init__(self, nIn, featdim=128, rot_dim=6, num_layers=3, norm="GN", num_gn_groups=32, num_regions=64, drop_prob=0.0,
+                 dropblock_size=5, mask_attention_type="none"):
+        super().__init__()
+        if norm != "GN" or num_gn_groups != 32 or featdim != 128 or num_layers != 3 or mask_attention_type != "none":
+            raise NotImplementedError("only ConvPnPNet(GN(32), featdim 128, 3 layers, no mask attention) is on the hot path")
+        if drop_prob != 0.0:
+            raise NotImplementedError("DropBlock is config-dead (drop_prob=0.0 in every shipped config)")
+        self.featdim, self.num_regions, self.mask_attention_type, self.drop_prob = featdim, num_regions, mask_attention_type, drop_prob
+        f = nn.ModuleList()
+        for i in range(3):
+            f.append(nn.Conv2d(nIn if i == 0 else featdim, featdim, 3, 2, 1, bias=False))
+            f.append(nn.GroupNorm(num_gn_groups, featdim))
+            f.append(nn.Identity())
+        self.features = f
+        self.fc1 = nn.Linear(featdim * 8 * 8, 1024)
+        self.fc2 = nn.Linear(1024, 256)
+        self.fc_r = nn.Linear(256, rot_dim)
+        self.fc_t = nn.Linear(256, 3)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                _normal_init(m, 0.001)
+        _normal_init(self.fc_r, 0.01)
+        _normal_init(self.fc_t, 0.01)
+
+
+def get_xyz_mask_region_out_dim(cfg):
+    """GDRN.py:524-547."""
+    r_head_cfg = cfg.MODEL.CDPN.ROT_HEAD
+    if r_head_cfg.XYZ_LOSS_TYPE in ["MSE", "L1", "L2", "SmoothL1"]:
+        r_out_dim = 3
+    elif r_head_cfg.XYZ_LOSS_TYPE in ["CE_coor", "CE"]:
+        r_out_dim = 3 * (r_head_cfg.XYZ_BIN + 1)
+    else:
+        raise NotImplementedError(f"unknown xyz loss type: {r_head_cfg.XYZ_LOSS_TYPE}")
+    if r_head_cfg.MASK_LOSS_TYPE in ["L1", "BCE"]:
+        mask_out_dim = 1
+    elif r_head_cfg.MASK_LOSS_TYPE in ["CE"]:
+        mask_out_dim = 2
+    else:
+        raise NotImplementedError(f"unknown mask loss type: {r_head_cfg.MASK_LOSS_TYPE}")
+    region_out_dim = r_head_cfg.NUM_REGIONS + 1
+    assert region_out_dim > 2, region_out_dim
+    return r_out_dim, mask_out_dim, region_out_dim
+
+
+def _check_supported(cfg):
+    m = cfg.MODEL.CDPN
+    r, p, t = m.ROT_HEAD, m.PNP_NET, m.TRANS_HEAD
+    bad = []
+    if m.get("USE_MTL", False): bad.append("USE_MTL")
+    if m.BACKBONE.NUM_LAYERS != 34 or m.BACKBONE.INPUT_RES != 256 or m.BACKBONE.OUTPUT_RES != 64: bad.append("BACKBONE")
+    if r.ROT_CONCAT or r.FREEZE or r.ROT_CLASS_AWARE or r.MASK_CLASS_AWARE or r.REGION_CLASS_AWARE: bad.append("ROT_HEAD flags")
+    if r.XYZ_LOSS_TYPE != "L1" or r.MASK_LOSS_TYPE != "L1" or r.REGION_LOSS_TYPE != "CE": bad.append("loss types")
+    if r.XYZ_LOSS_MASK_GT != "visib" or r.MASK_LOSS_GT != "trunc" or r.REGION_LOSS_MASK_GT != "visib": bad.append("loss masks")
+    if r.NUM_LAYERS != 3 or r.NUM_FILTERS != 256 or r.CONV_KERNEL_SIZE != 3 or r.OUT_CONV_KERNEL_SIZE != 1 or r.NORM != "BN": bad.append("head arch")
+    if not (1 < r.NUM_REGIONS <= 64): bad.append("NUM_REGIONS")
+    if t.ENABLED or p.R_ONLY or p.FREEZE: bad.append("TRANS_HEAD/R_ONLY/FREEZE")
+    if not (p.WITH_2D_COORD and p.REGION_ATTENTION and p.MASK_ATTENTION == "none"): bad.append("PNP inputs")
+    if p.ROT_TYPE != "allo_rot6d" or p.TRANS_TYPE != "centroid_z" or p.Z_TYPE != "REL": bad.append("pose parametrisation")
+    if not (p.PM_LW > 0 and p.PM_R_ONLY and p.PM_NORM_BY_EXTENT and p.PM_LOSS_TYPE == "L1"): bad.append("PM loss")
+    if p.ROT_LW > 0 or p.TRANS_LW > 0 or p.get("BIND_LW", 0.0) > 0: bad.append("rot/trans/bind losses")
+    if not (p.CENTROID_LW > 0 and p.CENTROID_LOSS_TYPE == "L1" and p.Z_LW > 0 and p.Z_LOSS_TYPE == "L1"): bad.append("centroid/z losses")
+    if bad:
+        raise NotImplementedError("config outside the MI355X hot-path scope (SURVEY.md section 8): " + ", ".join(bad))
+
+
+class _PathFn(torch.autograd.Function):
+    """The whole path (backbone -> head -> Patch-PnP -> pose -> losses) as ONE autograd node."""
+
+    @staticmethod
+    def forward(ctx, model, plan, kctx, *params):
+        plan.run_forward(kctx)
+        ctx.model, ctx.plan, ctx.kctx = model, plan, kctx
+        ctx.keep = kctx.get("_keep")
+        return plan.losses.clone()
+
+    @staticmethod
+    def backward(ctx, glosses):
+        plan, e = ctx.plan, ctx.plan.e
+        if not plan.has_backward:
+            raise cabi.GdrnHipError("backward needs train-mode BatchNorm (model.train()) together with do_loss=True")
+        plan.gw.copy_(glosses.to(torch.float32))
+        plan.run_backward(ctx.kctx, on_bucket=ctx.model._on_bucket)
+        return (None, None, None) + tuple(e.grads[n] for n in e.param_names)
+
+
+class GDRN(nn.Module):
+    def __init__(self, cfg, backbone, rot_head_net, trans_head_net=None, pnp_net=None):
+        super().__init__()
+        assert cfg.MODEL.CDPN.NAME == "GDRN", cfg.MODEL.CDPN.NAME
+        _check_supported(cfg)
+        self.backbone = backbone
+        self.rot_head_net = rot_head_net
+        self.pnp_net = pnp_net
+        self.trans_head_net = trans_head_net
+        self.cfg = cfg
+        self.concat = cfg.MODEL.CDPN.ROT_HEAD.ROT_CONCAT
+        self.r_out_dim, self.mask_out_dim, self.region_out_dim = get_xyz_mask_region_out_dim(cfg)
+        self.hip_dtype = str(cfg.MODEL.CDPN.get("HIP_DTYPE", os.environ.get("GDRN_HIP_DTYPE", "bf16")))
+        self._eng = None
+        self._eng_key = None
+        self._on_bucket = None   # set by dist.attach(): overlap the RCCL all-reduce with backward
+        self._loss_w = None
+        self.last_vis = None
+
+    # -------------------------------------------------------------------------------------------
+    def engine(self):
+        """The HIP engine bound to the current parameter storage (rebuilt after .to()/.load_state_dict re-allocation)."""
+        params = dict(self.named_parameters())
+        key = (self.hip_dtype,) + tuple(p.data_ptr() for p in params.values())
+        if self._eng is None or self._eng_key != key:
+            dev = next(iter(params.values())).device
+            if dev.type != "cuda":
+                raise cabi.GdrnHipError("GDRN runs on the HIP engine only: move the model to an MI355X (`model.to('cuda')`)")
+            r, p = self.cfg.MODEL.CDPN.ROT_HEAD, self.cfg.MODEL.CDPN.PNP_NET
+            self._eng = Engine(params, dict(self.named_buffers()), dtype=self.hip_dtype, num_regions=r.NUM_REGIONS,
+                               wgrad_variant=int(os.environ.get("GDRN_WGRAD_VARIANT", "0")))
+            self._eng_key = key
+            lw = [r.XYZ_LW, r.XYZ_LW, r.XYZ_LW, r.MASK_LW, r.REGION_LW, p.PM_LW, p.CENTROID_LW, p.Z_LW]
+            self._loss_w = torch.tensor(lw, dtype=torch.float32, device=dev)
+        return self._eng
+
+    @staticmethod
+    def _f32(t, dev):
+        return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+    def _pack_sym(self, sym_infos, B, dev):
+        """list of (K,3,3) / None (pm_loss.py:91-92) -> fp32 [B][Kmax][9] + int32 counts."""
+        mats = [None if s is None else torch.as_tensor(s).detach().cpu().to(torch.float32).reshape(-1, 9) for s in sym_infos]
+        K = max([m.shape[0] for m in mats if m is not None], default=0)
+        if K == 0:
+            return None, None, 0
+        sym = torch.zeros(B, K, 9, dtype=torch.float32)
+        cnt = torch.zeros(B, dtype=torch.int32)
+        for i, m in enumerate(mats):
+            if m is not None:
+                sym[i, : m.shape[0]] = m
+                cnt[i] = m.shape[0]
+        return sym.to(dev), cnt.to(dev), K
+
+    def _prepare(self, x, do_loss, a):
+        """Validate / stage the call's tensors (fp32, contiguous, on the device) and pick the plan."""
+        cfg = self.cfg
+        gt_xyz, gt_mask_trunc, gt_mask_visib, gt_region, gt_ego_rot = a['gt_xyz'], a['gt_mask_trunc'], a['gt_mask_visib'], a['gt_region'], a['gt_ego_rot']
+        gt_points, sym_infos, gt_trans, gt_trans_ratio = a['gt_points'], a['sym_infos'], a['gt_trans'], a['gt_trans_ratio']
+        roi_coord_2d, roi_cams, roi_centers, roi_whs = a['roi_coord_2d'], a['roi_cams'], a['roi_centers'], a['roi_whs']
+        roi_extents, resize_ratios = a['roi_extents'], a['resize_ratios']
+        eng = self.engine()
+        dev = eng.dev
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (3, 256, 256), x.shape
+        assert roi_coord_2d is not None and roi_extents is not None
+        f32 = lambda t: self._f32(t, dev)
+        cams = f32(roi_cams)
+        if cams.dim() == 2:
+            cams = cams.unsqueeze(0).expand(B, 3, 3).contiguous()
+        keep = [f32(x), f32(roi_coord_2d), f32(roi_extents), cams, f32(roi_centers), f32(roi_whs), f32(resize_ratios).reshape(B)]
+        kctx = dict(img=keep[0].data_ptr(), coord2d=keep[1].data_ptr(), extents=keep[2].data_ptr(), cams=keep[3].data_ptr(),
+                    centers=keep[4].data_ptr(), whs=keep[5].data_ptr(), ratios=keep[6].data_ptr(), _keep=keep)
+        if do_loss:
+            assert (gt_xyz is not None) and (gt_trans is not None) and (gt_trans_ratio is not None) and (gt_region is not None)
+            assert (gt_points is not None) and (gt_ego_rot is not None)
+            g = [f32(gt_xyz), f32(gt_mask_visib), f32(gt_mask_trunc), gt_region.detach().to(device=dev, dtype=torch.int64).contiguous(),
+                 f32(gt_ego_rot), f32(gt_trans), f32(gt_trans_ratio), f32(gt_points)]
+            keep += g
+            kctx.update(gt_xyz=g[0].data_ptr(), mask_visib=g[1].data_ptr(), mask_trunc=g[2].data_ptr(), gt_region=g[3].data_ptr(),
+                        gt_rot=g[4].data_ptr(), gt_trans=g[5].data_ptr(), gt_trans_ratio=g[6].data_ptr(), points=g[7].data_ptr(),
+                        npts=int(g[7].shape[1]))
+            if cfg.MODEL.CDPN.PNP_NET.PM_LOSS_SYM:
+                assert sym_infos is not None
+                sym, cnt, K = self._pack_sym(sym_infos, B, dev)
+                if K > 0:
+                    keep += [sym, cnt]
+                    kctx.update(sym=sym.data_ptr(), sym_count=cnt.data_ptr(), Kmax=K)
+        eng.repack()
+        plan = eng.plan(B, self.training, do_loss)
+        return eng, plan, kctx
+
+    def forward(
+        self,
+        x,
+        gt_xyz=None,
+        gt_xyz_bin=None,
+        gt_mask_trunc=None,
+        gt_mask_visib=None,
+        gt_mask_obj=None,
+        gt_region=None,
+        gt_allo_quat=None,
+        gt_ego_quat=None,
+        gt_allo_rot6d=None,
+        gt_ego_rot6d=None,
+        gt_ego_rot=None,
+        gt_points=None,
+        sym_infos=None,
+        gt_trans=None,
+        gt_trans_ratio=None,
+        roi_classes=None,
+        roi_coord_2d=None,
+        roi_cams=None,
+        roi_centers=None,
+        roi_whs=None,
+        roi_extents=None,
+        resize_ratios=None,
+        do_loss=False,
+    ):
+        a = dict(gt_xyz=gt_xyz, gt_mask_trunc=gt_mask_trunc, gt_mask_visib=gt_mask_visib, gt_region=gt_region, gt_ego_rot=gt_ego_rot,
+                 gt_points=gt_points, sym_infos=sym_infos, gt_trans=gt_trans, gt_trans_ratio=gt_trans_ratio, roi_coord_2d=roi_coord_2d,
+                 roi_cams=roi_cams, roi_centers=roi_centers, roi_whs=roi_whs, roi_extents=roi_extents, resize_ratios=resize_ratios)
+        cfg = self.cfg
+        eng, plan, kctx = self._prepare(x, do_loss, a)
+        dev, B = eng.dev, x.shape[0]
+
+        if not do_loss:  # test
+            with torch.no_grad():
+                plan.run_forward(kctx)
+            out_dict = {"rot": plan.rot.clone(), "trans": plan.trans.clone()}
+            if cfg.TEST.USE_PNP:
+                out_dict.update(self._maps(plan, B))
+            return out_dict
+
+        need_grad = torch.is_grad_enabled() and plan.has_backward
+        if need_grad:
+            losses = _PathFn.apply(self, plan, kctx, *[eng.P[n] for n in eng.param_names])
+        else:
+            plan.run_forward(kctx)
+            losses = plan.losses.clone()
+        losses = losses * self._loss_w
+        loss_dict = {k: losses[i] for i, k in enumerate(LOSS_NAMES)}
+        self._put_vis(plan, kctx, gt_trans, gt_trans_ratio, dev)
+        return {}, loss_dict
+
+    # -------------------------------------------------------------------------------------------
+    def train_step(self, x, optimizer=None, loss_weights=None, **kw):
+        """One fused training step without the autograd round trip: forward + losses + backward
+        (+ overlapped RCCL gradient all-reduce when dist.attach()ed) (+ fused optimizer step reading the
+        engine's flat gradient buffer).  Same arithmetic as ``loss_dict = model(...); sum(loss_dict.values()).backward();
+        optimizer.step()`` (core/gdrn_modeling/engine.py:244-280).  Returns the [8] loss tensor (device,
+        order engine.LOSS_NAMES)."""
+        assert self.training, "train_step needs model.train()"
+        a = dict(gt_xyz=None, gt_mask_trunc=None, gt_mask_visib=None, gt_region=None, gt_ego_rot=None, gt_points=None, sym_infos=None,
+                 gt_trans=None, gt_trans_ratio=None, roi_coord_2d=None, roi_cams=None, roi_centers=None, roi_whs=None, roi_extents=None,
+                 resize_ratios=None)
+        a.update({k: v for k, v in kw.items() if k in a})
+        eng, plan, kctx = self._prepare(x, True, a)
+        plan.run_forward(kctx)
+        plan.gw.copy_(self._loss_w if loss_weights is None else self._loss_w * loss_weights)
+        plan.run_backward(kctx, on_bucket=self._on_bucket)
+        red = getattr(self, "_reducer", None)
+        if red is not None:
+            red.wait()
+        if optimizer is not None:
+            eng = plan.e
+            optimizer.step(grads={eng.P[n]: eng.grads[n] for n in eng.param_names})
+        return plan.losses
+
+    def _maps(self, plan, B):
+        """mask / coor_x / coor_y / coor_z / region as NCHW fp32 (GDRN.py:235-237)."""
+        e, lib = plan.e, plan.e.lib
+        st = e._stream()
+        C_ = e.head_c
+        full = torch.empty(B, C_, 64, 64, dtype=torch.float32, device=e.dev)
+        cabi.check(lib.gdrn_nhwc_to_nchw_f32(plan.head_out.data_ptr(), plan.hs, 0, C_, full.data_ptr(), B, 4096, cabi.F32, st), "nhwc_to_nchw")
+        return {"mask": full[:, 0:1], "coor_x": full[:, 1:2], "coor_y": full[:, 2:3], "coor_z": full[:, 3:4], "region": full[:, 4:]}
+
+    def _put_vis(self, plan, kctx, gt_trans, gt_trans_ratio, dev):
+        """vis/* scalars of GDRN.py:246-303.  Values stay on the device (``self.last_vis``); they are
+        fetched (one host sync) only when a detectron2 EventStorage is active, as in the reference."""
+        vis = torch.cat([plan.vis.mean(0), plan.trans[0], plan.fc_out[0, 6:9]])
+        self.last_vis = (vis, gt_trans, gt_trans_ratio)
+        if _d2_get_event_storage is None:
+            return
+        try:
+            storage = _d2_get_event_storage()
+        except Exception:
+            return
+        storage.put_scalars(**self.vis_dict())
+
+    def vis_dict(self):
+        """Materialise the reference's vis/* dictionary (host sync)."""
+        vis, gt_trans, gt_trans_ratio = self.last_vis
+        v = vis.detach().cpu().numpy().astype(np.float64)
+        gt, gtr = gt_trans[0].detach().cpu().numpy(), gt_trans_ratio[0].detach().cpu().numpy()
+        return {
+            "vis/error_R": float(v[0]), "vis/error_t": float(v[1]) * 100,
+            "vis/error_tx": abs(v[2] - gt[0]) * 100, "vis/error_ty": abs(v[3] - gt[1]) * 100, "vis/error_tz": abs(v[4] - gt[2]) * 100,
+            "vis/tx_pred": v[2], "vis/ty_pred": v[3], "vis/tz_pred": v[4],
+            "vis/tx_net": v[5], "vis/ty_net": v[6], "vis/tz_net": v[7],
+            "vis/tx_gt": float(gt[0]), "vis/ty_gt": float(gt[1]), "vis/tz_gt": float(gt[2]),
+            "vis/tx_rel_gt": float(gtr[0]), "vis/ty_rel_gt": float(gtr[1]), "vis/tz_rel_gt": float(gtr[2]),
+        }
+
+
+def build_model_optimizer(cfg):
+    """GDRN.py:550-724: ResNet-34 backbone, RotWithRegionHead, ConvPnPNet, 3 parameter groups
+    (backbone / rot head / pnp with LR_MULT), optimizer from cfg.SOLVER.OPTIMIZER_CFG."""
+    backbone_cfg = cfg.MODEL.CDPN.BACKBONE
+    r_head_cfg = cfg.MODEL.CDPN.ROT_HEAD
+    pnp_net_cfg = cfg.MODEL.CDPN.PNP_NET
+    _check_supported(cfg)
+    assert "resnet" in backbone_cfg.ARCH
+    params_lr_list = []
+    _, layers, channels, _ = resnet_spec[backbone_cfg.NUM_LAYERS]
+    backbone_net = ResNetBackboneNet(layers, backbone_cfg.INPUT_CHANNEL, freeze=backbone_cfg.FREEZE, rot_concat=r_head_cfg.ROT_CONCAT)
+    params_lr_list.append({"params": [p for p in backbone_net.parameters() if p.requires_grad], "lr": float(cfg.SOLVER.BASE_LR)})
+    r_out_dim, mask_out_dim, region_out_dim = get_xyz_mask_region_out_dim(cfg)
+    rot_head_net = RotWithRegionHead(channels[-1], r_head_cfg.NUM_FILTERS, rot_output_dim=r_out_dim, mask_output_dim=mask_out_dim,
+                                     num_regions=r_head_cfg.NUM_REGIONS)
+    params_lr_list.append({"params": [p for p in rot_head_net.parameters() if p.requires_grad], "lr": float(cfg.SOLVER.BASE_LR)})
+    pnp_net_in_channel = r_out_dim + 2 + r_head_cfg.NUM_REGIONS
+    pnp_head_cfg = pnp_net_cfg.PNP_HEAD_CFG
+    pnp_head_type = pnp_head_cfg.pop("type")
+    if pnp_head_type != "ConvPnPNet":
+        raise NotImplementedError(f"pnp head {pnp_head_type} is not on the hot path")
+    pnp_head_cfg.update(nIn=pnp_net_in_channel, rot_dim=6, num_regions=r_head_cfg.NUM_REGIONS, featdim=128, num_layers=3,
+                        mask_attention_type=pnp_net_cfg.MASK_ATTENTION)
+    pnp_net = ConvPnPNet(**pnp_head_cfg)
+    params_lr_list.append({"params": [p for p in pnp_net.parameters() if p.requires_grad],
+                           "lr": float(cfg.SOLVER.BASE_LR) * pnp_net_cfg.LR_MULT})
+    model = GDRN(cfg, backbone_net, rot_head_net, trans_head_net=None, pnp_net=pnp_net)
+    optimizer = build_optimizer_with_params(cfg, params_lr_list)
+    if cfg.MODEL.WEIGHTS == "":
+        pre = cfg.MODEL.CDPN.BACKBONE.get("PRETRAINED", "")
+        if pre == "":
+            logger.warning("Randomly initialize weights for backbone!")
+        elif os.path.exists(pre):
+            sd = torch.load(pre, map_location="cpu")
+            model.backbone.load_state_dict(sd.get("state_dict", sd), strict=False)
+        else:
+            logger.warning(f"backbone weights {pre!r} not found (no network access); random init")
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model, optimizer
+
+
+def build_optimizer_with_params(cfg, params):
+    """core/utils/solver_utils.py:47-57 for the optimizers the shipped configs name (Ranger; plus the
+    torch.optim classes by name)."""
+    ocfg = dict(cfg.SOLVER.OPTIMIZER_CFG)
+    typ = ocfg.pop("type")
+    ocfg.pop("_delete_", None)
+    if typ.lower() == "ranger":
+        from .ranger import Ranger
+
+        return Ranger(params, **ocfg)
+    return getattr(torch.optim, typ)(params, **ocfg)

@@ -1,0 +1,127 @@
+"""ctypes binding of the C-ABI HIP library ``libgdrn_hip.so`` (declared in ``include/gdrn_hip.h``).
+
+The product path has no CPU fallback: if the library is missing or a call returns a non-zero
+status, ``GdrnHipError`` is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgdrn_hip.so")
+
+F32, BF16 = 0, 1
+P = C.c_void_p
+I = C.c_int
+LL = C.c_longlong
+F = C.c_float
+D = C.c_double
+
+
+class GdrnHipError(RuntimeError):
+    pass
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", P), ("w", P), ("y", P), ("bias", P), ("addend", P), ("stats", P),
+        ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
+        ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("add_cs", I),
+        ("KH", I), ("KW", I), ("stride", I), ("pad", I),
+        ("mode", I), ("act", I), ("out_f32", I),
+        ("M", I), ("w_rows", I), ("dtype", I),
+    ]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [
+        ("x", P), ("dy", P), ("dw", P),
+        ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
+        ("Ho", I), ("Wo", I), ("Cout", I), ("dy_cs", I),
+        ("KH", I), ("KW", I), ("stride", I), ("pad", I),
+        ("M", I), ("dtype", I), ("splits", I), ("variant", I),
+    ]
+
+
+class PoseParams(C.Structure):
+    _fields_ = [
+        ("fc", P), ("fs", I), ("cams", P), ("centers", P), ("whs", P), ("ratios", P), ("extents", P),
+        ("gt_rot", P), ("gt_trans", P), ("gt_trans_ratio", P), ("points", P), ("npts", I),
+        ("sym", P), ("sym_count", P), ("Kmax", I), ("N", I), ("train", I),
+        ("rot", P), ("trans", P), ("losses", P), ("dfc", P), ("vis", P),
+    ]
+
+
+# name -> argtypes (all return int status, except the two tile queries which return ints too)
+_SIGS = {
+    "gdrn_version": [],
+    "gdrn_device_info": [I, C.c_char_p, C.POINTER(I), C.c_char_p],
+    "gdrn_conv_gemm": [C.POINTER(ConvParams), P],
+    "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
+    "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],
+    "gdrn_conv_wgrad": [C.POINTER(WgradParams), P],
+    "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
+    "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],
+    "gdrn_pack_stem_w": [P, P, I, P],
+    "gdrn_unpack_stem_w": [P, P, P],
+    "gdrn_pack_image": [P, P, I, I, I, I, I, I, P],
+    "gdrn_cast_from_f32": [P, P, LL, I, P],
+    "gdrn_cast_to_f32": [P, P, LL, I, P],
+    "gdrn_nhwc_to_nchw_f32": [P, I, I, I, P, I, I, I, P],
+    "gdrn_bn_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P, P, P],
+    "gdrn_bn_eval_params": [P, P, P, P, F, I, P, P, P],
+    "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
+    "gdrn_bn_bwd_reduce": [P, P, P, P, P, LL, I, P, I, P],
+    "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
+    "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
+    "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
+    "gdrn_upsample2x_bwd": [P, P, I, I, I, I, I, P],
+    "gdrn_gn_relu_fwd": [P, P, P, P, P, I, I, I, I, F, I, P],
+    "gdrn_gn_relu_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "gdrn_leaky_bwd": [P, P, P, LL, I, P],
+    "gdrn_bias_grad": [P, I, I, I, P, I, P],
+    "gdrn_head_tail_fwd": [P, I, P, P, P, I, I, I, I, I, P],
+    "gdrn_map_loss_fwd": [P, I, P, P, P, P, I, I, I, P, P],
+    "gdrn_map_loss_finalize": [P, I, I, P, P],
+    "gdrn_head_tail_bwd": [P, I, P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "gdrn_pose_loss": [C.POINTER(PoseParams), P],
+    "gdrn_combine3": [P, P, P, I, P],
+    "gdrn_ranger_step": [P, P, P, P, P, I, I, I, F, F, F, F, F, F, I, I, F, P],
+}
+
+EXPORTS = tuple(_SIGS.keys())
+_lib = None
+
+
+def lib_path():
+    return LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises GdrnHipError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GdrnHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = I
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        names = {-1: "invalid argument", -2: "unsupported shape", -3: "launch failure"}
+        raise GdrnHipError(f"libgdrn_hip: {what} failed: {names.get(status, status)}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()

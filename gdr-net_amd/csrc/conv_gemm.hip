@@ -1,0 +1,337 @@
+// Implicit-GEMM gather convolution on MFMA for gfx950 -- forward conv, data-gradient and transposed
+// (stride-2) convolution of the GDR-Net RoI path, NHWC, fp32 accumulate.
+//
+//   y[m][co] = act( sum_{tap} sum_{c<Cin} X[pix(m,tap)][c] * Wp[co][tap][c]  (+ bias[co]) (+ addend[m][co]) )
+//
+// Replaces the ATen/cuDNN convolutions the reference dispatches at resnet_backbone.py:23,69-80 (via
+// torchvision BasicBlock), cdpn_rot_head_region.py:81-135 (ConvTranspose2d + Conv2d) and
+// conv_pnp_net.py:76-92 (Conv2d + Linear) -- forward, and the data-gradient of each in backward.
+//
+// Tile: BM output pixels x BN output channels per 256-thread workgroup (4 waves, 2x2), K staged in
+// 128-byte rows (64 bf16 / 32 fp32 per stage) through double-buffered, XOR-swizzled LDS.  Register
+// staging (global -> VGPR -> LDS) is used on purpose: it lets out-of-image taps be zero-filled and
+// keeps the door open for fusing the producer's BN-apply+ReLU into the operand load.
+// MFMA: v_mfma_f32_16x16x32_bf16 (T = bf16) / v_mfma_f32_16x16x4_f32 (T = float; exact fp32).
+// The weight rows feed the MFMA "A" operand and the pixel rows the "B" operand, so each lane ends up
+// with 4 consecutive output channels of one pixel (8/16-byte stores, per-channel BN statistics by a
+// 16-lane butterfly).
+#include "common.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+constexpr int ROWB = 128;  // bytes of K per LDS row per stage
+
+template <typename T>
+__device__ __forceinline__ f32x4_t mma_step(uint4 a, uint4 b, f32x4_t c);
+
+template <>
+__device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ f32x4_t mma_step<float>(uint4 a, uint4 b, f32x4_t c) {
+    // lane group g holds k = 4g..4g+3 of this 16-wide k-step for BOTH operands; the four MFMAs below
+    // therefore cover k = {j, 4+j, 8+j, 12+j} for j = 0..3 -- every k exactly once.
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const gdrn_conv_params p) {
+    constexpr int EPS = ROWB / (int)sizeof(T);  // elements of K per stage row
+    constexpr int A_LD = BN / 32;               // weight-tile 16B loads per thread
+    constexpr int B_LD = BM / 32;               // pixel-tile 16B loads per thread
+    constexpr int WM = BM / 2, WN = BN / 2;     // per-wave tile
+    constexpr int FM = WM / 16, FN = WN / 16;   // 16x16 fragments per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_taps = reinterpret_cast<int*>(smem);                 // [64] valid taps + [64]=count
+    unsigned char* sW = smem + 512;                              // 2 stages x BN rows x 128 B
+    unsigned char* sX = sW + 2 * BN * ROWB;                      // 2 stages x BM rows x 128 B
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, r16 = lane & 15;
+
+    const int NT = (p.Cout + BN - 1) / BN;
+    const int mt = blockIdx.x / NT, nt = blockIdx.x % NT;
+    const int co0 = nt * BN;
+
+    // ---- tile -> pixel mapping -------------------------------------------------------------
+    int cls = 0, row0;
+    int Hc = p.Ho, Wc = p.Wo, Mrows = p.M;
+    if (p.mode == 1) {
+        Hc = p.Ho >> 1; Wc = p.Wo >> 1;
+        const int tpc = (p.M + BM - 1) / BM;
+        cls = mt / tpc;
+        row0 = (mt % tpc) * BM;
+    } else {
+        row0 = mt * BM;
+    }
+    const int py = cls >> 1, px = cls & 1;
+
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+            const int ky = t / p.KW, kx = t % p.KW;
+            bool ok = true;
+            if (p.mode == 1) ok = (((py + p.pad - ky) & 1) == 0) && (((px + p.pad - kx) & 1) == 0);
+            if (ok) s_taps[n++] = t;
+        }
+        s_taps[64] = n;
+    }
+
+    const int seg = tid & 7, lrow = tid >> 3;
+    const int pseg = seg ^ (lrow & 7);  // swizzled 16B slot inside the 128B LDS row (row&7 == lrow&7)
+
+    // pixel rows this thread stages
+    int pbase[B_LD], pya[B_LD], pxa[B_LD];
+    bool pval[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int r = row0 + lrow + 32 * i;
+        pval[i] = r < Mrows;
+        const int rr = pval[i] ? r : 0;
+        const int n = rr / (Hc * Wc);
+        const int rem = rr - n * (Hc * Wc);
+        int oy = rem / Wc, ox = rem - (rem / Wc) * Wc;
+        if (p.mode == 1) {
+            pya[i] = 2 * oy + py + p.pad;  // iy = (pya - ky) >> 1
+            pxa[i] = 2 * ox + px + p.pad;
+        } else {
+            pya[i] = oy * p.stride - p.pad;  // iy = pya + ky
+            pxa[i] = ox * p.stride - p.pad;
+        }
+        pbase[i] = n * p.Hi * p.Wi;
+    }
+
+    __syncthreads();
+    const int ntap = s_taps[64];
+    const int kch = p.Cin / EPS;
+    const int nstage = ntap * kch;
+    const int KK = p.KH * p.KW;
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 rw[A_LD], rx[B_LD];
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    const char* wg = reinterpret_cast<const char*>(p.w);
+
+    auto load_stage = [&](int s) {
+        const int ti = s / kch, kc = s - ti * kch;
+        const int tap = s_taps[ti];
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int co = co0 + lrow + 32 * i;  // weight buffer is zero-padded to a multiple of BN rows
+            const size_t off = ((size_t)(co * KK + tap) * p.Cin + (size_t)kc * EPS) * sizeof(T) + seg * 16;
+            rw[i] = *reinterpret_cast<const uint4*>(wg + off);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            int iy, ix;
+            if (p.mode == 1) { iy = (pya[i] - ky) >> 1; ix = (pxa[i] - kx) >> 1; }
+            else { iy = pya[i] + ky; ix = pxa[i] + kx; }
+            const bool ok = pval[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t off = ((size_t)(pbase[i] + iy * p.Wi + ix) * p.x_cs + (size_t)kc * EPS) * sizeof(T) + seg * 16;
+                v = *reinterpret_cast<const uint4*>(xg + off);
+            }
+            rx[i] = v;
+        }
+    };
+    auto write_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<uint4*>(sW + (size_t)buf * BN * ROWB + (lrow + 32 * i) * ROWB + pseg * 16) = rw[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            *reinterpret_cast<uint4*>(sX + (size_t)buf * BM * ROWB + (lrow + 32 * i) * ROWB + pseg * 16) = rx[i];
+    };
+
+    if (nstage > 0) {
+        load_stage(0);
+        write_stage(0);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) load_stage(s + 1);
+        const unsigned char* aW = sW + (size_t)buf * BN * ROWB;
+        const unsigned char* aX = sX + (size_t)buf * BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fa[FN], fb[FM];
+            const int lseg = ks * 4 + g;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int row = wn * WN + a * 16 + r16;
+                fa[a] = *reinterpret_cast<const uint4*>(aW + row * ROWB + ((lseg ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int row = wm * WM + b * 16 + r16;
+                fb[b] = *reinterpret_cast<const uint4*>(aX + row * ROWB + ((lseg ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = mma_step<T>(fa[a], fb[b], acc[a][b]);
+        }
+        if (s + 1 < nstage) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    // lane holds D[i = g*4+j][col = r16] of fragment (a,b): channel co0 + wn*WN + a*16 + g*4 + j,
+    // pixel row wm*WM + b*16 + r16.
+    if (p.stats != nullptr) {
+        float* red = reinterpret_cast<float*>(smem + 512);  // [2 (wm)][BN][2]
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) { const float v = acc[a][b][j]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (r16 == 0) {
+                    const int c = wn * WN + a * 16 + g * 4 + j;
+                    red[(wm * BN + c) * 2 + 0] = s1;
+                    red[(wm * BN + c) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < p.Cout) {
+            const float s1 = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+            const float s2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+            p.stats[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = s1;
+            p.stats[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = s2;
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int r = row0 + wm * WM + b * 16 + r16;
+        if (r >= Mrows) continue;
+        size_t orow;
+        if (p.mode == 1) {
+            const int n = r / (Hc * Wc);
+            const int rem = r - n * (Hc * Wc);
+            const int yc = rem / Wc, xc = rem - yc * Wc;
+            orow = (size_t)(n * p.Ho + 2 * yc + py) * p.Wo + 2 * xc + px;
+        } else {
+            orow = (size_t)r;
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int c0 = co0 + wn * WN + a * 16 + g * 4;
+            if (c0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
+            const bool full = (c0 + 3 < p.Cout);
+            if (p.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) v[j] += p.bias[c0 + j];
+            }
+            if (p.addend != nullptr) {
+                const T* ap = reinterpret_cast<const T*>(p.addend) + orow * p.add_cs + c0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) v[j] += ld1<T>(ap + j);
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.1f * v[j];
+            }
+            if (p.out_f32 || sizeof(T) == 4) {
+                float* yp = reinterpret_cast<float*>(p.y) + orow * p.y_cs + c0;
+                if (full) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) yp[j] = v[j];
+            } else {
+                bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + orow * p.y_cs + c0;
+                if (full) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) yp[j] = f2bf(v[j]);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch(const gdrn_conv_params& p, hipStream_t st) {
+    constexpr size_t smem = 512 + 2 * (size_t)(BM + BN) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GDRN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int NT = cdiv(p.Cout, BN);
+    const int MT = (p.mode == 1) ? 4 * cdiv(p.M, BM) : cdiv(p.M, BM);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(MT * NT), dim3(256), smem, st, p);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+}  // namespace
+
+extern "C" int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn) {
+    if (!p || !bm || !bn) return GDRN_ERR_ARG;
+    // BN: 64 for <= 64 output channels, else 128.  BM: 128 unless that leaves the chip mostly idle.
+    *bn = (p->Cout <= 64) ? 64 : 128;
+    const int nt = cdiv(p->Cout, *bn);
+    const int rows = (p->mode == 1) ? 4 * p->M : p->M;
+    *bm = (cdiv(rows, 128) * nt >= 512) ? 128 : 64;
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_conv_stats_rows(const gdrn_conv_params* p) {
+    int bm, bn;
+    if (gdrn_conv_tile(p, &bm, &bn) != GDRN_OK) return GDRN_ERR_ARG;
+    return (p->mode == 1) ? 4 * cdiv(p->M, bm) : cdiv(p->M, bm);
+}
+
+extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
+    if (!pp || !pp->x || !pp->w || !pp->y) return GDRN_ERR_ARG;
+    const gdrn_conv_params& p = *pp;
+    const int esz = (p.dtype == GDRN_DT_BF16) ? 2 : 4;
+    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    if (p.Cin <= 0 || (p.Cin * esz) % ROWB != 0) return GDRN_ERR_SHAPE;
+    if ((p.x_cs * esz) % 8 != 0 || p.KH * p.KW > 64 || p.KH * p.KW < 1) return GDRN_ERR_SHAPE;
+    if (p.mode == 1 && (p.stride != 2 || (p.Ho & 1) || (p.Wo & 1))) return GDRN_ERR_SHAPE;
+    if (p.mode != 0 && p.mode != 1) return GDRN_ERR_ARG;
+    if (p.M <= 0 || p.Cout <= 0 || (p.y_cs & 3)) return GDRN_ERR_SHAPE;
+    if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
+    int bm, bn;
+    gdrn_conv_tile(pp, &bm, &bn);
+    if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.dtype == GDRN_DT_BF16) {
+        if (bn == 64) return bm == 128 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 64, 64>(p, st);
+        return bm == 128 ? launch<bf16_t, 128, 128>(p, st) : launch<bf16_t, 64, 128>(p, st);
+    } else {
+        if (bn == 64) return bm == 128 ? launch<float, 128, 64>(p, st) : launch<float, 64, 64>(p, st);
+        return bm == 128 ? launch<float, 128, 128>(p, st) : launch<float, 64, 128>(p, st);
+    }
+}

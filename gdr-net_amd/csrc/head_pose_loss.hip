@@ -1,0 +1,473 @@
+// Head tail (slice / softmax / concat / extent scaling), map losses, pose decode and pose losses of
+// the GDR-Net RoI path for gfx950 -- forward and backward, no host synchronisation.
+// Reference call sites: GDRN.py:156-169 (glue), conv_pnp_net.py:121-125, GDRN.py:345-471 (losses),
+// rot_reps.py:34-49, pose_from_pred_centroid_z.py:52-227, core/utils/utils.py:39-94,208-236,
+// pose_utils.py:323-370,430-482, pm_loss.py:82-114, lib/pysixd/misc.py:930-949, pose_error.py:400-425.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ head tail fwd
+// one wave per pixel: lane j <-> region class j+1
+template <typename T>
+__global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restrict__ head, int hs,
+                                                            const float* __restrict__ coord2d,
+                                                            const float* __restrict__ extents, T* __restrict__ pnp, int pcs,
+                                                            int N, int HW, int nreg) {
+    const int lane = threadIdx.x & 63;
+    const long long M = (long long)N * HW;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long m = wave0; m < M; m += nwaves) {
+        const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+        const float* h = head + m * hs;
+        const float r = (lane < nreg) ? h[5 + lane] : -INFINITY;
+        const float mx = wave_max(r);
+        const float e = (lane < nreg) ? expf(r - mx) : 0.f;
+        const float s = wave_sum(e);
+        T* o = pnp + m * pcs;
+        if (lane < nreg) st1<T>(o + 5 + lane, e / s);
+        if (lane < 3) st1<T>(o + lane, (h[1 + lane] - 0.5f) * extents[n * 3 + lane]);
+        else if (lane < 5) st1<T>(o + lane, coord2d[((size_t)n * 2 + (lane - 3)) * HW + pix]);
+        for (int c = 5 + nreg + lane; c < pcs; c += 64) st1<T>(o + c, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ map losses fwd
+__global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restrict__ head, int hs,
+                                                           const float* __restrict__ gt_xyz,
+                                                           const float* __restrict__ mvis, const float* __restrict__ mtr,
+                                                           const long long* __restrict__ gt_region, int N, int HW, int nreg,
+                                                           double* acc) {
+    __shared__ float red[6][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long M = (long long)N * HW;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // lane-0 accumulators
+    for (long long m = wave0; m < M; m += nwaves) {
+        const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+        const float* h = head + m * hs;
+        const float mv = mvis[m];
+        // CE over nreg+1 classes of logits region*mv; lane j <-> class j, lane 0 also class 64 (if nreg == 64)
+        const int ncls = nreg + 1;
+        const float z0 = (lane < ncls) ? h[4 + lane] * mv : -INFINITY;
+        const float z1 = (lane + 64 < ncls) ? h[4 + 64 + lane] * mv : -INFINITY;
+        const float mx = wave_max(fmaxf(z0, z1));
+        float e = 0.f;
+        if (lane < ncls) e += expf(z0 - mx);
+        if (lane + 64 < ncls) e += expf(z1 - mx);
+        const float se = wave_sum(e);
+        const int tgt = (int)(gt_region[m] * (long long)mv);
+        float zt = 0.f;
+        if (tgt == lane) zt = z0;
+        if (tgt == lane + 64) zt = z1;
+        zt = wave_sum(zt);
+        if (lane == 0) {
+            a[4] += (logf(se) + mx) - zt;
+            a[5] += mv;
+            a[3] += fabsf(h[0] - mtr[m]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] += fabsf(h[1 + c] * mv - gt_xyz[((size_t)n * 3 + c) * HW + pix] * mv);
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[k][wave] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double v = (double)red[threadIdx.x][0] + (double)red[threadIdx.x][1] + (double)red[threadIdx.x][2] + (double)red[threadIdx.x][3];
+        unsafeAtomicAdd(&acc[threadIdx.x], v);
+    }
+}
+
+__global__ void map_loss_finalize_kernel(const double* acc, double npix, float* losses) {
+    if (threadIdx.x == 0) {
+        const double den = acc[5] < 1.0 ? 1.0 : acc[5];
+        losses[0] = (float)(acc[0] / den);
+        losses[1] = (float)(acc[1] / den);
+        losses[2] = (float)(acc[2] / den);
+        losses[3] = (float)(acc[3] / npix);
+        losses[4] = (float)(acc[4] / den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ head tail bwd
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restrict__ head, int hs, const T* __restrict__ pnp,
+                                                            const T* __restrict__ dpnp, int pcs,
+                                                            const float* __restrict__ extents,
+                                                            const float* __restrict__ gt_xyz, const float* __restrict__ mvis,
+                                                            const float* __restrict__ mtr,
+                                                            const long long* __restrict__ gt_region,
+                                                            const double* __restrict__ acc, const float* __restrict__ gw,
+                                                            T* __restrict__ dhead, int dcs, int N, int HW, int nreg) {
+    const int lane = threadIdx.x & 63;
+    const long long M = (long long)N * HW;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const float inv_den = (float)(1.0 / (acc[5] < 1.0 ? 1.0 : acc[5]));
+    const float inv_np = (float)(1.0 / (double)M);
+    const float gx[3] = {gw[0], gw[1], gw[2]};
+    const float gmask = gw[3], gce = gw[4];
+    const int ncls = nreg + 1;
+    for (long long m = wave0; m < M; m += nwaves) {
+        const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+        const float* h = head + m * hs;
+        const float mv = mvis[m];
+        // CE gradient: mv * (softmax(region*mv)_k - onehot_k) / den
+        const float z0 = (lane < ncls) ? h[4 + lane] * mv : -INFINITY;
+        const float z1 = (lane + 64 < ncls) ? h[4 + 64 + lane] * mv : -INFINITY;
+        const float mx = wave_max(fmaxf(z0, z1));
+        const float e0 = (lane < ncls) ? expf(z0 - mx) : 0.f;
+        const float e1 = (lane + 64 < ncls) ? expf(z1 - mx) : 0.f;
+        const float se = wave_sum(e0 + e1);
+        const int tgt = (int)(gt_region[m] * (long long)mv);
+        float d0 = gce * mv * inv_den * (e0 / se - (tgt == lane ? 1.f : 0.f));        // class lane
+        float d1 = gce * mv * inv_den * (e1 / se - (tgt == lane + 64 ? 1.f : 0.f));   // class lane+64
+        // attention softmax chain: region class j+1 <- pnp channel 5+j
+        float dsm = 0.f;
+        if (dpnp != nullptr) {
+            const float s = (lane < nreg) ? ld1<T>(pnp + m * pcs + 5 + lane) : 0.f;
+            const float ds = (lane < nreg) ? ld1<T>(dpnp + m * pcs + 5 + lane) : 0.f;
+            const float dot = wave_sum(s * ds);
+            dsm = s * (ds - dot);  // gradient for class lane+1
+        }
+        // shift dsm from "lane j <-> class j+1" to "lane j <-> class j": class k takes dsm of lane k-1
+        float dsm_k = __shfl_up(dsm, 1, 64);
+        if (lane == 0) dsm_k = 0.f;
+        const float dsm_64 = __shfl(dsm, 63, 64);  // class 64 <- lane 63
+        T* o = dhead + m * dcs;
+        if (lane < ncls) st1<T>(o + 4 + lane, d0 + dsm_k);
+        if (lane + 64 < ncls) st1<T>(o + 4 + 64 + lane, d1 + dsm_64);
+        if (lane == 0) {
+            st1<T>(o + 0, gmask * inv_np * sgn(h[0] - mtr[m]));
+        } else if (lane < 4) {
+            const int c = lane - 1;
+            const float gt = gt_xyz[((size_t)n * 3 + c) * HW + pix];
+            float d = gx[c] * mv * inv_den * sgn(h[1 + c] * mv - gt * mv);
+            if (dpnp != nullptr) d += ld1<T>(dpnp + m * pcs + c) * extents[n * 3 + c];
+            st1<T>(o + lane, d);
+        }
+        for (int c = 4 + ncls + lane; c < dcs; c += 64) st1<T>(o + c, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ pose decode
+struct D9 {  // forward-mode dual number with 9 partials (rot6d[6], t_[3])
+    float v;
+    float d[9];
+};
+__device__ __forceinline__ D9 dconst(float c) { D9 r; r.v = c; for (int i = 0; i < 9; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ D9 dvar(float v, int k) { D9 r = dconst(v); r.d[k] = 1.f; return r; }
+__device__ __forceinline__ D9 operator+(const D9& a, const D9& b) { D9 r; r.v = a.v + b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D9 operator-(const D9& a, const D9& b) { D9 r; r.v = a.v - b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D9 operator*(const D9& a, const D9& b) { D9 r; r.v = a.v * b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D9 operator*(const D9& a, float s) { D9 r; r.v = a.v * s; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D9 operator+(const D9& a, float s) { D9 r = a; r.v += s; return r; }
+__device__ __forceinline__ D9 operator/(const D9& a, const D9& b) {
+    D9 r; const float ib = 1.f / b.v; r.v = a.v * ib;
+    for (int i = 0; i < 9; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+__device__ __forceinline__ D9 dfun(const D9& a, float f, float df) { D9 r; r.v = f; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * df; return r; }
+__device__ __forceinline__ D9 dsqrt(const D9& a) { const float s = sqrtf(a.v); return dfun(a, s, s > 0.f ? 0.5f / s : 0.f); }
+__device__ __forceinline__ D9 dacos(const D9& a) { const float q = 1.f - a.v * a.v; return dfun(a, acosf(a.v), q > 0.f ? -1.f / sqrtf(q) : 0.f); }
+__device__ __forceinline__ D9 dsin(const D9& a) { return dfun(a, sinf(a.v), cosf(a.v)); }
+__device__ __forceinline__ D9 dcos(const D9& a) { return dfun(a, cosf(a.v), -sinf(a.v)); }
+
+template <typename S>
+__device__ __forceinline__ void cross3(const S* a, const S* b, S* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// F.normalize(v, p=2, dim=1, eps=1e-12): v / max(||v||, eps)
+__device__ __forceinline__ void normalize3(const D9* v, D9* o) {
+    D9 n = dsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n.v < 1e-12f) n = dconst(1e-12f);
+    for (int i = 0; i < 3; ++i) o[i] = v[i] / n;
+}
+
+// train-mode decode (differentiable): R_ego[9] row-major, t[3]
+__device__ void decode_train(const D9* in, const float* K, const float* ctr, const float* wh, float ratio, D9* R, D9* t) {
+    const float eps = 1e-4f;
+    D9 x[3], y[3], z[3], zr[3];
+    normalize3(in, x);            // x = normalize(a1)
+    cross3(x, in + 3, zr);        // z = normalize(x x a2)
+    normalize3(zr, z);
+    cross3(z, x, y);              // y = z x x ; R_allo = [x y z] as columns
+    D9 cx = in[6] * wh[0] + ctr[0];
+    D9 cy = in[7] * wh[1] + ctr[1];
+    D9 zz = in[8] * ratio;
+    t[2] = zz;
+    // written as in the reference: z * (cx - px) / fx
+    t[0] = (zz * (cx + (-K[2]))) / dconst(K[0]);
+    t[1] = (zz * (cy + (-K[5]))) / dconst(K[4]);
+    D9 nt = dsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + eps;
+    D9 ray[3] = {t[0] / nt, t[1] / nt, t[2] / nt};
+    D9 angle = dacos(ray[2]);
+    // axis = cross((0,0,1), ray) = (-ray_y, ray_x, 0)
+    D9 ax[3] = {dconst(0.f) - ray[1], ray[0], dconst(0.f)};
+    D9 na = dsqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + eps;
+    D9 half = angle * 0.5f;
+    D9 sh = dsin(half);
+    D9 q[4] = {dcos(half), (ax[0] / na) * sh, (ax[1] / na) * sh, (ax[2] / na) * sh};
+    D9 nq = dsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    D9 qw = q[0] / nq, qx = q[1] / nq, qy = q[2] / nq, qz = q[3] / nq;
+    D9 X = qx * 2.f, Y = qy * 2.f, Z = qz * 2.f;
+    D9 wX = qw * X, wY = qw * Y, wZ = qw * Z, xX = qx * X, xY = qx * Y, xZ = qx * Z, yY = qy * Y, yZ = qy * Z, zZ = qz * Z;
+    D9 one = dconst(1.f);
+    D9 Q[9] = {one - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, one - (xX + zZ), yZ - wX, xZ - wY, yZ + wX, one - (xX + yY)};
+    // R_allo[r][c]: column 0 = x, 1 = y, 2 = z
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const D9* col = (c == 0) ? x : ((c == 1) ? y : z);
+            R[r * 3 + c] = Q[r * 3 + 0] * col[0] + Q[r * 3 + 1] * col[1] + Q[r * 3 + 2] * col[2];
+        }
+}
+
+// test-mode decode (reference: numpy float64 loop, no eps, `if angle > 0`)
+__device__ void decode_test(const float* in, const float* K, const float* ctr, const float* wh, float ratio, float* R, float* t) {
+    // rot6d -> R_allo in fp32 exactly as train mode (torch ops), then fp64 allo->ego
+    float x[3], y[3], z[3], zr[3];
+    float n = fmaxf(sqrtf(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]), 1e-12f);
+    for (int i = 0; i < 3; ++i) x[i] = in[i] / n;
+    cross3(x, in + 3, zr);
+    n = fmaxf(sqrtf(zr[0] * zr[0] + zr[1] * zr[1] + zr[2] * zr[2]), 1e-12f);
+    for (int i = 0; i < 3; ++i) z[i] = zr[i] / n;
+    cross3(z, x, y);
+    const float cx = in[6] * wh[0] + ctr[0], cy = in[7] * wh[1] + ctr[1], zz = in[8] * ratio;
+    t[0] = zz * (cx - K[2]) / K[0];
+    t[1] = zz * (cy - K[5]) / K[4];
+    t[2] = zz;
+    const double tx = t[0], ty = t[1], tz = t[2];
+    const float nt32 = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);  // np.linalg.norm on float32
+    const float ray32[3] = {t[0] / nt32, t[1] / nt32, t[2] / nt32};
+    (void)tx; (void)ty; (void)tz;
+    double c = (double)ray32[2];
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double angle = acos(c);
+    double Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (angle > 0.0) {
+        double ax = -(double)ray32[1], ay = (double)ray32[0], az = 0.0;
+        const double na = sqrt(ax * ax + ay * ay + az * az);
+        ax /= na; ay /= na; az /= na;
+        const double cs = cos(angle), sn = sin(angle), C = 1.0 - cs;
+        Q[0] = ax * ax * C + cs;      Q[1] = ax * ay * C - az * sn; Q[2] = ax * az * C + ay * sn;
+        Q[3] = ay * ax * C + az * sn; Q[4] = ay * ay * C + cs;      Q[5] = ay * az * C - ax * sn;
+        Q[6] = az * ax * C - ay * sn; Q[7] = az * ay * C + ax * sn; Q[8] = az * az * C + cs;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) {
+            const float* col = (cc == 0) ? x : ((cc == 1) ? y : z);
+            R[r * 3 + cc] = (float)(Q[r * 3 + 0] * (double)col[0] + Q[r * 3 + 1] * (double)col[1] + Q[r * 3 + 2] * (double)col[2]);
+        }
+}
+
+__device__ double rot_err_deg(const double* A, const double* B) {  // pose_error.re: arccos((tr(A B^T)-1)/2)
+    double tr = 0.0;
+    for (int i = 0; i < 9; ++i) tr += A[i] * B[i];
+    if (tr > 3.0) tr = 3.0;
+    double c = 0.5 * (tr - 1.0);
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    return acos(c) * 57.29577951308232;
+}
+
+__global__ __launch_bounds__(256) void pose_loss_kernel(const gdrn_pose_params p) {
+    __shared__ float sR[9], sG[9], sT[3], sW;
+    __shared__ float red[10][4];
+    __shared__ float sS[10];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* in = p.fc + (size_t)n * p.fs;
+    const float* K = p.cams + n * 9;
+    const float* ctr = p.centers + n * 2;
+    const float* wh = p.whs + n * 2;
+    const float ratio = p.ratios[n];
+
+    D9 Rd[9], td[3];
+    if (tid == 0) {
+        float Rf[9], tf[3];
+        if (p.train) {
+            D9 v[9];
+            for (int k = 0; k < 9; ++k) v[k] = dvar(in[k], k);
+            decode_train(v, K, ctr, wh, ratio, Rd, td);
+            for (int k = 0; k < 9; ++k) Rf[k] = Rd[k].v;
+            for (int k = 0; k < 3; ++k) tf[k] = td[k].v;
+        } else {
+            decode_test(in, K, ctr, wh, ratio, Rf, tf);
+        }
+        for (int k = 0; k < 9; ++k) { sR[k] = Rf[k]; p.rot[n * 9 + k] = Rf[k]; }
+        for (int k = 0; k < 3; ++k) { sT[k] = tf[k]; p.trans[n * 3 + k] = tf[k]; }
+        if (p.gt_rot != nullptr) {
+            // closest symmetric ground truth (pose_utils.py:430-482), errors in fp64
+            double P[9], G0[9], best[9];
+            for (int k = 0; k < 9; ++k) { P[k] = Rf[k]; G0[k] = p.gt_rot[n * 9 + k]; best[k] = G0[k]; }
+            double best_err = rot_err_deg(P, G0);
+            const double err0 = best_err;
+            const int ns = (p.sym != nullptr && p.sym_count != nullptr) ? p.sym_count[n] : 0;
+            for (int s = 0; s < ns; ++s) {
+                const float* S = p.sym + ((size_t)n * p.Kmax + s) * 9;
+                double C[9];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) C[r * 3 + c] = G0[r * 3 + 0] * S[0 * 3 + c] + G0[r * 3 + 1] * S[1 * 3 + c] + G0[r * 3 + 2] * S[2 * 3 + c];
+                const double e = rot_err_deg(P, C);
+                if (e < best_err) { best_err = e; for (int k = 0; k < 9; ++k) best[k] = C[k]; }
+            }
+            for (int k = 0; k < 9; ++k) sG[k] = (float)best[k];
+            if (p.vis != nullptr) {
+                p.vis[n * 2 + 0] = (float)err0;
+                float te = 0.f;
+                if (p.gt_trans != nullptr)
+                    for (int k = 0; k < 3; ++k) { const float d = p.gt_trans[n * 3 + k] - tf[k]; te += d * d; }
+                p.vis[n * 2 + 1] = sqrtf(te);
+            }
+        }
+        if (p.extents != nullptr) sW = 1.f / fmaxf(fmaxf(p.extents[n * 3], p.extents[n * 3 + 1]), p.extents[n * 3 + 2]);
+    }
+    __syncthreads();
+    if (!p.train || p.gt_rot == nullptr || p.points == nullptr) return;
+
+    // point-matching loss: sum_p sum_a |w (R p - Rgt p)_a| and S[a][b] = sum_p sign(.)_a w p_b
+    float acc[10];
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    const float w = sW;
+    for (int i = tid; i < p.npts; i += 256) {
+        const float* pt = p.points + ((size_t)n * p.npts + i) * 3;
+        const float px = pt[0], py = pt[1], pz = pt[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float e = sR[a * 3] * px + sR[a * 3 + 1] * py + sR[a * 3 + 2] * pz;
+            const float g = sG[a * 3] * px + sG[a * 3 + 1] * py + sG[a * 3 + 2] * pz;
+            const float d = w * e - w * g;
+            acc[0] += fabsf(d);
+            const float s = sgn(d) * w;
+            acc[1 + a * 3 + 0] += s * px;
+            acc[1 + a * 3 + 1] += s * py;
+            acc[1 + a * 3 + 2] += s * pz;
+        }
+    }
+    for (int k = 0; k < 10; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[k][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 10) sS[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    __syncthreads();
+    if (tid == 0) {
+        const float inv = 1.f / ((float)p.N * (float)p.npts);  // 3 * mean over (N, npts, 3)
+        unsafeAtomicAdd(&p.losses[0], sS[0] * inv);
+        float lc = 0.f;
+        const float* gtr = p.gt_trans_ratio + n * 3;
+        lc = fabsf(in[6] - gtr[0]) + fabsf(in[7] - gtr[1]);
+        unsafeAtomicAdd(&p.losses[1], lc / (2.f * p.N));
+        unsafeAtomicAdd(&p.losses[2], fabsf(in[8] - gtr[2]) / (float)p.N);
+        if (p.dfc != nullptr) {
+            float* d0 = p.dfc + ((size_t)0 * p.N + n) * p.fs;
+            float* d1 = p.dfc + ((size_t)1 * p.N + n) * p.fs;
+            float* d2 = p.dfc + ((size_t)2 * p.N + n) * p.fs;
+            for (int k = 0; k < p.fs; ++k) { d0[k] = 0.f; d1[k] = 0.f; d2[k] = 0.f; }
+            for (int k = 0; k < 9; ++k) {
+                float g = 0.f;
+                for (int ab = 0; ab < 9; ++ab) g += sS[1 + ab] * Rd[ab].d[k];
+                d0[k] = g * inv;
+            }
+            d1[6] = sgn(in[6] - gtr[0]) / (2.f * p.N);
+            d1[7] = sgn(in[7] - gtr[1]) / (2.f * p.N);
+            d2[8] = sgn(in[8] - gtr[2]) / (float)p.N;
+        }
+    }
+}
+
+__global__ void combine3_kernel(const float* in, const float* w, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[0] * in[i] + w[1] * in[n + i] + w[2] * in[2 * n + i];
+}
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
+                                  int N, int HW, int nreg, int dtype, void* stream) {
+    if (!head || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0 || nreg < 1 || nreg > 64 || hs < nreg + 5 ||
+        pcs < nreg + 5)
+        return GDRN_ERR_ARG;
+    const long long M = (long long)N * HW;
+    const int blocks = (int)std::min<long long>((M + 3) / 4, 4096);
+    if (dtype == GDRN_DT_F32)
+        hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
+    else if (dtype == GDRN_DT_BF16)
+        hipLaunchKernelGGL(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
+    else
+        return GDRN_ERR_ARG;
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                                 const long long* gt_region, int N, int HW, int nreg, double* acc, void* stream) {
+    if (!head || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || N <= 0 || HW <= 0 || nreg < 1 || nreg > 64)
+        return GDRN_ERR_ARG;
+    if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    const long long M = (long long)N * HW;
+    const int blocks = (int)std::min<long long>((M + 3) / 4, 2048);
+    hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* losses, void* stream) {
+    if (!acc || !losses) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(map_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, acc, (double)N * (double)HW, losses);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in, const void* d_pnp_in, int pcs,
+                                  const float* extents, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                                  const long long* gt_region, const double* acc, const float* gw, void* d_head, int dcs, int N,
+                                  int HW, int nreg, int dtype, void* stream) {
+    if (!head || !extents || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || !gw || !d_head || N <= 0 ||
+        HW <= 0 || nreg < 1 || nreg > 64 || dcs < nreg + 5)
+        return GDRN_ERR_ARG;
+    if (d_pnp_in != nullptr && pnp_in == nullptr) return GDRN_ERR_ARG;
+    const long long M = (long long)N * HW;
+    const int blocks = (int)std::min<long long>((M + 3) / 4, 4096);
+    if (dtype == GDRN_DT_F32)
+        hipLaunchKernelGGL(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
+                           (const float*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
+                           (float*)d_head, dcs, N, HW, nreg);
+    else if (dtype == GDRN_DT_BF16)
+        hipLaunchKernelGGL(head_tail_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in,
+                           (const bf16_t*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
+                           (bf16_t*)d_head, dcs, N, HW, nreg);
+    else
+        return GDRN_ERR_ARG;
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_pose_loss(const gdrn_pose_params* p, void* stream) {
+    if (!p || !p->fc || !p->cams || !p->centers || !p->whs || !p->ratios || !p->rot || !p->trans || p->N <= 0 || p->fs < 9)
+        return GDRN_ERR_ARG;
+    if (p->train && (!p->losses || !p->gt_rot || !p->gt_trans_ratio || !p->points || !p->extents || p->npts <= 0))
+        return GDRN_ERR_ARG;
+    if (p->losses && hipMemsetAsync(p->losses, 0, 3 * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    hipLaunchKernelGGL(pose_loss_kernel, dim3(p->N), dim3(256), 0, ST, *p);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_combine3(const float* in, const float* w, float* out, int n, void* stream) {
+    if (!in || !w || !out || n <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(combine3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, in, w, out, n);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}

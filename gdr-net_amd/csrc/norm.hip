@@ -1,0 +1,668 @@
+// HBM-bound normalisation / pooling / resampling kernels of the GDR-Net RoI path for gfx950:
+// BatchNorm2d (train + eval) with fused ReLU / residual / max-pool, GroupNorm+ReLU, bilinear x2
+// upsampling (align_corners), LeakyReLU backward, bias gradients.  NHWC, 16-byte vector accesses,
+// fp32 arithmetic, storage type T = float | bf16.  Reference call sites: see include/gdrn_hip.h.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ BN
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                          const float* gamma, const float* beta, float* running_mean,
+                                                          float* running_var, long long* nbt, float momentum, float eps,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (ch < C) {
+        for (int r = rl; r < rows; r += 16) {
+            s1 += (double)partial[((size_t)r * 2 + 0) * C + ch];
+            s2 += (double)partial[((size_t)r * 2 + 1) * C + ch];
+        }
+    }
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && ch < C) {
+        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        mean[ch] = (float)m;
+        invstd[ch] = (float)is;
+        const float sc = gamma[ch] * (float)is;
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - (float)m * sc;
+        if (running_mean != nullptr) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res,
+                                                       T* __restrict__ y, long long nvec, int C, int relu) {
+    constexpr int V = Vec16<T>::VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * V) % C);
+        float v[V], r[V];
+        Vec16<T>::load(x + i * V, v);
+        if (res != nullptr) Vec16<T>::load(res + i * V, r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float t = v[j] * scale[c + j] + shift[c + j];
+            if (res != nullptr) t += r[j];
+            if (relu) t = fmaxf(t, 0.f);
+            v[j] = t;
+        }
+        Vec16<T>::store(y + i * V, v);
+    }
+}
+
+// per-channel sums of g and g*xhat; rows strided over threads, LDS + global fp32 atomics
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long long npix, int C,
+                                                            float* sums, int rows_per_block) {
+    constexpr int V = Vec16<T>::VEC;
+    __shared__ float acc[2 * 512];
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    float s1[V], s2[V], mu[V], is[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[cv * V + j]; is[j] = invstd[cv * V + j]; }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(npix, r0 + rows_per_block);
+    if (rl < rpp) {
+        for (long long r = r0 + rl; r < r1; r += rpp) {
+            float g[V], xv[V], yv[V];
+            Vec16<T>::load(dy + r * C + cv * V, g);
+            Vec16<T>::load(x + r * C + cv * V, xv);
+            if (ym != nullptr) Vec16<T>::load(ym + r * C + cv * V, yv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float gg = g[j];
+                if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
+                s1[j] += gg;
+                s2[j] += gg * (xv[j] - mu[j]) * is[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            atomicAdd(&acc[cv * V + j], s1[j]);
+            atomicAdd(&acc[C + cv * V + j], s2[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) unsafeAtomicAdd(&sums[i], acc[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, long long nvec, int C, float inv_n,
+                                                           T* __restrict__ dx, T* __restrict__ gout, float* dgamma,
+                                                           float* dbeta) {
+    constexpr int V = Vec16<T>::VEC;
+    if (blockIdx.x == 0 && dgamma != nullptr) {
+        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * V) % C);
+        float g[V], xv[V], yv[V], o[V];
+        Vec16<T>::load(dy + i * V, g);
+        Vec16<T>::load(x + i * V, xv);
+        if (ym != nullptr) Vec16<T>::load(ym + i * V, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float gg = g[j];
+            if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
+            g[j] = gg;
+            const float is = invstd[c + j];
+            const float xh = (xv[j] - mean[c + j]) * is;
+            o[j] = gamma[c + j] * is * (gg - sums[c + j] * inv_n - xh * sums[C + c + j] * inv_n);
+        }
+        Vec16<T>::store(dx + i * V, o);
+        if (gout != nullptr) Vec16<T>::store(gout + i * V, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ stem pool
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ y,
+                                                                  unsigned char* __restrict__ idx, int N, int H, int W, int C) {
+    constexpr int V = Vec16<T>::VEC;
+    const int Ho = H / 2, Wo = W / 2, cvn = C / V;
+    const long long total = (long long)N * Ho * Wo * cvn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long long t = i / cvn;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best[V]; int bi[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float v[V];
+                Vec16<T>::load(x + ((size_t)(n * H + iy) * W + ix) * C + cv * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float a = fmaxf(v[j] * scale[cv * V + j] + shift[cv * V + j], 0.f);
+                    if (a > best[j]) { best[j] = a; bi[j] = ky * 3 + kx; }
+                }
+            }
+        }
+        Vec16<T>::store(y + i * V, best);
+        unsigned char* ip = idx + i * V;
+        if (V == 8) {
+            uint2 pk;
+            pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+            pk.y = bi[4 % V] | (bi[5 % V] << 8) | (bi[6 % V] << 16) | (bi[7 % V] << 24);
+            *reinterpret_cast<uint2*>(ip) = pk;
+        } else {
+            *reinterpret_cast<uint32_t*>(ip) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                          const T* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ g, int N, int H,
+                                                          int W, int C) {
+    constexpr int V = Vec16<T>::VEC;
+    const int Ho = H / 2, Wo = W / 2, cvn = C / V;
+    const long long total = (long long)N * H * W * cvn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long long t = i / cvn;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[V], xv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        // windows containing iy: oy with 2*oy-1 <= iy <= 2*oy+1
+        const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
+        const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - 2 * oy + 1;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - 2 * ox + 1;
+                const int tap = ky * 3 + kx;
+                const size_t o = ((size_t)(n * Ho + oy) * Wo + ox) * C + cv * V;
+                float d[V];
+                Vec16<T>::load(dy + o, d);
+                const unsigned char* ip = idx + o;
+#pragma unroll
+                for (int j = 0; j < V; ++j) if (ip[j] == tap) acc[j] += d[j];
+            }
+        }
+        Vec16<T>::load(x + i * V, xv);
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            if (!(xv[j] * scale[cv * V + j] + shift[cv * V + j] > 0.f)) acc[j] = 0.f;
+        Vec16<T>::store(g + i * V, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ upsample
+// PyTorch area_pixel_compute_source_index(align_corners=True): src = dst * (in-1)/(out-1) in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    constexpr int V = Vec16<T>::VEC;
+    const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
+    const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+    const long long total = (long long)N * Ho * Wo * cvn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long long t = i / cvn;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float fy = sh * oy, fx = sw * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
+        const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
+        const T* b = x + ((size_t)(n * H + y0) * W + x0) * C + cv * V;
+        float a00[V], a01[V], a10[V], a11[V], o[V];
+        Vec16<T>::load(b, a00);
+        Vec16<T>::load(b + (size_t)xp * C, a01);
+        Vec16<T>::load(b + (size_t)yp * W * C, a10);
+        Vec16<T>::load(b + ((size_t)yp * W + xp) * C, a11);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+        Vec16<T>::store(y + i * V, o);
+    }
+}
+
+__device__ __forceinline__ float up_weight(int o, int i, int In, float s) {
+    const float f = s * o;
+    const int i0 = (int)f;
+    const int ip = (i0 < In - 1) ? 1 : 0;
+    const float l1 = f - i0;
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i0 + ip == i) w += l1;
+    return w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
+    constexpr int V = Vec16<T>::VEC;
+    const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
+    const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
+    const long long total = (long long)N * H * W * cvn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long long t = i / cvn;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        // outputs whose source coordinate lies in (iy-1, iy+1)
+        const int oy_lo = max(0, (int)floorf((iy - 1) / sh)), oy_hi = min(Ho - 1, (int)ceilf((iy + 1) / sh));
+        const int ox_lo = max(0, (int)floorf((ix - 1) / sw)), ox_hi = min(Wo - 1, (int)ceilf((ix + 1) / sw));
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const float wy = up_weight(oy, iy, H, sh);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const float w = wy * up_weight(ox, ix, W, sw);
+                if (w == 0.f) continue;
+                float d[V];
+                Vec16<T>::load(dy + ((size_t)(n * Ho + oy) * Wo + ox) * C + cv * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += w * d[j];
+            }
+        }
+        Vec16<T>::store(dx + i * V, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// one block per sample; CPG = C/G channels per group (4 at the benchmark configs).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          float* __restrict__ mean_rstd, int HW, int C, int G, float eps) {
+    constexpr int V = Vec16<T>::VEC;
+    __shared__ double sg[2 * 128];
+    const int n = blockIdx.x, cpg = C / G;
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sg[i] = 0.0;
+    __syncthreads();
+    const T* xb = x + (size_t)n * HW * C;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int r = rl; r < HW; r += rpp) {
+        float v[V];
+        Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int gi = (cv * V + j) / cpg;
+        atomicAdd(&sg[gi], (double)s1[j]);
+        atomicAdd(&sg[G + gi], (double)s2[j]);
+    }
+    __syncthreads();
+    const double cnt = (double)HW * cpg;
+    float mu[V], rs[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int gi = (cv * V + j) / cpg;
+        const double m = sg[gi] / cnt;
+        const double var = fmax(sg[G + gi] / cnt - m * m, 0.0);
+        mu[j] = (float)m;
+        rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (threadIdx.x < G) {
+        const double m = sg[threadIdx.x] / cnt;
+        const double var = fmax(sg[G + threadIdx.x] / cnt - m * m, 0.0);
+        mean_rstd[((size_t)n * G + threadIdx.x) * 2 + 0] = (float)m;
+        mean_rstd[((size_t)n * G + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    T* yb = y + (size_t)n * HW * C;
+    for (int r = rl; r < HW; r += rpp) {
+        float v[V];
+        Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = fmaxf((v[j] - mu[j]) * rs[j] * gamma[cv * V + j] + beta[cv * V + j], 0.f);
+        Vec16<T>::store(yb + (size_t)r * C + cv * V, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                          const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_rstd, T* __restrict__ dx,
+                                                          float* dgamma, float* dbeta, int HW, int C, int G) {
+    constexpr int V = Vec16<T>::VEC;
+    __shared__ float sg[2 * 128];   // per group: sum g*gamma, sum g*gamma*xhat
+    __shared__ float sc[2 * 512];   // per channel: sum g*xhat, sum g
+    const int n = blockIdx.x, cpg = C / G;
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sg[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sc[i] = 0.f;
+    __syncthreads();
+    const size_t base = (size_t)n * HW * C;
+    float mu[V], rs[V], gm[V], a1[V], a2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j, gi = c / cpg;
+        mu[j] = mean_rstd[((size_t)n * G + gi) * 2 + 0];
+        rs[j] = mean_rstd[((size_t)n * G + gi) * 2 + 1];
+        gm[j] = gamma[c];
+        a1[j] = 0.f; a2[j] = 0.f;
+    }
+    for (int r = rl; r < HW; r += rpp) {
+        float g[V], yv[V], xv[V];
+        const size_t o = base + (size_t)r * C + cv * V;
+        Vec16<T>::load(dy + o, g);
+        Vec16<T>::load(y + o, yv);
+        Vec16<T>::load(x + o, xv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (yv[j] > 0.f) ? g[j] : 0.f;
+            a1[j] += gg;
+            a2[j] += gg * (xv[j] - mu[j]) * rs[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j, gi = c / cpg;
+        atomicAdd(&sc[c], a2[j]);
+        atomicAdd(&sc[C + c], a1[j]);
+        atomicAdd(&sg[gi], a1[j] * gm[j]);
+        atomicAdd(&sg[G + gi], a2[j] * gm[j]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        unsafeAtomicAdd(&dgamma[c], sc[c]);
+        unsafeAtomicAdd(&dbeta[c], sc[C + c]);
+    }
+    const float inv_m = 1.f / ((float)HW * cpg);
+    float A[V], B[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int gi = (cv * V + j) / cpg;
+        A[j] = sg[gi] * inv_m;
+        B[j] = sg[G + gi] * inv_m;
+    }
+    for (int r = rl; r < HW; r += rpp) {
+        float g[V], yv[V], xv[V], o[V];
+        const size_t off = base + (size_t)r * C + cv * V;
+        Vec16<T>::load(dy + off, g);
+        Vec16<T>::load(y + off, yv);
+        Vec16<T>::load(x + off, xv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gg = (yv[j] > 0.f) ? g[j] : 0.f;
+            const float xh = (xv[j] - mu[j]) * rs[j];
+            o[j] = rs[j] * (gg * gm[j] - A[j] - xh * B[j]);
+        }
+        Vec16<T>::store(dx + off, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ misc
+template <typename T>
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const T* dy, const T* y, T* dx, long long nvec) {
+    constexpr int V = Vec16<T>::VEC;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float g[V], yv[V];
+        Vec16<T>::load(dy + i * V, g);
+        Vec16<T>::load(y + i * V, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = (yv[j] > 0.f) ? g[j] : 0.1f * g[j];
+        Vec16<T>::store(dx + i * V, g);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, int cs, int rows, int C, float* db,
+                                                        int rows_per_block) {
+    constexpr int V = Vec16<T>::VEC;
+    __shared__ float acc[1024];
+    const int tpr = cs / V;  // <= 256
+    const int rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    for (int i = threadIdx.x; i < cs; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (rl < rpp) {
+        for (int r = r0 + rl; r < r1; r += rpp) {
+            float v[V];
+            Vec16<T>::load(dy + (size_t)r * cs + cv * V, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) atomicAdd(&acc[cv * V + j], s[j]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) unsafeAtomicAdd(&db[c], acc[c]);
+}
+
+inline int ew_grid(long long n) { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
+
+}  // namespace
+
+#define ST reinterpret_cast<hipStream_t>(stream)
+#define DISPATCH(dtype, CALL_F32, CALL_BF16)                \
+    do {                                                    \
+        if ((dtype) == GDRN_DT_F32) { CALL_F32; }           \
+        else if ((dtype) == GDRN_DT_BF16) { CALL_BF16; }    \
+        else return GDRN_ERR_ARG;                           \
+    } while (0)
+
+extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
+                                float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
+                       running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                   float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !rm || !rv || !scale || !shift || C <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, gamma, beta, rm, rv, eps, C, scale, shift);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
+                             long long npix, int C, int relu, int dtype, void* stream) {
+    if (!x || !scale || !shift || !y || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(npix * C / 4)), dim3(256), 0, ST, (const float*)x, scale,
+                                shift, (const float*)residual, (float*)y, npix * C / 4, C, relu),
+             hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(npix * C / 8)), dim3(256), 0, ST, (const bf16_t*)x,
+                                scale, shift, (const bf16_t*)residual, (bf16_t*)y, npix * C / 8, C, relu));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
+                                  long long npix, int C, float* sums, int dtype, void* stream) {
+    if (!dy || !x || !mean || !invstd || !sums || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
+    if (hipMemsetAsync(sums, 0, 2 * C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    const int rpp = 256 / (C / V);
+    int rpb = rpp * 16;
+    long long blocks = (npix + rpb - 1) / rpb;
+    if (blocks > 2048) { rpb = (int)(((npix + 2047) / 2048 + rpp - 1) / rpp * rpp); blocks = (npix + rpb - 1) / rpb; }
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, ST, (const float*)dy,
+                                (const float*)ymask, (const float*)x, mean, invstd, npix, C, sums, rpb),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, ST, (const bf16_t*)dy,
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, npix, C, sums, rpb));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* sums, long long npix, int C, void* dx, void* g_out,
+                                 float* dgamma, float* dbeta, int dtype, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
+    const float inv_n = (float)(1.0 / (double)npix);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(npix * C / 4)), dim3(256), 0, ST, (const float*)dy,
+                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, npix * C / 4, C, inv_n,
+                                (float*)dx, (float*)g_out, dgamma, dbeta),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(npix * C / 8)), dim3(256), 0, ST, (const bf16_t*)dy,
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, npix * C / 8, C, inv_n,
+                                (bf16_t*)dx, (bf16_t*)g_out, dgamma, dbeta));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
+                                        int N, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !scale || !shift || !y || !idx || N <= 0 || (H & 1) || (W & 1) || (C % 8)) return GDRN_ERR_ARG;
+    const long long n = (long long)N * (H / 2) * (W / 2) * C;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x,
+                                scale, shift, (float*)y, idx, N, H, W, C),
+             hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x,
+                                scale, shift, (bf16_t*)y, idx, N, H, W, C));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale,
+                                const float* shift, void* g, int N, int H, int W, int C, int dtype, void* stream) {
+    if (!dy || !idx || !x || !scale || !shift || !g || N <= 0 || (H & 1) || (W & 1) || (C % 8)) return GDRN_ERR_ARG;
+    const long long n = (long long)N * H * W * C;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, idx,
+                                (const float*)x, scale, shift, (float*)g, N, H, W, C),
+             hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, idx,
+                                (const bf16_t*)x, scale, shift, (bf16_t*)g, N, H, W, C));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !y || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
+    const long long n = (long long)N * 4 * H * W * C;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C),
+             hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
+    if (!dy || !dx || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
+    const long long n = (long long)N * H * W * C;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (float*)dx, N, H, W, C),
+             hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_gn_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N,
+                                int HW, int C, int G, float eps, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean_rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 128 || C > 512 || (C % G) ||
+        (C % 8))
+        return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(N), dim3(256), 0, ST, (const float*)x, gamma, beta, (float*)y, mean_rstd, HW, C, G, eps),
+             hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, HW, C, G, eps));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* mean_rstd,
+                                void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int dtype, void* stream) {
+    if (!dy || !y || !x || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || G <= 0 || G > 128 ||
+        C > 512 || (C % G) || (C % 8))
+        return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    if (hipMemsetAsync(dgamma, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (hipMemsetAsync(dbeta, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(gn_relu_bwd_kernel<float>, dim3(N), dim3(256), 0, ST, (const float*)dy, (const float*)y,
+                                (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, HW, C, G),
+             hipLaunchKernelGGL(gn_relu_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y,
+                                (const bf16_t*)x, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, HW, C, G));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_leaky_bwd(const void* dy, const void* y, void* dx, long long n, int dtype, void* stream) {
+    if (!dy || !y || !dx || n <= 0 || (n % 8)) return GDRN_ERR_ARG;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(leaky_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (const float*)y, (float*)dx, n / 4),
+             hipLaunchKernelGGL(leaky_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db, int dtype, void* stream) {
+    if (!dy || !db || rows <= 0 || C <= 0 || C > cs || cs > 1024 || (cs % 8)) return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if ((cs / V) > 256 || 256 % (cs / V)) return GDRN_ERR_SHAPE;
+    if (hipMemsetAsync(db, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    const int rpp = 256 / (cs / V);
+    int rpb = rpp * 16;
+    int blocks = cdiv(rows, rpb);
+    if (blocks > 1024) { rpb = cdiv(cdiv(rows, 1024), rpp) * rpp; blocks = cdiv(rows, rpb); }
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy, cs, rows, C, db, rpb),
+             hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy, cs, rows, C, db, rpb));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}

@@ -1,0 +1,638 @@
+"""Forward / backward executor of GDR-Net's per-RoI hot path on the HIP kernels of libgdrn_hip.so.
+
+The reference runs this path as ~150 ATen ops forward and their autograd backward
+(core/gdrn_modeling/models/GDRN.py:110-306, resnet_backbone.py:69-80,
+cdpn_rot_head_region.py:182-193, conv_pnp_net.py:111-157).  Here the fixed graph is compiled once per
+(batch size, mode) into a *plan*: statically allocated NHWC buffers plus two flat lists of
+pre-bound C-ABI calls (forward, backward).  Running a plan is a tight loop of ctypes calls on the
+current HIP stream -- no allocation, no host synchronisation, graph-capturable.
+
+Only PyTorch facilities used: device memory (torch.empty), streams, autograd glue.  No ATen compute
+op touches activations.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import cabi
+from .cabi import BF16, F32, ConvParams, PoseParams, WgradParams, check, ptr
+
+RESNET34_LAYERS = (3, 4, 6, 3)
+RESNET34_PLANES = (64, 128, 256, 512)
+HEAD_CONVS = ((3, 4, False), (6, 7, False), (10, 11, True), (13, 14, False), (17, 18, True), (20, 21, False))
+LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_PM_R", "loss_centroid", "loss_z")
+
+
+def _ru(a, b):
+    return (a + b - 1) // b * b
+
+
+class Engine:
+    """Owns the packed (kernel-layout) weight copies and the per-batch-size plans for one GDRN module."""
+
+    def __init__(self, params, buffers, dtype="bf16", num_regions=64, wgrad_variant=0):
+        """params / buffers: dict name -> tensor with the reference's state_dict names."""
+        self.lib = cabi.load()
+        self.P = params
+        self.Bf = buffers
+        self.dt = BF16 if dtype in ("bf16", BF16) else F32
+        self.tdt = torch.bfloat16 if self.dt == BF16 else torch.float32
+        self.esz = 2 if self.dt == BF16 else 4
+        self.dev = next(iter(params.values())).device
+        if self.dev.type != "cuda":
+            raise cabi.GdrnHipError("the HIP engine needs parameters on a GPU device (no CPU fallback)")
+        self.nreg = num_regions
+        self.wgrad_variant = wgrad_variant
+        self.layers = OrderedDict()
+        self._versions = {}
+        self._build_layers()
+        self.plans = {}
+        self.param_names = list(self.P.keys())
+        # flat fp32 gradient buffer, ordered by backward completion (reverse of forward order)
+        order = list(reversed(self.param_names))
+        self.grad_offsets = {}
+        off = 0
+        for n in order:
+            self.grad_offsets[n] = off
+            off += _ru(self.P[n].numel(), 4)
+        self.grad_flat = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.grads = {n: self.grad_flat[self.grad_offsets[n]: self.grad_offsets[n] + self.P[n].numel()].view(self.P[n].shape)
+                      for n in self.param_names}
+        self.bucket_bounds = self._bucket_bounds()
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdt, device=self.dev)
+
+    def _zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.tdt, device=self.dev)
+
+    def _bucket_bounds(self):
+        """Flat-gradient slices in the order backward completes them: pnp, head, layer4+3, rest."""
+        marks = ["rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer2.3.bn2.bias"]
+        cuts = [0]
+        for m in marks:
+            cuts.append(self.grad_offsets[m])
+        cuts.append(self.grad_flat.numel())
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+
+    # ------------------------------------------------------------------------------------------ layers
+    def _add_conv(self, key, kind, src_names, O, I, KH, KW, in_ch=None, out_ch=None, s2=False):
+        """kind: conv | convT | stem | fc1 | fc.  in_ch/out_ch: channel counts of the activation buffers
+        (>= I / O, padded).  Packed operands:
+          wf [rows_f][KK][cin_f]  forward operand          (rows = out channels)
+          wd [rows_d][KK][cin_d]  data-gradient operand    (rows = in channels)
+          dwp fp32 [O_w][KK][I_w] packed weight gradient   (layout of `wf` for conv/fc, of `wd` for convT)"""
+        in_ch = in_ch or _ru(I, 64)
+        out_ch = out_ch or _ru(O, 64)
+        KK = KH * KW
+        L = NS(key=key, kind=kind, src=src_names, O=O, I=I, KH=KH, KW=KW, KK=KK, in_ch=in_ch, out_ch=out_ch, s2=s2)
+        bn_rows = lambda c: 64 if c <= 64 else _ru(c, 128)
+        if kind == "stem":
+            L.cin_f, L.rows_f = 64, 64
+            L.wf = self._zeros(64, 7, 64)
+            L.wd = None
+            L.dwp_shape = (64, 7, 64)
+        elif kind == "convT":  # weight (Cin=O_w, Cout=I_w, k, k) with O_w = I(fwd in), I_w = O(fwd out)
+            L.cin_f, L.rows_f = in_ch, bn_rows(O)
+            L.wf = self._zeros(L.rows_f, KK, in_ch)  # rows = fwd out channels
+            L.cin_d, L.rows_d = out_ch, bn_rows(I)
+            L.wd = self._zeros(L.rows_d, KK, out_ch)  # rows = fwd in channels
+            L.dwp_shape = (I, KK, out_ch)
+        elif kind == "fc1":
+            L.cin_f, L.rows_f = in_ch, bn_rows(O)
+            L.wf = self._zeros(L.rows_f, KK, in_ch)
+            L.cin_d, L.rows_d = out_ch, KK * in_ch  # 1x1 "conv" from O channels to KK*in_ch
+            L.wd = self._zeros(L.rows_d, 1, out_ch)
+            L.dwp_shape = (O, KK, in_ch)
+        else:  # conv / fc
+            L.cin_f, L.rows_f = in_ch, bn_rows(O)
+            L.wf = self._zeros(L.rows_f, KK, in_ch)
+            L.cin_d, L.rows_d = out_ch, bn_rows(in_ch)
+            L.wd = self._zeros(L.rows_d, KK, out_ch)
+            L.dwp_shape = (O, KK, in_ch)
+        self.layers[key] = L
+        return L
+
+    def _build_layers(self):
+        self._add_conv("backbone.conv1", "stem", ["backbone.conv1.weight"], 64, 3, 7, 7)
+        inpl = 64
+        for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
+            for b in range(nb):
+                p = f"backbone.layer{li}.{b}"
+                self._add_conv(p + ".conv1", "conv", [p + ".conv1.weight"], pl, inpl, 3, 3, s2=(b == 0 and li > 1))
+                self._add_conv(p + ".conv2", "conv", [p + ".conv2.weight"], pl, pl, 3, 3)
+                if (p + ".downsample.0.weight") in self.P:
+                    self._add_conv(p + ".downsample.0", "conv", [p + ".downsample.0.weight"], pl, inpl, 1, 1, s2=True)
+                inpl = pl
+        h = "rot_head_net.features."
+        self._add_conv(h + "0", "convT", [h + "0.weight"], 256, 512, 3, 3)
+        for ci, _, _ in HEAD_CONVS:
+            self._add_conv(h + str(ci), "conv", [h + f"{ci}.weight"], 256, 256, 3, 3)
+        self.head_c = 1 + 3 + self.nreg + 1
+        self._add_conv(h + "23", "conv", [h + "23.weight"], self.head_c, 256, 1, 1, out_ch=128)
+        q = "pnp_net.features."
+        self.pnp_c = 3 + 2 + self.nreg
+        self._add_conv(q + "0", "conv", [q + "0.weight"], 128, self.pnp_c, 3, 3, in_ch=128, s2=True)
+        self._add_conv(q + "3", "conv", [q + "3.weight"], 128, 128, 3, 3, s2=True)
+        self._add_conv(q + "6", "conv", [q + "6.weight"], 128, 128, 3, 3, s2=True)
+        self._add_conv("pnp_net.fc1", "fc1", ["pnp_net.fc1.weight"], 1024, 128, 8, 8)
+        self._add_conv("pnp_net.fc2", "fc", ["pnp_net.fc2.weight"], 256, 1024, 1, 1)
+        self._add_conv("pnp_net.fc_rt", "fc", ["pnp_net.fc_r.weight", "pnp_net.fc_t.weight"], 9, 256, 1, 1)
+        # packed fp32 weight-gradient scratch (zeroed once per backward; wgrad accumulates with atomics)
+        tot = 0
+        for L in self.layers.values():
+            L.dwp_off = tot
+            tot += _ru(int(math.prod(L.dwp_shape)), 4)
+        self.dwp_flat = torch.zeros(tot, dtype=torch.float32, device=self.dev)
+        for L in self.layers.values():
+            L.dwp = self.dwp_flat[L.dwp_off: L.dwp_off + int(math.prod(L.dwp_shape))]
+        self.rt_w = torch.zeros(9, 256, dtype=torch.float32, device=self.dev)
+        self.rt_b = torch.zeros(9, dtype=torch.float32, device=self.dev)
+
+    def _src_version(self, L):
+        return tuple(self.P[n]._version for n in L.src) + tuple(self.P[n].data_ptr() for n in L.src)
+
+    def repack(self, force=False):
+        """(Re)build the kernel-layout operand copies of every weight whose parameter changed."""
+        st = self._stream()
+        lib = self.lib
+        for key, L in self.layers.items():
+            v = self._src_version(L)
+            if not force and self._versions.get(key) == v:
+                continue
+            self._versions[key] = v
+            if key == "pnp_net.fc_rt":
+                with torch.no_grad():
+                    self.rt_w[:6].copy_(self.P["pnp_net.fc_r.weight"])
+                    self.rt_w[6:].copy_(self.P["pnp_net.fc_t.weight"])
+                    self.rt_b[:6].copy_(self.P["pnp_net.fc_r.bias"])
+                    self.rt_b[6:].copy_(self.P["pnp_net.fc_t.bias"])
+                w = self.rt_w
+            else:
+                w = self.P[L.src[0]].detach()
+            O, I, KK = L.O, L.I, L.KK
+            if L.kind == "stem":
+                check(lib.gdrn_pack_stem_w(ptr(w), ptr(L.wf), self.dt, st), "pack_stem_w")
+            elif L.kind == "convT":
+                # weight[ci=I][co=O][k]; fwd rows = co, b = ci ; dgrad rows = ci, b = co
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, KK, 0, 1, O * KK, 0, self.dt, st), "pack4")
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), L.rows_d, 1, KK, L.cin_d, I, 1, O, O * KK, 0, 1, KK, 0, self.dt, st), "pack4")
+            elif L.kind == "fc1":
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0, self.dt, st), "pack4")
+                # dgrad rows (p, c) -> src[o*I*KK + c*KK + p]
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), KK, L.in_ch, 1, L.cin_d, KK, I, O, 1, KK, 0, I * KK, 0, self.dt, st), "pack4")
+            else:
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0, self.dt, st), "pack4")
+                flip = 1 if (KK == 9 and not L.s2) else 0
+                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), L.rows_d, 1, KK, L.cin_d, I, 1, O, KK, 0, 1, I * KK, flip, self.dt, st), "pack4")
+
+    # ------------------------------------------------------------------------------------------ plans
+    def plan(self, B, bn_train, with_loss):
+        """bn_train: BatchNorm uses batch statistics (module.training); with_loss: train-mode pose
+        decode + losses (do_loss=True).  The backward graph exists when both are set."""
+        key = (B, bool(bn_train), bool(with_loss))
+        if key not in self.plans:
+            self.plans[key] = Plan(self, B, bool(bn_train), bool(with_loss))
+        return self.plans[key]
+
+
+class Plan:
+    """Static buffers + pre-bound call lists for one (batch size, train/eval) configuration."""
+
+    def __init__(self, eng, B, bn_train, with_loss):
+        self.e = eng
+        self.B = B
+        self.bn_train = bn_train
+        self.with_loss = with_loss
+        self.has_backward = bn_train and with_loss
+        self.fwd = []          # callables f(stream, ctx)
+        self.bwd_groups = []   # list of lists, appended in forward order, executed reversed
+        self.keep = []         # keep ctypes structs alive
+        self.bn = {}           # bn key -> NS(mean, invstd, scale, shift, sums)
+        self._build()
+        self.bwd = [op for g in reversed(self.bwd_groups) for op in g]
+
+    # ---- op builders -------------------------------------------------------------------------
+    def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None):
+        e = self.e
+        cp = ConvParams()
+        cp.x, cp.w, cp.y = ptr(x), ptr(w if w is not None else L.wf), ptr(y)
+        cp.bias, cp.addend, cp.stats = ptr(bias), ptr(addend), ptr(stats)
+        cp.Hi, cp.Wi, cp.Cin, cp.x_cs = Hi, Wi, cin or L.cin_f, x_cs or xs
+        cp.Ho, cp.Wo, cp.Cout = Ho, Wo, cout or L.O
+        cp.y_cs = y_cs or y.shape[-1]
+        cp.add_cs = add_cs
+        cp.KH, cp.KW, cp.stride, cp.pad = KH or L.KH, KW or L.KW, stride, pad
+        cp.mode, cp.act, cp.out_f32 = mode, act, out_f32
+        cp.M = self.B * (Ho // 2) * (Wo // 2) if mode == 1 else self.B * Ho * Wo
+        cp.w_rows = rows or L.rows_f
+        cp.dtype = e.dt
+        self.keep.append(cp)
+        fn, ref = e.lib.gdrn_conv_gemm, C.byref(cp)
+
+        def run(st, ctx):
+            s = fn(ref, st)
+            if s:
+                check(s, f"conv_gemm {L.key}")
+
+        # metadata for the roofline measurement in bench.py: kernel instantiation + algorithmic FLOPs
+        bm, bn = C.c_int(0), C.c_int(0)
+        e.lib.gdrn_conv_tile(ref, C.byref(bm), C.byref(bn))
+        # true (unpadded) MACs: the layer's forward MAC count whichever direction this launch computes
+        if L.kind == "stem":
+            macs = self.B * 128 * 128 * 64 * 3 * 49
+        elif L.kind == "fc1":
+            macs = self.B * L.O * L.I * L.KK
+        else:
+            sp = (Ho * Wo) if (mode == 0 and (w is None or L.kind == "convT")) else (Hi * Wi)
+            if L.kind == "convT":
+                sp = 8 * 8  # Hin*Win*Cin*Cout*k^2
+            macs = self.B * sp * L.O * L.I * L.KK
+        run.meta = dict(kernel=f"conv_gemm_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bm.value},{bn.value}>", flops=2.0 * macs,
+                        layer=L.key)
+        return run, cp
+
+    def _stats_rows(self, cp):
+        return self.e.lib.gdrn_conv_stats_rows(C.byref(cp))
+
+    def _wgrad(self, L, x, dy, Hi, Wi, Ho, Wo, stride, pad, cin, cout, x_cs, dy_cs, KH=None, KW=None):
+        e = self.e
+        wp = WgradParams()
+        wp.x, wp.dy, wp.dw = ptr(x), ptr(dy), ptr(L.dwp)
+        wp.Hi, wp.Wi, wp.Cin, wp.x_cs = Hi, Wi, cin, x_cs
+        wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Ho, Wo, cout, dy_cs
+        wp.KH, wp.KW, wp.stride, wp.pad = KH or L.KH, KW or L.KW, stride, pad
+        wp.M, wp.dtype, wp.splits, wp.variant = self.B * Ho * Wo, e.dt, 0, e.wgrad_variant
+        self.keep.append(wp)
+        fn, ref = e.lib.gdrn_conv_wgrad, C.byref(wp)
+
+        def run(st, ctx):
+            s = fn(ref, st)
+            if s:
+                check(s, f"conv_wgrad {L.key}")
+
+        return run
+
+    def _unpack(self, L):
+        e = self.e
+        lib = e.lib
+        O, I, KK = L.O, L.I, L.KK
+        if L.kind == "stem":
+            g = e.grads[L.src[0]]
+            return lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w")
+        if L.key == "pnp_net.fc_rt":
+            gr, gt = e.grads["pnp_net.fc_r.weight"], e.grads["pnp_net.fc_t.weight"]
+
+            def run(st, ctx):
+                check(lib.gdrn_unpack4(ptr(L.dwp), ptr(gr), 9, 1, 1, L.in_ch, 6, 1, 256, 256, 0, 0, 1, 0, st), "unpack4")
+                check(lib.gdrn_unpack4(L.dwp.data_ptr() + 6 * L.in_ch * 4, ptr(gt), 3, 1, 1, L.in_ch, 3, 1, 256, 256, 0, 0, 1, 0, st), "unpack4")
+
+            return run
+        g = e.grads[L.src[0]]
+        if L.kind == "convT":  # dwp [ci=I][KK][co(out_ch)] -> weight[ci][co][k]
+            return lambda st, ctx: check(lib.gdrn_unpack4(ptr(L.dwp), ptr(g), I, 1, KK, L.out_ch, I, 1, O, O * KK, 0, 1, KK, 0, st), "unpack4")
+        return lambda st, ctx: check(lib.gdrn_unpack4(ptr(L.dwp), ptr(g), O, 1, KK, L.in_ch, O, 1, I, I * KK, 0, 1, KK, 0, st), "unpack4")
+
+    def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
+        """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
+        e, lib = self.e, self.e.lib
+        s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
+               scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32),
+               sums=e._empty(2 * C_, dtype=torch.float32), C=C_, npix=npix)
+        self.bn[bnkey] = s
+        g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
+        rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
+        ops = []
+        if self.bn_train:
+            rows = self._stats_rows(cp)
+            ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
+                                                                  ptr(rv), ptr(nbt), 0.1, 1e-5, ptr(s.mean), ptr(s.invstd),
+                                                                  ptr(s.scale), ptr(s.shift), st), "bn_finalize"))
+        else:
+            ops.append(lambda st, ctx: check(lib.gdrn_bn_eval_params(ptr(g), ptr(b), ptr(rm), ptr(rv), 1e-5, C_, ptr(s.scale),
+                                                                     ptr(s.shift), st), "bn_eval_params"))
+        if y is not None:
+            ops.append(lambda st, ctx: check(lib.gdrn_bn_apply(ptr(raw), ptr(s.scale), ptr(s.shift), ptr(residual), ptr(y), npix,
+                                                               C_, relu, e.dt, st), "bn_apply"))
+        return ops
+
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None):
+        e, lib = self.e, self.e.lib
+        s = self.bn[bnkey]
+        g = e.P[bnkey + ".weight"]
+        dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
+        return [
+            lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ptr(ymask), ptr(raw), ptr(s.mean), ptr(s.invstd), s.npix, s.C,
+                                                         ptr(s.sums), e.dt, st), "bn_bwd_reduce"),
+            lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ptr(ymask), ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g),
+                                                        ptr(s.sums), s.npix, s.C, ptr(dx), ptr(g_out), ptr(dg), ptr(db), e.dt, st),
+                                  "bn_bwd_apply"),
+        ]
+
+    # ---- graph -------------------------------------------------------------------------------
+    def _build(self):
+        e, lib, B = self.e, self.e.lib, self.B
+        S, T, WL = self.bn_train, self.has_backward, self.with_loss  # batch stats | backward graph | losses
+        E = e._empty
+        F32t = torch.float32
+        self.stats = E(B * 32768 + 65536, dtype=F32t)  # per-M-tile BN partial sums (max over layers)
+        nreg = e.nreg
+
+        # ---------------- stem
+        Ls = e.layers["backbone.conv1"]
+        self.img_p = e._zeros(B, 262, 272, 4)
+        raw0 = E(B, 128, 128, 64)
+        p0 = E(B, 64, 64, 64)
+        idx0 = E(B, 64, 64, 64, dtype=torch.uint8)
+        self.fwd.append(lambda st, ctx: check(lib.gdrn_pack_image(ctx["img"], ptr(self.img_p), B, 256, 256, 262, 272, e.dt, st), "pack_image"))
+        op, cp = self._conv(Ls, self.img_p, 4, raw0, 262, 272, 128, 128, 2, 0, cin=64, cout=64, x_cs=4, KH=7, KW=1,
+                            stats=self.stats if S else None)
+        self.fwd.append(op)
+        self.fwd += self._bn_fwd("backbone.bn1", raw0, cp, 64, B * 128 * 128, None)
+        s0 = self.bn["backbone.bn1"]
+        self.fwd.append(lambda st, ctx: check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw0), ptr(s0.scale), ptr(s0.shift), ptr(p0), ptr(idx0),
+                                                                           B, 128, 128, 64, e.dt, st), "bn_relu_maxpool"))
+        if T:
+            d_p0 = E(B, 64, 64, 64)
+            g_stem = E(B, 128, 128, 64)
+            d_raw0 = g_stem  # in place
+            grp = [lambda st, ctx: check(lib.gdrn_maxpool_bwd(ptr(d_p0), ptr(idx0), ptr(raw0), ptr(s0.scale), ptr(s0.shift),
+                                                              ptr(g_stem), B, 128, 128, 64, e.dt, st), "maxpool_bwd")]
+            grp += self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0)
+            grp.append(self._wgrad(Ls, self.img_p, d_raw0, 262, 272, 128, 128, 2, 0, 64, 64, 4, 64, KH=7, KW=1))
+            grp.append(self._unpack(Ls))
+            self.bwd_groups.append(grp)
+        else:
+            d_p0 = None
+
+        # ---------------- residual blocks
+        x, d_x, Hc, inpl = p0, d_p0, 64, 64
+        for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
+            for b in range(nb):
+                pfx = f"backbone.layer{li}.{b}"
+                stride = 2 if (b == 0 and li > 1) else 1
+                Ho = Hc // stride
+                L1, L2 = e.layers[pfx + ".conv1"], e.layers[pfx + ".conv2"]
+                Ld = e.layers.get(pfx + ".downsample.0")
+                npo = B * Ho * Ho
+                raw1, a1, raw2, out = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                op, cp = self._conv(L1, x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None)
+                self.fwd.append(op)
+                self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, a1)
+                op, cp = self._conv(L2, a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None)
+                self.fwd.append(op)
+                if Ld is not None:
+                    rawd, idn = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                    self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
+                    op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
+                    self.fwd.append(op)
+                    self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd, pl, npo, idn, relu=0)
+                    s2 = self.bn[pfx + ".bn2"]
+                    self.fwd.append(lambda st, ctx, raw2=raw2, s2=s2, idn=idn, out=out, npo=npo, pl=pl: check(
+                        lib.gdrn_bn_apply(ptr(raw2), ptr(s2.scale), ptr(s2.shift), ptr(idn), ptr(out), npo, pl, 1, e.dt, st), "bn_apply"))
+                else:
+                    self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, out, residual=x)
+                if T:
+                    d_out = E(B, Ho, Ho, pl)
+                    d_raw2, g2, d_a1, d_raw1 = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                    grp = self._bn_bwd(pfx + ".bn2", d_out, out, raw2, d_raw2, g_out=g2)
+                    grp.append(self._wgrad(L2, a1, d_raw2, Ho, Ho, Ho, Ho, 1, 1, pl, pl, pl, pl))
+                    grp.append(self._unpack(L2))
+                    op, _ = self._conv(L2, d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl)
+                    grp.append(op)
+                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1)
+                    grp.append(self._wgrad(L1, x, d_raw1, Hc, Hc, Ho, Ho, stride, 1, inpl, pl, inpl, pl))
+                    grp.append(self._unpack(L1))
+                    need_dx = d_x is not None
+                    if Ld is not None:
+                        d_rawd, d_xd = E(B, Ho, Ho, pl), E(B, Hc, Hc, inpl)
+                        grp += self._bn_bwd(pfx + ".downsample.1", g2, None, rawd, d_rawd)
+                        grp.append(self._wgrad(Ld, x, d_rawd, Hc, Hc, Ho, Ho, stride, 0, inpl, pl, inpl, pl))
+                        grp.append(self._unpack(Ld))
+                        op, _ = self._conv(Ld, d_rawd, pl, d_xd, Ho, Ho, Hc, Hc, 2, 0, mode=1, w=Ld.wd, rows=Ld.rows_d, cin=Ld.cin_d, cout=inpl)
+                        grp.append(op)
+                        op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 2, 1, mode=1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d,
+                                           cout=inpl, addend=d_xd, add_cs=inpl)
+                        grp.append(op)
+                    elif need_dx:
+                        op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 1, 1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d, cout=inpl,
+                                           addend=g2, add_cs=pl)
+                        grp.append(op)
+                    self.bwd_groups.append(grp)
+                    d_x = d_out
+                x, Hc, inpl = out, Ho, pl
+        feat, d_feat = x, d_x
+
+        # ---------------- geometric head
+        h = "rot_head_net.features."
+        LT = e.layers[h + "0"]
+        rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
+        op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
+        self.fwd.append(op)
+        self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
+        if T:
+            d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
+            grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt)
+            # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
+            grp.append(self._wgrad(LT, d_rawt, feat, 16, 16, 8, 8, 2, 1, 256, 512, 256, 512))
+            grp.append(self._unpack(LT))
+            op, _ = self._conv(LT, d_rawt, 256, d_feat, 16, 16, 8, 8, 2, 1, mode=0, w=LT.wd, rows=LT.rows_d, cin=256, cout=512)
+            grp.append(op)
+            self.bwd_groups.append(grp)
+        hx, d_hx, Hh = h0, (d_h0 if T else None), 16
+        for ci, bi, up in HEAD_CONVS:
+            Lc = e.layers[h + str(ci)]
+            grp = []
+            if up:
+                u = E(B, 2 * Hh, 2 * Hh, 256)
+                self.fwd.append(lambda st, ctx, hx=hx, u=u, Hh=Hh: check(lib.gdrn_upsample2x_fwd(ptr(hx), ptr(u), B, Hh, Hh, 256, e.dt, st), "upsample_fwd"))
+                if T:
+                    d_u = E(B, 2 * Hh, 2 * Hh, 256)
+                    up_bwd = (lambda st, ctx, d_u=d_u, d_hx=d_hx, Hh=Hh: check(lib.gdrn_upsample2x_bwd(ptr(d_u), ptr(d_hx), B, Hh, Hh, 256, e.dt, st), "upsample_bwd"))
+                    d_in = d_u
+                xin, Hh = u, 2 * Hh
+            else:
+                xin = hx
+                d_in = d_hx
+                up_bwd = None
+            raw, act = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
+            op, cp = self._conv(Lc, xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None)
+            self.fwd.append(op)
+            self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
+            if T:
+                d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
+                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw)
+                grp.append(self._wgrad(Lc, xin, d_raw, Hh, Hh, Hh, Hh, 1, 1, 256, 256, 256, 256))
+                grp.append(self._unpack(Lc))
+                op, _ = self._conv(Lc, d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256)
+                grp.append(op)
+                if up_bwd is not None:
+                    grp.append(up_bwd)
+                self.bwd_groups.append(grp)
+                d_hx = d_act
+            hx = act
+        LO = e.layers[h + "23"]
+        M = B * 64 * 64
+        self.hs = 72
+        self.head_out = E(M, self.hs, dtype=F32t)
+        bias_o = e.P[h + "23.bias"]
+        op, _ = self._conv(LO, hx, 256, self.head_out, 64, 64, 64, 64, 1, 0, bias=bias_o, out_f32=1, y_cs=self.hs, cout=e.head_c)
+        self.fwd.append(op)
+        self.pnp_in = E(M, 128)
+        self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"],
+                                                                     ptr(self.pnp_in), 128, B, 4096, nreg, e.dt, st), "head_tail_fwd"))
+        if WL:
+            self.acc = E(8, dtype=torch.float64)
+            self.losses = e._zeros(8, dtype=F32t)
+        if T:
+            self.d_head = E(M, 128)
+            self.d_pnp_in = E(M, 128)
+            self.gw = e._zeros(8, dtype=F32t)
+            grp = [lambda st, ctx: check(lib.gdrn_head_tail_bwd(ptr(self.head_out), self.hs, ptr(self.pnp_in), ptr(self.d_pnp_in), 128,
+                                                                ctx["extents"], ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"],
+                                                                ctx["gt_region"], ptr(self.acc), ptr(self.gw), ptr(self.d_head), 128, B,
+                                                                4096, nreg, e.dt, st), "head_tail_bwd")]
+            grp.append(self._wgrad(LO, hx, self.d_head, 64, 64, 64, 64, 1, 0, 256, e.head_c, 256, 128))
+            grp.append(self._unpack(LO))
+            gb = e.grads[h + "23.bias"]
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt, st), "bias_grad"))
+            op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256)
+            grp.append(op)
+            self.bwd_groups.append(grp)
+
+        # ---------------- Patch-PnP
+        q = "pnp_net.features."
+        px, d_px, Hp, cin = self.pnp_in, (self.d_pnp_in if T else None), 64, 128
+        for ci, gi in ((0, 1), (3, 4), (6, 7)):
+            Lc = e.layers[q + str(ci)]
+            Ho = Hp // 2
+            r, gact = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
+            mr = E(B, 32, 2, dtype=F32t)
+            op, _ = self._conv(Lc, px, cin, r, Hp, Hp, Ho, Ho, 2, 1, cin=cin, cout=128)
+            self.fwd.append(op)
+            gam, bet = e.P[q + f"{gi}.weight"], e.P[q + f"{gi}.bias"]
+            self.fwd.append(lambda st, ctx, r=r, gam=gam, bet=bet, gact=gact, mr=mr, Ho=Ho: check(
+                lib.gdrn_gn_relu_fwd(ptr(r), ptr(gam), ptr(bet), ptr(gact), ptr(mr), B, Ho * Ho, 128, 32, 1e-5, e.dt, st), "gn_relu_fwd"))
+            if T:
+                d_g, d_r = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
+                dgam, dbet = e.grads[q + f"{gi}.weight"], e.grads[q + f"{gi}.bias"]
+                grp = [lambda st, ctx, d_g=d_g, gact=gact, r=r, gam=gam, mr=mr, d_r=d_r, dgam=dgam, dbet=dbet, Ho=Ho: check(
+                    lib.gdrn_gn_relu_bwd(ptr(d_g), ptr(gact), ptr(r), ptr(gam), ptr(mr), ptr(d_r), ptr(dgam), ptr(dbet), B, Ho * Ho, 128, 32,
+                                         e.dt, st), "gn_relu_bwd")]
+                grp.append(self._wgrad(Lc, px, d_r, Hp, Hp, Ho, Ho, 2, 1, cin, 128, cin, 128))
+                grp.append(self._unpack(Lc))
+                op, _ = self._conv(Lc, d_r, 128, d_px, Ho, Ho, Hp, Hp, 2, 1, mode=1, w=Lc.wd, rows=Lc.rows_d, cin=128, cout=cin)
+                grp.append(op)
+                self.bwd_groups.append(grp)
+                d_px = d_g
+            px, Hp, cin = gact, Ho, 128
+        g2act, d_g2 = px, d_px
+        L1, L2, L3 = e.layers["pnp_net.fc1"], e.layers["pnp_net.fc2"], e.layers["pnp_net.fc_rt"]
+        f1, f2 = E(B, 1024), E(B, 256)
+        self.fc_out = E(B, 64, dtype=F32t)
+        b1, b2 = e.P["pnp_net.fc1.bias"], e.P["pnp_net.fc2.bias"]
+        op, _ = self._conv(L1, g2act, 128, f1, 8, 8, 1, 1, 1, 0, bias=b1, act=2, cin=128, cout=1024)
+        self.fwd.append(op)
+        op, _ = self._conv(L2, f1, 1024, f2, 1, 1, 1, 1, 1, 0, bias=b2, act=2, cin=1024, cout=256)
+        self.fwd.append(op)
+        op, _ = self._conv(L3, f2, 256, self.fc_out, 1, 1, 1, 1, 1, 0, bias=e.rt_b, out_f32=1, cin=256, cout=9, y_cs=64)
+        self.fwd.append(op)
+        if T:
+            self.dfc3 = e._zeros(3, B, 64, dtype=F32t)
+            d_fc32 = e._zeros(B, 64, dtype=F32t)
+            d_fc = E(B, 64)
+            d_f2, d_f2p, d_f1, d_f1p = E(B, 256), E(B, 256), E(B, 1024), E(B, 1024)
+            self.rt_gb = e._zeros(9, dtype=F32t)
+            g_b1, g_b2 = e.grads["pnp_net.fc1.bias"], e.grads["pnp_net.fc2.bias"]
+            grp = [
+                lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3"),
+                lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
+                self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64),
+                self._unpack(L3),
+                lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt, st), "bias_grad"),
+                lambda st, ctx: (e.grads["pnp_net.fc_r.bias"].copy_(self.rt_gb[:6]), e.grads["pnp_net.fc_t.bias"].copy_(self.rt_gb[6:])),
+            ]
+            op, _ = self._conv(L3, d_fc, 64, d_f2, 1, 1, 1, 1, 1, 0, w=L3.wd, rows=L3.rows_d, cin=64, cout=256)
+            grp.append(op)
+            grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f2), ptr(f2), ptr(d_f2p), B * 256, e.dt, st), "leaky_bwd"))
+            grp.append(self._wgrad(L2, f1, d_f2p, 1, 1, 1, 1, 1, 0, 1024, 256, 1024, 256))
+            grp.append(self._unpack(L2))
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt, st), "bias_grad"))
+            op, _ = self._conv(L2, d_f2p, 256, d_f1, 1, 1, 1, 1, 1, 0, w=L2.wd, rows=L2.rows_d, cin=256, cout=1024)
+            grp.append(op)
+            grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f1), ptr(f1), ptr(d_f1p), B * 1024, e.dt, st), "leaky_bwd"))
+            grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024))
+            grp.append(self._unpack(L1))
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt, st), "bias_grad"))
+            op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
+            grp.append(op)
+            self.bwd_groups.append(grp)
+
+        # ---------------- pose decode (+ pose / map losses in train mode)
+        self.rot = E(B, 3, 3, dtype=F32t)
+        self.trans = E(B, 3, dtype=F32t)
+        self.vis = e._zeros(B, 2, dtype=F32t)
+        self.pose_p = PoseParams()
+
+        def pose(st, ctx):
+            pp = self.pose_p
+            pp.fc, pp.fs = ptr(self.fc_out), 64
+            pp.cams, pp.centers, pp.whs, pp.ratios, pp.extents = ctx["cams"], ctx["centers"], ctx["whs"], ctx["ratios"], ctx["extents"]
+            pp.gt_rot, pp.gt_trans, pp.gt_trans_ratio = ctx.get("gt_rot"), ctx.get("gt_trans"), ctx.get("gt_trans_ratio")
+            pp.points, pp.npts = ctx.get("points"), ctx.get("npts", 0)
+            pp.sym, pp.sym_count, pp.Kmax = ctx.get("sym"), ctx.get("sym_count"), ctx.get("Kmax", 0)
+            pp.N, pp.train = B, 1 if WL else 0
+            pp.rot, pp.trans = ptr(self.rot), ptr(self.trans)
+            pp.losses = (self.losses.data_ptr() + 20) if WL else None
+            pp.dfc = ptr(self.dfc3) if T else None
+            pp.vis = ptr(self.vis) if WL else None
+            check(lib.gdrn_pose_loss(C.byref(pp), st), "pose_loss")
+
+        self.fwd.append(pose)
+        if WL:
+            self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_fwd(ptr(self.head_out), self.hs, ctx["gt_xyz"], ctx["mask_visib"],
+                                                                        ctx["mask_trunc"], ctx["gt_region"], B, 4096, nreg, ptr(self.acc),
+                                                                        st), "map_loss_fwd"))
+            self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize(ptr(self.acc), B, 4096, ptr(self.losses), st), "map_loss_finalize"))
+
+    # ---- execution ---------------------------------------------------------------------------
+    def run_forward(self, ctx):
+        st = self.e._stream()
+        for op in self.fwd:
+            op(st, ctx)
+
+    def run_backward(self, ctx, on_bucket=None):
+        """ctx as in forward; self.gw must hold dL/dloss_k.  on_bucket(i) is called after the ops that
+        complete gradient bucket i have been enqueued (used to overlap the RCCL all-reduce)."""
+        e = self.e
+        st = e._stream()
+        e.dwp_flat.zero_()
+        marks = self._bucket_marks() if on_bucket is not None else {}
+        for i, op in enumerate(self.bwd):
+            op(st, ctx)
+            if i in marks:
+                on_bucket(marks[i])
+
+    def _bucket_marks(self):
+        """index of the last backward op of each gradient bucket (pnp | head | layer4+3 | rest)."""
+        if hasattr(self, "_marks"):
+            return self._marks
+        n_groups = len(self.bwd_groups)
+        sizes = [len(g) for g in reversed(self.bwd_groups)]
+        # groups in forward order: stem(1) + 16 blocks + convT(1) + 6 head convs + head out(1) + 3 pnp convs + fc(1)
+        cum, ends = 0, []
+        for s in sizes:
+            cum += s
+            ends.append(cum - 1)
+        # reversed order: fc, pnp x3 | head-out, head convs x6, convT | layer4 (3) + layer3 (6) | layer2 (4), layer1 (3), stem
+        bounds = [4, 4 + 8, 4 + 8 + 9, n_groups]
+        self._marks = {ends[b - 1]: i for i, b in enumerate(bounds)}
+        return self._marks

@@ -1,0 +1,95 @@
+"""Ranger (RAdam + gradient centralisation + Lookahead) with a fused HIP step.
+
+Semantics of ``lib/torch_utils/solver/ranger.py:29-200`` (version 20.4.11): same constructor
+arguments, same ``state`` keys (``step``, ``exp_avg``, ``exp_avg_sq``, ``slow_buffer``) so optimizer
+checkpoints interchange.  The per-parameter Python arithmetic of the reference (about 12 ATen
+launches per tensor x 148 tensors) is one ``gdrn_ranger_step`` launch per tensor here; the RAdam
+rectification scalars (ranger.py:154-186) are computed on the host exactly as the reference does.
+"""
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import cabi
+
+
+def _bump_version(t):
+    try:
+        torch.autograd.graph.increment_version(t)
+    except AttributeError:  # older torch
+        t.add_(0)
+
+
+def radam_step_size(step, beta1, beta2, n_sma_threshold):
+    """(N_sma, step_size) of ranger.py:160-186."""
+    beta2_t = beta2 ** step
+    n_sma_max = 2 / (1 - beta2) - 1
+    n_sma = n_sma_max - 2 * step * beta2_t / (1 - beta2_t)
+    if n_sma > n_sma_threshold:
+        step_size = math.sqrt(
+            (1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max / (n_sma_max - 2)
+        ) / (1 - beta1 ** step)
+    else:
+        step_size = 1.0 / (1 - beta1 ** step)
+    return n_sma, step_size
+
+
+class Ranger(Optimizer):
+    def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5, weight_decay=0,
+                 use_gc=True, gc_conv_only=False):
+        if not 0.0 <= alpha <= 1.0:
+            raise ValueError(f"Invalid slow update rate: {alpha}")
+        if not 1 <= k:
+            raise ValueError(f"Invalid lookahead steps: {k}")
+        if not lr > 0:
+            raise ValueError(f"Invalid Learning Rate: {lr}")
+        if not eps > 0:
+            raise ValueError(f"Invalid eps: {eps}")
+        defaults = dict(lr=lr, alpha=alpha, k=k, step_counter=0, betas=betas, N_sma_threshhold=N_sma_threshhold, eps=eps,
+                        weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.N_sma_threshhold = N_sma_threshhold
+        self.alpha = alpha
+        self.k = k
+        self.use_gc = use_gc
+        self.gc_gradient_threshold = 3 if gc_conv_only else 1
+
+    @torch.no_grad()
+    def step(self, closure=None, grads=None):
+        """grads: optional dict param -> fp32 gradient tensor (used by the fused train step to read the
+        engine's flat gradient buffer directly instead of ``p.grad``)."""
+        lib = cabi.load()
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                g = grads.get(p) if grads is not None else p.grad
+                if g is None:
+                    continue
+                if p.device.type != "cuda" or p.dtype != torch.float32:
+                    raise cabi.GdrnHipError("fused Ranger needs fp32 parameters on the GPU")
+                g = g.detach()
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                    state["slow_buffer"] = p.detach().clone()
+                state["step"] += 1
+                step = state["step"]
+                n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
+                gc = 1 if (self.use_gc and g.dim() > self.gc_gradient_threshold) else 0
+                rows = p.shape[0] if (gc and p.dim() > 1) else 1
+                cols = p.numel() // rows
+                st = torch.cuda.current_stream(p.device).cuda_stream
+                cabi.check(
+                    lib.gdrn_ranger_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                         state["slow_buffer"].data_ptr(), rows, cols, gc, group["lr"], beta1, beta2, group["eps"],
+                                         group["weight_decay"], step_size, 1 if n_sma > self.N_sma_threshhold else 0,
+                                         1 if step % group["k"] == 0 else 0, self.alpha, st),
+                    "ranger_step",
+                )
+                _bump_version(p)  # updated in place behind autograd's back: tell repack() the weights changed
+        return None

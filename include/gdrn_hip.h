@@ -1,0 +1,221 @@
+/* gdrn_hip.h -- C ABI of libgdrn_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for GDR-Net's
+ * per-RoI hot path (ResNet-34 backbone + geometric head + Patch-PnP + pose decode + losses, forward
+ * and backward).
+ *
+ * This is the drop-in boundary for the path.  The reference has no native interface here: its hot
+ * path is Python dispatching ATen/cuDNN ops.  Each entry point below names the
+ * reference call site(s) whose ATen dispatch it replaces; paths are relative to the reference
+ * checkout.  Binding stub for a reference maintainer: INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-owned device memory (the library never
+ *     allocates or frees device memory and keeps no state besides per-kernel launch attributes);
+ *   - every call enqueues asynchronously on `stream` (a hipStream_t passed as void*; 0 = null stream)
+ *     and returns an int status: 0 ok, <0 error (GDRN_ERR_*); nothing throws across the boundary;
+ *   - activations are NHWC with an explicit pixel stride (`*_cs`, in elements); `dtype` selects the
+ *     storage/operand type: GDRN_DT_F32 (fp32 MFMA, parity mode) or GDRN_DT_BF16 (bf16 MFMA, fp32
+ *     accumulate, throughput mode).  Statistics, losses, pose and parameter gradients are fp32.
+ *   - re-entrant and thread-compatible: one host thread per stream.
+ */
+#ifndef GDRN_HIP_H
+#define GDRN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDRN_ABI_VERSION 1
+enum { GDRN_F32 = 0, GDRN_BF16 = 1 };
+enum { GDRN_E_ARG = -1, GDRN_E_SHAPE = -2, GDRN_E_LAUNCH = -3 };
+
+int gdrn_version(void);
+/* fills name (<=255 chars), compute units and the gcn arch string of device `dev`. */
+int gdrn_device_info(int dev, char* name, int* cus, char* arch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM gather convolution (forward conv, data gradient, transposed stride-2 conv, linear).
+ * Replaces F.conv2d / F.conv_transpose2d / F.linear dispatched from
+ *   resnet_backbone.py:23,69-80 + torchvision BasicBlock (twin: pvnet_net/resnet.py:44-74),
+ *   cdpn_rot_head_region.py:81-135,183-185, conv_pnp_net.py:76-92,140-156,
+ * and their autograd data-gradients (engine.py:279).
+ *   mode 0: y[m][co] = sum_{ky,kx,c} x[n][oy*stride-pad+ky][ox*stride-pad+kx][c] * w[co][ky*KW+kx][c]
+ *           m = (n*Ho+oy)*Wo+ox, M = N*Ho*Wo
+ *   mode 1: transposed stride-2 gather (ConvTranspose2d forward / stride-2 data gradient):
+ *           y[n][oy][ox][co] = sum x[n][(oy+pad-ky)/2][(ox+pad-kx)/2][c] * w[co][ky*KW+kx][c] over the
+ *           taps where both divisions are exact; M = N*(Ho/2)*(Wo/2) (rows per parity class)
+ *   w: packed [w_rows][KH*KW][Cin] of dtype, zero padded to w_rows (multiple of the N tile, see
+ *      gdrn_conv_tile).  Cin*sizeof(dtype) must be a multiple of 128.
+ *   epilogue: + bias[co] (fp32), + addend[m][co] (dtype), act (0 none, 1 ReLU, 2 LeakyReLU 0.1);
+ *   stats != NULL: per-M-tile partial sum / sum of squares of the raw accumulators,
+ *      stats[tile][0][co], stats[tile][1][co] (gdrn_conv_stats_rows tiles) for the following BatchNorm.
+ */
+typedef struct gdrn_conv_params {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    const void* addend;
+    float* stats;
+    int Hi, Wi, Cin, x_cs;
+    int Ho, Wo, Cout, y_cs, add_cs;
+    int KH, KW, stride, pad;
+    int mode, act, out_f32;
+    int M, w_rows, dtype;
+} gdrn_conv_params;
+int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
+int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
+int gdrn_conv_stats_rows(const gdrn_conv_params* p);
+
+/* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
+ *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather).  variant: 0 = LDS transpose-read (bf16),
+ *   1 = scalar LDS reads (bf16 reference variant).  splits <= 0: automatic pixel-range split.
+ * Replaces the autograd weight-gradients of the same layers (engine.py:279). */
+typedef struct gdrn_wgrad_params {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int Hi, Wi, Cin, x_cs;
+    int Ho, Wo, Cout, dy_cs;
+    int KH, KW, stride, pad;
+    int M, dtype, splits, variant;
+} gdrn_wgrad_params;
+int gdrn_conv_wgrad(const gdrn_wgrad_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight / layout packing.
+ * gdrn_pack4: dst[a1][a2][t][b] (contiguous, A1 x A2 x T x B, dtype) = src[a1*s1 + a2*s2 + t'*st + b*sb]
+ *   (fp32), zero where a1>=A1v, a2>=A2v or b>=Bv; t' = flip ? T-1-t : t.
+ * gdrn_unpack4: the inverse scatter for gradients: src_grad[...] = packed[a1][a2][t][b] (fp32 -> fp32),
+ *   only valid indices are written.
+ * Used to turn the reference's OIHW / (Cin,Cout,kH,kW) / (out,in) parameter tensors
+ * (state_dict schema) into the kernels' [rows][tap][Cin] operand layout. */
+int gdrn_pack4(const float* src, void* dst, int A1, int A2, int T, int B, int A1v, int A2v, int Bv,
+               long long s1, long long s2, long long st, long long sb, int flip, int dtype, void* stream);
+int gdrn_unpack4(const float* packed, float* dst, int A1, int A2, int T, int B, int A1v, int A2v, int Bv,
+                 long long s1, long long s2, long long st, long long sb, int flip, void* stream);
+/* stem: conv1.weight (64,3,7,7) <-> [64][7][16 px * 4 ch]; image NCHW fp32 -> zero-padded NHWC4 */
+int gdrn_pack_stem_w(const float* w, void* dst, int dtype, void* stream);
+int gdrn_unpack_stem_w(const float* packed, float* dw, void* stream);
+int gdrn_pack_image(const float* img, void* dst, int N, int H, int W, int Hp, int Wp, int dtype, void* stream);
+/* generic casts between fp32 and dtype (n elements) */
+int gdrn_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream);
+int gdrn_cast_to_f32(const void* src, float* dst, long long n, int dtype, void* stream);
+/* NHWC (dtype, pixel stride cs) -> NCHW fp32 for handing maps back to the caller */
+int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, float* dst, int N, int HW, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (train / eval), fused with ReLU, residual add and max-pool where the graph has them.
+ * Replaces nn.BatchNorm2d + nn.ReLU + `out += identity` + nn.MaxPool2d at resnet_backbone.py:24-26,
+ * BasicBlock, cdpn_rot_head_region.py:92-93,113-114 and their backward. */
+int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                     float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
+int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
+                  long long npix, int C, int relu, int dtype, void* stream);
+/* sums[0][c] = sum g, sums[1][c] = sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy) */
+int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
+                       long long npix, int C, float* sums, int dtype, void* stream);
+/* dx = gamma*invstd*(g - sums0/n - xhat*sums1/n); optional g_out = g; dgamma = sums1, dbeta = sums0 */
+int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* sums, long long npix, int C, void* dx, void* g_out,
+                      float* dgamma, float* dbeta, int dtype, void* stream);
+int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
+                             int N, int H, int W, int C, int dtype, void* stream);
+int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale, const float* shift,
+                     void* g, int N, int H, int W, int C, int dtype, void* stream);
+
+/* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), cdpn_rot_head_region.py:102 */
+int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+
+/* nn.GroupNorm(G, C) + ReLU (conv_pnp_net.py:78-80) and backward.  dgamma/dbeta: fp32 [C], accumulated
+ * over samples (zeroed inside). */
+int gdrn_gn_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N,
+                     int HW, int C, int G, float eps, int dtype, void* stream);
+int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* mean_rstd,
+                     void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int dtype, void* stream);
+
+/* elementwise LeakyReLU(0.1) backward on [n] elements given the activation output y: dx = dy*(y>0?1:0.1) */
+int gdrn_leaky_bwd(const void* dy, const void* y, void* dx, long long n, int dtype, void* stream);
+/* bias gradient: db[c] = sum_rows dy[r][c]  (dy of dtype, row stride cs) */
+int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head tail: slicing of the 1x1 output conv into mask / xyz / region, channel softmax over
+ * region[:,1:], concat with roi_coord_2d, extent de-normalisation -> Patch-PnP input
+ * (GDRN.py:156-169, conv_pnp_net.py:121-125).  head: fp32 [N*HW][hs] = (mask, x, y, z, region[nreg+1]);
+ * pnp_in: dtype [N*HW][pcs], channels (xyz(3), coord2d(2), softmax(nreg), zero pad). */
+int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
+                       int N, int HW, int nreg, int dtype, void* stream);
+/* Map losses (GDRN.py:345-400): acc[0..2] = sum|x*m-gt*m| per coordinate, acc[3] = sum|mask-trunc|,
+ * acc[4] = CE_sum(region*m, gt_region*m), acc[5] = sum m  (acc: fp64 [8], zeroed inside). */
+int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                      const long long* gt_region, int N, int HW, int nreg, double* acc, void* stream);
+/* d_head[m][0..nreg+4] (dtype, stride dcs, rest zero) = grad of sum_k gw[k]*loss_k through the map
+ * losses plus the chain through the head tail from d_pnp_in (NULL: none).
+ * gw: device fp32 [5] = dL/d(loss_coor_x, loss_coor_y, loss_coor_z, loss_mask, loss_region). */
+int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in, const void* d_pnp_in, int pcs,
+                       const float* extents, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                       const long long* gt_region, const double* acc, const float* gw, void* d_head, int dcs, int N,
+                       int HW, int nreg, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pose decode + pose losses for one batch, one thread block per RoI:
+ *   rot6d -> R_allo (rot_reps.py:34-49); (dcx,dcy,z_rel) -> t (pose_from_pred_centroid_z.py:176-212);
+ *   allocentric -> egocentric (train: core/utils/utils.py:208-236 with eps; test: utils.py:39-94, no eps);
+ *   point-matching loss (pm_loss.py:82-114, misc.py:930-949, symmetric: pose_utils.py:430-482),
+ *   centroid / z L1 (GDRN.py:444-471).
+ * fc: fp32 [N][fs] rows = (rot6d[6], t_[3]).  sym: fp32 [N][Kmax][9] + sym_count[N] (NULL: none).
+ * outputs: rot [N][9], trans [N][3]; losses[3] = (loss_PM_R, loss_centroid, loss_z) (zeroed inside);
+ * dfc: fp32 [3][N][fs] unit gradients d loss_k / d fc (NULL in test mode); vis: fp32 [N][2] per-RoI
+ * rotation error (deg) / translation error. */
+typedef struct gdrn_pose_params {
+    const float* fc;
+    int fs;
+    const float* cams;
+    const float* centers;
+    const float* whs;
+    const float* ratios;
+    const float* extents;
+    const float* gt_rot;
+    const float* gt_trans;
+    const float* gt_trans_ratio;
+    const float* points;
+    int npts;
+    const float* sym;
+    const int* sym_count;
+    int Kmax;
+    int N;
+    int train;
+    float* rot;
+    float* trans;
+    float* losses;
+    float* dfc;
+    float* vis;
+} gdrn_pose_params;
+int gdrn_pose_loss(const gdrn_pose_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small fp32 helpers */
+/* out[r][c] = sum_k w[k] * in[k][r][c]  (combine the unit gradients with the incoming loss grads) */
+int gdrn_combine3(const float* in, const float* w, float* out, int n, void* stream);
+/* map-loss finalisation: losses[0..4] from acc (GDRN.py:347-400) */
+int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* losses, void* stream);
+
+/* Fused Ranger step (RAdam + gradient centralisation + Lookahead) over one parameter tensor
+ * (lib/torch_utils/solver/ranger.py:100-200).  The tensor is viewed as [rows][cols]; gc != 0 subtracts
+ * the per-row gradient mean first (ranger.py:144-145).  step_size / adaptive are the RAdam
+ * rectification terms of ranger.py:154-186 (host scalars); lookahead != 0 applies
+ * slow += alpha*(p - slow); p = slow (ranger.py:192-198). */
+int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* slow, int rows, int cols,
+                     int gc, float lr, float beta1, float beta2, float eps, float weight_decay, float step_size,
+                     int adaptive, int lookahead, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDRN_HIP_H */

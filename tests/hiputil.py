@@ -1,0 +1,122 @@
+"""Thin test-side wrappers that call the C-ABI entry points of libgdrn_hip.so on torch tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from gdrnet_amd import cabi
+from gdrnet_amd.cabi import BF16, F32, ConvParams, WgradParams, check, ptr
+
+DEV = "cuda:0"
+
+
+def tdt(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ru(a, b):
+    return (a + b - 1) // b * b
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / max(b.norm().item(), 1e-30))
+
+
+def nhwc(x, dt, cpad=None):
+    """NCHW fp32 cpu -> NHWC device tensor of dtype dt, channels zero-padded to cpad."""
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if cpad is not None and cpad > x.shape[-1]:
+        x = torch.nn.functional.pad(x, (0, cpad - x.shape[-1]))
+    return x.to(DEV).to(tdt(dt)).contiguous()
+
+
+def nchw(y, C_=None):
+    y = y.float().cpu()
+    if C_ is not None:
+        y = y[..., :C_]
+    return y.permute(0, 3, 1, 2).contiguous()
+
+
+def rounded(x, dt):
+    """value a tensor has after storage in dt (for building references of bf16 runs)."""
+    return x.to(tdt(dt)).float()
+
+
+def pack(w_src, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip, dt):
+    lib = cabi.load()
+    dst = torch.zeros(A1, A2, T, B, dtype=tdt(dt), device=DEV)
+    w = w_src.to(DEV).float().contiguous()
+    check(lib.gdrn_pack4(ptr(w), ptr(dst), A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip, dt, stream()), "pack4")
+    return dst
+
+
+def bn_rows(c):
+    return 64 if c <= 64 else ru(c, 128)
+
+
+def pack_fwd(w, dt, cin_p=None):
+    """OIHW -> [rows][KK][cin_p]"""
+    O, I, KH, KW = w.shape
+    KK = KH * KW
+    cin_p = cin_p or ru(I, 64)
+    return pack(w, bn_rows(O), 1, KK, cin_p, O, 1, I, I * KK, 0, 1, KK, 0, dt).view(bn_rows(O), KK, cin_p)
+
+
+def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
+    """OIHW -> [rows = in channels][KK][cout_p] (optionally tap-flipped)"""
+    O, I, KH, KW = w.shape
+    KK = KH * KW
+    cout_p = cout_p or ru(O, 64)
+    rows = bn_rows(rows_valid_pad or ru(I, 64))
+    return pack(w, rows, 1, KK, cout_p, I, 1, O, KK, 0, 1, I * KK, flip, dt).view(rows, KK, cout_p)
+
+
+def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
+              out_f32=0, y_cs=None, want_stats=False):
+    lib = cabi.load()
+    y_cs = y_cs or ru(Cout, 4)
+    ydt = torch.float32 if (out_f32 or dt == F32) else torch.bfloat16
+    y = torch.full((B, Ho, Wo, y_cs), float("nan"), dtype=ydt, device=DEV)
+    cp = ConvParams()
+    cp.x, cp.w, cp.y = ptr(x), ptr(w), ptr(y)
+    cp.bias, cp.addend = ptr(bias), ptr(addend)
+    cp.Hi, cp.Wi, cp.Cin, cp.x_cs = Hi, Wi, Cin, x_cs
+    cp.Ho, cp.Wo, cp.Cout, cp.y_cs = Ho, Wo, Cout, y_cs
+    cp.add_cs = addend.shape[-1] if addend is not None else 0
+    cp.KH, cp.KW, cp.stride, cp.pad = KH, KW, stride, pad
+    cp.mode, cp.act, cp.out_f32 = mode, act, out_f32
+    cp.M = B * (Ho // 2) * (Wo // 2) if mode == 1 else B * Ho * Wo
+    cp.w_rows, cp.dtype = w.shape[0], dt
+    stats = None
+    if want_stats:
+        rows = lib.gdrn_conv_stats_rows(C.byref(cp))
+        stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
+        cp.stats = ptr(stats)
+    check(lib.gdrn_conv_gemm(C.byref(cp), stream()), "conv_gemm")
+    torch.cuda.synchronize()
+    return y, stats
+
+
+def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0):
+    lib = cabi.load()
+    dw = torch.zeros(Cout, KH * KW, Cin, dtype=torch.float32, device=DEV)
+    wp = WgradParams()
+    wp.x, wp.dy, wp.dw = ptr(x), ptr(dy), ptr(dw)
+    wp.Hi, wp.Wi, wp.Cin, wp.x_cs = Hi, Wi, Cin, x_cs
+    wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Ho, Wo, Cout, dy_cs
+    wp.KH, wp.KW, wp.stride, wp.pad = KH, KW, stride, pad
+    wp.M, wp.dtype, wp.splits, wp.variant = B * Ho * Wo, dt, splits, variant
+    check(lib.gdrn_conv_wgrad(C.byref(wp), stream()), "conv_wgrad")
+    torch.cuda.synchronize()
+    return dw
+
+
+def randn(seed, *shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)

@@ -1,0 +1,242 @@
+"""End-to-end parity tests (-m gpu): the drop-in GDRN module on the HIP engine against (a) the golden
+vectors produced by the reference itself (tests/golden/g5_e2e.npz) and (b) the CPU oracle on the
+same seeded inputs.  fp32 mode is judged at the 1e-4 pose tolerance of BASELINE.json (the reference's
+own fp32-vs-fp64 noise floor is ~4e-5); bf16 mode is reported with its own, looser bound."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gdrnet_amd import cabi, synth
+from gdrnet_amd.cabi import check, ptr
+from gdrnet_amd.cfg import lm13_cfg, ycbv_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a)).double().flatten()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b)).double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def g5(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return np.load(os.path.join(golden_dir, "g5_e2e.npz"))
+
+
+def build(dtype, cfgfn=lm13_cfg):
+    from gdrnet_amd import GDRN
+
+    cfg = cfgfn(device=DEV)
+    cfg.MODEL.CDPN.HIP_DTYPE = dtype
+    model, opt = GDRN.build_model_optimizer(cfg)
+    model.load_state_dict(synth.make_state_dict(0))
+    return model, opt
+
+
+def to_dev(batch):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("B,tag", [(2, "b2"), (4, "b4")])
+def test_fp32_train_step_vs_reference(g5, B, tag):
+    model, _ = build("fp32")
+    model.train()
+    batch = to_dev(synth.make_batch(B, seed=1))
+    out_dict, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    assert out_dict == {}
+    names = list(g5[f"{tag}/loss_names"])
+    assert sorted(loss_dict.keys()) == names
+    vals = np.array([loss_dict[k].item() for k in names])
+    np.testing.assert_allclose(vals, g5[f"{tag}/loss_values"], rtol=2e-4)
+    plan = model.engine().plan(B, True, True)
+    fc = plan.fc_out.cpu()
+    assert rel(fc[:, :6], g5[f"{tag}/rot6d"]) < 1e-4
+    assert rel(fc[:, 6:9], g5[f"{tag}/t_"]) < 1e-4
+    assert rel(plan.rot, g5[f"{tag}/rot_train"]) < 1e-4      # BASELINE.json: pose within 1e-4 rel-err
+    assert rel(plan.trans, g5[f"{tag}/trans"]) < 1e-4
+    vd = model.vis_dict()
+    assert abs(vd["vis/error_R"] - float(g5[f"{tag}/vis_error_R"])) < 2e-2
+    assert abs(vd["vis/error_t"] - float(g5[f"{tag}/vis_error_t"])) < 2e-3
+    sum(loss_dict.values()).backward()
+    gn = dict(zip(g5[f"{tag}/grad_names"], g5[f"{tag}/grad_norms"]))
+    errs = {}
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        errs[n] = abs(p.grad.double().norm().item() - gn[n]) / max(gn[n], 1e-12)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # BN backward at B<=4 is ill-conditioned: the reference's own fp32 vs fp64 differs by 2e-2 at conv1
+    assert worst[0][1] < 3e-2, worst
+    for key in g5.files:
+        if key.startswith(f"{tag}/grad/"):
+            n = key[len(f"{tag}/grad/"):]
+            assert rel(dict(model.named_parameters())[n].grad, g5[key]) < 3e-2, n
+    sd = model.state_dict()
+    for key in g5.files:
+        if key.startswith(f"{tag}/buf/") and not key.endswith("nbt"):
+            assert rel(sd[key[len(f"{tag}/buf/"):]], g5[key]) < 1e-4, key
+    assert int(sd["backbone.bn1.num_batches_tracked"]) == int(g5[f"{tag}/buf/nbt"])
+
+
+def test_fp32_maps_and_inference_vs_reference(g5):
+    model, _ = build("fp32")
+    B = 2
+    batch = to_dev(synth.make_batch(B, seed=1))
+    # train-mode BN statistics, no loss: maps as the reference's sub-modules produce them
+    model.train()
+    model.cfg.TEST.USE_PNP = True
+    with torch.no_grad():
+        od = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=False))
+    full = torch.cat([od["mask"], od["coor_x"], od["coor_y"], od["coor_z"], od["region"]], 1)
+    assert full.shape == (B, 69, 64, 64)
+    assert rel(full, g5["b2/head_out_full"]) < 1e-4
+    # eval mode (running stats are still (0,1): load fresh weights) + test-mode pose decode
+    model.load_state_dict(synth.make_state_dict(0))
+    model.eval()
+    model.cfg.TEST.USE_PNP = False
+    with torch.no_grad():
+        od = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=False))
+    assert set(od.keys()) == {"rot", "trans"}
+    assert rel(od["rot"], g5["b2/eval_rot"]) < 1e-4
+    assert rel(od["trans"], g5["b2/eval_trans"]) < 1e-4
+
+
+def test_bf16_train_step_vs_reference(g5):
+    """bf16 operands cannot reach 1e-4 through ~40 layers; the throughput mode is held to
+    a stated looser bound instead and its measured error is what DESIGN.md reports."""
+    B, tag = 4, "b4"
+    model, _ = build("bf16")
+    model.train()
+    batch = to_dev(synth.make_batch(B, seed=1))
+    _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    names = list(g5[f"{tag}/loss_names"])
+    vals = np.array([loss_dict[k].item() for k in names])
+    np.testing.assert_allclose(vals, g5[f"{tag}/loss_values"], rtol=5e-2)
+    plan = model.engine().plan(B, True, True)
+    e_rot, e_tr = rel(plan.rot, g5[f"{tag}/rot_train"]), rel(plan.trans, g5[f"{tag}/trans"])
+    print("bf16 pose rel-err: rot %.3e trans %.3e" % (e_rot, e_tr))
+    assert e_rot < 5e-2 and e_tr < 5e-2
+    sum(loss_dict.values()).backward()
+    gn = dict(zip(g5[f"{tag}/grad_names"], g5[f"{tag}/grad_norms"]))
+    errs = [abs(p.grad.double().norm().item() - gn[n]) / max(gn[n], 1e-12) for n, p in model.named_parameters()]
+    print("bf16 grad-norm rel-err: median %.3e max %.3e" % (float(np.median(errs)), float(np.max(errs))))
+    assert np.median(errs) < 5e-2 and np.max(errs) < 0.5
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_vs_oracle_other_seed_and_sym(dtype):
+    """Same seeded inputs through the HIP path and the CPU oracle (YCB-V style symmetric PM loss, B=3)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import gdrn_oracle as O
+
+    B = 3
+    model, _ = build(dtype, ycbv_cfg)
+    model.train()
+    cpu_batch = synth.make_batch(B, seed=5, num_classes=21, cam="ycbv", with_sym=True)
+    sd = synth.make_state_dict(0)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    ref = O.gdrn_forward(sd, cpu_batch, do_loss=True, training=True, bufs={}, sym=True)
+    sum(ref["loss_dict"].values()).backward()
+    batch = to_dev(cpu_batch)
+    _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    tol = 2e-4 if dtype == "fp32" else 5e-2
+    for k, v in ref["loss_dict"].items():
+        assert abs(loss_dict[k].item() - v.item()) <= tol * max(abs(v.item()), 1e-3), k
+    sum(loss_dict.values()).backward()
+    params = dict(model.named_parameters())
+    gtol = 3e-2 if dtype == "fp32" else 0.5
+    for n in ("pnp_net.fc_r.weight", "pnp_net.fc_t.bias", "pnp_net.fc1.weight", "pnp_net.features.0.weight",
+              "rot_head_net.features.23.weight", "rot_head_net.features.20.weight", "rot_head_net.features.0.weight",
+              "backbone.layer4.2.conv2.weight", "backbone.layer2.0.downsample.0.weight", "backbone.layer1.0.conv1.weight",
+              "backbone.conv1.weight", "backbone.bn1.bias"):
+        assert rel(params[n].grad, sd[n].grad) < gtol, n
+
+
+def test_pose_decode_kernel_vs_reference_golden(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.cabi import PoseParams
+
+    lib = cabi.load()
+    g = np.load(os.path.join(golden_dir, "g3_pose.npz"))
+    N = g["rot6d"].shape[0]
+    pb = synth.make_batch(N, seed=21)
+    fc = torch.zeros(N, 64)
+    fc[:, :6] = torch.from_numpy(g["rot6d"])
+    fc[:, 6:9] = torch.from_numpy(g["t_"])
+    d = lambda t: t.to(DEV).float().contiguous()
+    fc_d, cams, ctr, wh, rat = d(fc), d(pb["roi_cam"]), d(torch.from_numpy(g["center"])), d(pb["roi_wh"]), d(pb["resize_ratio"])
+    for train, rkey, tkey in ((0, "rot_test", "trans_test"), (1, "rot_train", "trans_train")):
+        rot, trans = torch.zeros(N, 9, device=DEV), torch.zeros(N, 3, device=DEV)
+        pp = PoseParams()
+        pp.fc, pp.fs, pp.cams, pp.centers, pp.whs, pp.ratios = ptr(fc_d), 64, ptr(cams), ptr(ctr), ptr(wh), ptr(rat)
+        pp.N, pp.train, pp.rot, pp.trans = N, 0, ptr(rot), ptr(trans)  # decode only (no losses): train flag off
+        if train:
+            # train-mode decode needs the loss inputs; feed dummies and read rot/trans
+            ext, gr, gtr = d(pb["roi_extent"]), d(pb["ego_rot"]), d(pb["roi_trans_ratio"])
+            pts = d(pb["roi_points"][:, :64])
+            losses, dfc, vis = torch.zeros(3, device=DEV), torch.zeros(3, N, 64, device=DEV), torch.zeros(N, 2, device=DEV)
+            pp.train, pp.extents, pp.gt_rot, pp.gt_trans_ratio, pp.gt_trans = 1, ptr(ext), ptr(gr), ptr(gtr), ptr(d(pb["trans"]))
+            pp.points, pp.npts, pp.losses, pp.dfc, pp.vis = ptr(pts), 64, ptr(losses), ptr(dfc), ptr(vis)
+        check(lib.gdrn_pose_loss(C.byref(pp), torch.cuda.current_stream().cuda_stream), "pose_loss")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(trans.cpu().numpy(), g[tkey], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(rot.cpu().numpy().reshape(N, 3, 3), g[rkey], rtol=0, atol=5e-6)
+
+
+def test_ranger_vs_reference_golden(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.ranger import Ranger
+
+    g = np.load(os.path.join(golden_dir, "g6_ranger.npz"))
+    ps = [torch.nn.Parameter(torch.from_numpy(synth.hash_normal(31, f"p{i}", s).astype(np.float32)).to(DEV))
+          for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
+    opt = Ranger(ps, lr=1e-2, weight_decay=0)
+    for step in range(7):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(synth.hash_normal(32 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)
+        opt.step()
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"step{step}/p{i}"], rtol=2e-5, atol=2e-7)
+
+
+def test_full_size_properties_bs64():
+    """BASELINE config 2 (bs=64, bf16): size-independent properties instead of an oracle run --
+    finite losses / gradients, R in SO(3), losses invariant to the order of the RoIs in the batch
+    (all 8 losses are batch means), gradient w.r.t. a zero loss weight is zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 64
+    model, _ = build("bf16")
+    model.train()
+    batch = to_dev(synth.make_batch(B, seed=3))
+    _, L = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    vals = torch.stack([L[k] for k in sorted(L)])
+    assert torch.isfinite(vals).all()
+    plan = model.engine().plan(B, True, True)
+    R = plan.rot.double()
+    eye = torch.eye(3, dtype=torch.float64, device=DEV).expand(B, 3, 3)
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-5 and (torch.linalg.det(R) - 1).abs().max() < 1e-5
+    (L["loss_region"] * 0 + L["loss_mask"]).backward()
+    gmask = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in gmask.values())
+    assert float(gmask["pnp_net.fc1.weight"].abs().max()) == 0.0  # mask loss does not reach Patch-PnP
+    assert float(gmask["rot_head_net.features.23.weight"].abs().max()) > 0.0
+    # permutation invariance of the batch-mean losses (BN statistics are permutation invariant too)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(DEV)
+    pb = {k: (v[perm] if isinstance(v, torch.Tensor) else [v[i] for i in perm.tolist()]) for k, v in batch.items()}
+    model.load_state_dict(synth.make_state_dict(0))
+    _, L2 = model(pb["roi_img"], **synth.model_kwargs(pb, do_loss=True))
+    for k in L:
+        assert abs(L[k].item() - L2[k].item()) <= 2e-2 * max(abs(L[k].item()), 1e-3), k

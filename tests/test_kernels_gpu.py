@@ -1,0 +1,370 @@
+"""Kernel-level parity tests (-m gpu): every HIP kernel, called through the C-ABI, against the same op
+evaluated with plain PyTorch on the CPU (fp32).  fp32 kernels: tolerance 2e-5 relative L2 (different
+summation order only).  bf16 kernels: inputs are rounded to bf16 first so the reference sees the same
+operands; tolerance 6e-3 (bf16 output rounding is 2^-9 ~ 2e-3 relative per element)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gdrnet_amd import cabi
+from gdrnet_amd.cabi import BF16, F32, check, ptr
+
+pytestmark = pytest.mark.gpu
+
+DTS = [F32, BF16]
+TOL = {F32: 2e-5, BF16: 6e-3}
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import hiputil
+
+    cabi.load()
+    return hiputil
+
+
+# ---------------------------------------------------------------------------------------------- conv forward
+CONV_CASES = [
+    # B, I, O, H, k, stride, pad
+    (2, 64, 64, 16, 3, 1, 1),
+    (3, 64, 128, 16, 3, 2, 1),
+    (2, 128, 256, 8, 1, 2, 0),
+    (1, 256, 256, 16, 3, 1, 1),
+    (5, 512, 512, 8, 3, 1, 1),
+    (2, 256, 69, 16, 1, 1, 0),
+    (2, 69, 128, 16, 3, 2, 1),
+    (3, 64, 64, 7, 3, 1, 1),   # M not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(H, dt, case):
+    B, I, O, Hh, k, s, p = case
+    x = H.rounded(H.randn(1, B, I, Hh, Hh), dt)
+    w = H.rounded(H.randn(2, O, I, k, k) / math.sqrt(I * k * k), dt)
+    Ho = (Hh + 2 * p - k) // s + 1
+    cin_p = H.ru(I, 64)
+    xd = H.nhwc(x, dt, cin_p)
+    wp = H.pack_fwd(w, dt, cin_p)
+    y, stats = H.conv_gemm(xd, wp, B, Hh, Hh, cin_p, cin_p, Ho, Ho, O, k, k, s, p, dt, want_stats=True)
+    ref = F.conv2d(x, w, None, s, p)
+    assert H.rel(H.nchw(y, O), ref) < TOL[dt]
+    st = stats.sum(0).cpu()
+    assert H.rel(st[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dt]
+    assert H.rel(st[1], (ref * ref).sum((0, 2, 3))) < 1e-3
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_epilogue_bias_act_addend_f32out(H, dt):
+    B, I, O, Hh = 2, 256, 69, 16
+    x = H.rounded(H.randn(3, B, I, Hh, Hh), dt)
+    w = H.rounded(H.randn(4, O, I, 1, 1) / 16, dt)
+    bias = H.randn(5, O)
+    add = H.rounded(H.randn(6, B, O, Hh, Hh), dt)
+    xd, wp = H.nhwc(x, dt), H.pack_fwd(w, dt)
+    addd = H.nhwc(add, dt, 72)
+    for act in (0, 1, 2):
+        y, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 1, 1, 1, 0, dt, bias=bias.to(H.DEV), addend=addd, act=act, out_f32=1, y_cs=72)
+        ref = F.conv2d(x, w, bias) + add
+        ref = ref if act == 0 else (F.relu(ref) if act == 1 else F.leaky_relu(ref, 0.1))
+        assert y.dtype == torch.float32
+        assert H.rel(H.nchw(y, O), ref) < (2e-5 if dt == F32 else 1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_stem_conv(H, dt):
+    """7x7 s2 p3 conv on a zero-padded NHWC4 image as a 7x1-tap gather of 16 px * 4 ch (resnet_backbone.py:23)."""
+    lib = cabi.load()
+    B = 2
+    img = H.rounded(torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(7)), dt)
+    w = H.rounded(H.randn(8, 64, 3, 7, 7) / 12, dt)
+    imgp = torch.zeros(B, 262, 272, 4, dtype=H.tdt(dt), device=H.DEV)
+    check(lib.gdrn_pack_image(ptr(img.to(H.DEV)), ptr(imgp), B, 256, 256, 262, 272, dt, H.stream()), "pack_image")
+    wp = torch.zeros(64, 7, 64, dtype=H.tdt(dt), device=H.DEV)
+    check(lib.gdrn_pack_stem_w(ptr(w.to(H.DEV)), ptr(wp), dt, H.stream()), "pack_stem_w")
+    y, stats = H.conv_gemm(imgp, wp, B, 262, 272, 64, 4, 128, 128, 64, 7, 1, 2, 0, dt, want_stats=True)
+    ref = F.conv2d(img, w, None, 2, 3)
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    # weight gradient through the same gather + unpack
+    dy = H.rounded(H.randn(9, B, 64, 128, 128) * 0.1, dt)
+    dw = H.conv_wgrad(imgp, H.nhwc(dy, dt), B, 262, 272, 64, 4, 128, 128, 64, 64, 7, 1, 2, 0, dt)
+    g = torch.zeros(64, 3, 7, 7, device=H.DEV)
+    check(lib.gdrn_unpack_stem_w(ptr(dw), ptr(g), H.stream()), "unpack_stem_w")
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(img, wr, None, 2, 3).backward(dy)
+    assert H.rel(g, wr.grad) < (1e-4 if dt == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_fc_as_conv(H, dt):
+    """fc1 = 8x8 'valid' conv over the [B,8,8,128] map with the NCHW flatten order c*64+h*8+w (conv_pnp_net.py:140-152)."""
+    B = 4
+    x = H.rounded(H.randn(10, B, 128, 8, 8), dt)
+    w = H.rounded(H.randn(11, 1024, 8192) / 90, dt)
+    b = H.randn(12, 1024)
+    xd = H.nhwc(x, dt)
+    wp = H.pack_fwd(w.view(1024, 128, 8, 8), dt)
+    y, _ = H.conv_gemm(xd, wp, B, 8, 8, 128, 128, 1, 1, 1024, 8, 8, 1, 0, dt, bias=b.to(H.DEV), act=2)
+    ref = F.leaky_relu(F.linear(x.reshape(B, -1), w, b), 0.1)
+    assert H.rel(y.view(B, 1024), ref) < TOL[dt]
+
+
+# ---------------------------------------------------------------------------------------------- data gradient
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 3, 1, 1), (2, 64, 128, 16, 3, 2, 1), (3, 128, 256, 8, 1, 2, 0), (2, 256, 69, 8, 1, 1, 0),
+                                  (2, 69, 128, 16, 3, 2, 1)])
+def test_conv_dgrad(H, dt, case):
+    B, I, O, Hh, k, s, p = case
+    x = H.randn(20, B, I, Hh, Hh).requires_grad_(True)
+    w = H.rounded(H.randn(21, O, I, k, k) / math.sqrt(O * k * k), dt)
+    Ho = (Hh + 2 * p - k) // s + 1
+    dy = H.rounded(H.randn(22, B, O, Ho, Ho), dt)
+    F.conv2d(x, w, None, s, p).backward(dy)
+    op, ip = H.ru(O, 64), H.ru(I, 64)
+    dyd = H.nhwc(dy, dt, op)
+    if s == 1:
+        wd = H.pack_dgrad(w, dt, flip=1 if k == 3 else 0, cout_p=op)
+        dx, _ = H.conv_gemm(dyd, wd, B, Ho, Ho, op, op, Hh, Hh, ip, k, k, 1, p, dt)
+    else:
+        wd = H.pack_dgrad(w, dt, flip=0, cout_p=op)
+        dx, _ = H.conv_gemm(dyd, wd, B, Ho, Ho, op, op, Hh, Hh, ip, k, k, 2, p, dt, mode=1)
+    assert H.rel(H.nchw(dx, I), x.grad) < TOL[dt]
+    if ip > I:
+        assert float(dx[..., I:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_transpose_fwd_bwd(H, dt):
+    """ConvTranspose2d(512,256,3,s2,p1,op1) (cdpn_rot_head_region.py:81-91): forward = transposed gather, data
+    gradient = stride-2 conv, weight gradient = conv wgrad with the roles of input / output grad swapped."""
+    B = 2
+    x = H.rounded(H.randn(30, B, 512, 8, 8), dt).requires_grad_(True)
+    w = H.rounded(H.randn(31, 512, 256, 3, 3) / 34, dt).requires_grad_(True)
+    ref = F.conv_transpose2d(x, w, None, 2, 1, 1)
+    dy = H.rounded(H.randn(32, B, 256, 16, 16), dt)
+    ref.backward(dy)
+    KK = 9
+    wf = H.pack(w.detach(), 256, 1, KK, 512, 256, 1, 512, KK, 0, 1, 256 * KK, 0, dt).view(256, KK, 512)
+    wd = H.pack(w.detach(), 512, 1, KK, 256, 512, 1, 256, 256 * KK, 0, 1, KK, 0, dt).view(512, KK, 256)
+    xd, dyd = H.nhwc(x.detach(), dt), H.nhwc(dy, dt)
+    y, stats = H.conv_gemm(xd, wf, B, 8, 8, 512, 512, 16, 16, 256, 3, 3, 2, 1, dt, mode=1, want_stats=True)
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    assert H.rel(stats.sum(0)[0].cpu(), ref.sum((0, 2, 3))) < 1e-3 + TOL[dt]
+    dx, _ = H.conv_gemm(dyd, wd, B, 16, 16, 256, 256, 8, 8, 512, 3, 3, 2, 1, dt, mode=0)
+    assert H.rel(H.nchw(dx), x.grad) < TOL[dt]
+    dw = H.conv_wgrad(dyd, xd, B, 16, 16, 256, 256, 8, 8, 512, 512, 3, 3, 2, 1, dt)  # [ci=512][tap][co=256]
+    assert H.rel(dw.view(512, 3, 3, 256).permute(0, 3, 1, 2), w.grad) < (1e-4 if dt == F32 else 1e-2)
+
+
+# ---------------------------------------------------------------------------------------------- weight gradient
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 3, 1, 1), (3, 64, 128, 16, 3, 2, 1), (2, 128, 128, 9, 3, 1, 1), (2, 128, 256, 8, 1, 2, 0),
+                                  (2, 256, 69, 8, 1, 1, 0), (4, 1024, 256, 1, 1, 1, 0)])
+def test_conv_wgrad(H, dt, case, variant):
+    if dt == F32 and variant == 1:
+        pytest.skip("variant only exists for bf16")
+    B, I, O, Hh, k, s, p = case
+    x = H.rounded(H.randn(40, B, I, Hh, Hh), dt)
+    w = H.randn(41, O, I, k, k).requires_grad_(True)
+    Ho = (Hh + 2 * p - k) // s + 1
+    dy = H.rounded(H.randn(42, B, O, Ho, Ho), dt)
+    F.conv2d(x, w, None, s, p).backward(dy)
+    op = H.bn_rows(O)
+    dw = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt, op), B, Hh, Hh, I, I, Ho, Ho, O, op, k, k, s, p, dt, variant=variant)
+    got = dw.view(O, k, k, I).permute(0, 3, 1, 2)
+    assert H.rel(got, w.grad) < (5e-5 if dt == F32 else 1e-2)
+
+
+# ---------------------------------------------------------------------------------------------- BatchNorm
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C_", [64, 256, 512])
+def test_batchnorm_train_fwd_bwd(H, dt, C_):
+    lib = cabi.load()
+    B, Hh = 3, 12
+    x = H.rounded(H.randn(50, B, C_, Hh, Hh) * 2 + 0.5, dt).requires_grad_(True)
+    res = H.rounded(H.randn(51, B, C_, Hh, Hh), dt)
+    gam = (0.5 + torch.rand(C_, generator=torch.Generator().manual_seed(1))).requires_grad_(True)
+    bet = (torch.rand(C_, generator=torch.Generator().manual_seed(2)) - 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(C_), torch.ones(C_)
+    yref = F.relu(F.batch_norm(x, rm, rv, gam, bet, True, 0.1, 1e-5) + res)
+    dy = H.rounded(H.randn(52, B, C_, Hh, Hh), dt)
+    yref.backward(dy)
+    npix = B * Hh * Hh
+    xd, resd, dyd = H.nhwc(x.detach(), dt), H.nhwc(res, dt), H.nhwc(dy, dt)
+    # partial stats as the conv epilogue would emit them (2 row tiles)
+    xf = xd.float().view(npix, C_)
+    half = npix // 2
+    part = torch.stack([torch.stack([xf[:half].sum(0), (xf[:half] ** 2).sum(0)]), torch.stack([xf[half:].sum(0), (xf[half:] ** 2).sum(0)])]).contiguous()
+    dev = H.DEV
+    mk = lambda: torch.zeros(C_, device=dev)
+    mean, invstd, scale, shift = mk(), mk(), mk(), mk()
+    rmd, rvd, nbt = torch.zeros(C_, device=dev), torch.ones(C_, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    st = H.stream()
+    check(lib.gdrn_bn_finalize(ptr(part), 2, C_, float(npix), ptr(gam.detach().to(dev)), ptr(bet.detach().to(dev)), ptr(rmd), ptr(rvd), ptr(nbt),
+                               0.1, 1e-5, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st), "bn_finalize")
+    y = torch.empty_like(xd)
+    check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), ptr(resd), ptr(y), npix, C_, 1, dt, st), "bn_apply")
+    assert H.rel(H.nchw(y), yref) < TOL[dt]
+    assert H.rel(rmd, rm) < 1e-5 and H.rel(rvd, rv) < 1e-5 and int(nbt) == 1
+    sums = torch.zeros(2 * C_, device=dev)
+    dx, gout = torch.empty_like(xd), torch.empty_like(xd)
+    dg, db = mk(), mk()
+    yd = H.nhwc(yref.detach(), dt)  # mask source: the stored activation
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), npix, C_, ptr(sums), dt, st), "bn_bwd_reduce")
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam.detach().to(dev)), ptr(sums), npix, C_, ptr(dx),
+                                ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
+    tol = 2e-4 if dt == F32 else 1e-2
+    assert H.rel(H.nchw(dx), x.grad) < tol
+    assert H.rel(dg, gam.grad) < tol and H.rel(db, bet.grad) < tol
+    assert H.rel(H.nchw(gout), dy * (yref > 0)) < TOL[dt]
+    # eval-mode scale/shift
+    check(lib.gdrn_bn_eval_params(ptr(gam.detach().to(dev)), ptr(bet.detach().to(dev)), ptr(rmd), ptr(rvd), 1e-5, C_, ptr(scale), ptr(shift), st), "bn_eval")
+    check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), None, ptr(y), npix, C_, 0, dt, st), "bn_apply")
+    assert H.rel(H.nchw(y), F.batch_norm(x.detach(), rm, rv, gam.detach(), bet.detach(), False, 0.1, 1e-5)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bn_relu_maxpool(H, dt):
+    lib = cabi.load()
+    B, C_, Hh = 2, 64, 24
+    x = H.rounded(H.randn(60, B, C_, Hh, Hh), dt).requires_grad_(True)
+    scale, shift = 0.5 + torch.rand(C_), torch.rand(C_) - 0.5
+    ref = F.max_pool2d(F.relu(x * scale[None, :, None, None] + shift[None, :, None, None]), 3, 2, 1)
+    dy = H.rounded(H.randn(61, B, C_, Hh // 2, Hh // 2), dt)
+    ref.backward(dy)
+    xd, dyd = H.nhwc(x.detach(), dt), H.nhwc(dy, dt)
+    y = torch.empty(B, Hh // 2, Hh // 2, C_, dtype=H.tdt(dt), device=H.DEV)
+    idx = torch.empty(B, Hh // 2, Hh // 2, C_, dtype=torch.uint8, device=H.DEV)
+    sc, sh = scale.to(H.DEV), shift.to(H.DEV)
+    check(lib.gdrn_bn_relu_maxpool_fwd(ptr(xd), ptr(sc), ptr(sh), ptr(y), ptr(idx), B, Hh, Hh, C_, dt, H.stream()), "pool_fwd")
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    g = torch.empty_like(xd)
+    check(lib.gdrn_maxpool_bwd(ptr(dyd), ptr(idx), ptr(xd), ptr(sc), ptr(sh), ptr(g), B, Hh, Hh, C_, dt, H.stream()), "pool_bwd")
+    # g = grad wrt the BN output (pre-ReLU) = x.grad / scale
+    assert H.rel(H.nchw(g) * scale[None, :, None, None], x.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_upsample2x(H, dt):
+    lib = cabi.load()
+    B, C_, Hh = 2, 256, 16
+    x = H.rounded(H.randn(70, B, C_, Hh, Hh), dt).requires_grad_(True)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = H.rounded(H.randn(71, B, C_, 2 * Hh, 2 * Hh), dt)
+    ref.backward(dy)
+    xd, dyd = H.nhwc(x.detach(), dt), H.nhwc(dy, dt)
+    y = torch.empty(B, 2 * Hh, 2 * Hh, C_, dtype=H.tdt(dt), device=H.DEV)
+    check(lib.gdrn_upsample2x_fwd(ptr(xd), ptr(y), B, Hh, Hh, C_, dt, H.stream()), "up_fwd")
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    dx = torch.empty_like(xd)
+    check(lib.gdrn_upsample2x_bwd(ptr(dyd), ptr(dx), B, Hh, Hh, C_, dt, H.stream()), "up_bwd")
+    assert H.rel(H.nchw(dx), x.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Hh", [32, 8])
+def test_groupnorm_relu(H, dt, Hh):
+    lib = cabi.load()
+    B, C_ = 3, 128
+    x = H.rounded(H.randn(80, B, C_, Hh, Hh) * 1.5 + 0.3, dt).requires_grad_(True)
+    gam = (0.5 + torch.rand(C_)).requires_grad_(True)
+    bet = (torch.rand(C_) - 0.5).requires_grad_(True)
+    ref = F.relu(F.group_norm(x, 32, gam, bet, 1e-5))
+    dy = H.rounded(H.randn(81, B, C_, Hh, Hh), dt)
+    ref.backward(dy)
+    dev = H.DEV
+    xd, dyd = H.nhwc(x.detach(), dt), H.nhwc(dy, dt)
+    y = torch.empty_like(xd)
+    mr = torch.zeros(B, 32, 2, device=dev)
+    g, b = gam.detach().to(dev), bet.detach().to(dev)
+    check(lib.gdrn_gn_relu_fwd(ptr(xd), ptr(g), ptr(b), ptr(y), ptr(mr), B, Hh * Hh, C_, 32, 1e-5, dt, H.stream()), "gn_fwd")
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    dx = torch.empty_like(xd)
+    dg, db = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    yd = H.nhwc(ref.detach(), dt)
+    check(lib.gdrn_gn_relu_bwd(ptr(dyd), ptr(yd), ptr(xd), ptr(g), ptr(mr), ptr(dx), ptr(dg), ptr(db), B, Hh * Hh, C_, 32, dt, H.stream()), "gn_bwd")
+    tol = 2e-4 if dt == F32 else 1e-2
+    assert H.rel(H.nchw(dx), x.grad) < tol
+    assert H.rel(dg, gam.grad) < tol and H.rel(db, bet.grad) < tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_leaky_and_bias_grad(H, dt):
+    lib = cabi.load()
+    B, C_ = 4, 1024
+    y = H.rounded(H.randn(90, B, C_), dt)
+    dy = H.rounded(H.randn(91, B, C_), dt)
+    yd, dyd = y.to(H.DEV).to(H.tdt(dt)), dy.to(H.DEV).to(H.tdt(dt))
+    dx = torch.empty_like(yd)
+    check(lib.gdrn_leaky_bwd(ptr(dyd), ptr(yd), ptr(dx), B * C_, dt, H.stream()), "leaky_bwd")
+    assert H.rel(dx, dy * torch.where(y > 0, 1.0, 0.1)) < TOL[dt]
+    db = torch.zeros(C_, device=H.DEV)
+    check(lib.gdrn_bias_grad(ptr(dyd), C_, B, C_, ptr(db), dt, H.stream()), "bias_grad")
+    assert H.rel(db, dy.sum(0)) < 1e-5
+    # strided / partially valid columns, many rows (head output conv bias)
+    R = 5000
+    d2 = H.rounded(H.randn(92, R, 128), dt)
+    d2d = d2.to(H.DEV).to(H.tdt(dt))
+    db2 = torch.zeros(69, device=H.DEV)
+    check(lib.gdrn_bias_grad(ptr(d2d), 128, R, 69, ptr(db2), dt, H.stream()), "bias_grad")
+    assert H.rel(db2, d2[:, :69].sum(0)) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- head tail + map losses
+@pytest.mark.parametrize("dt", DTS)
+def test_head_tail_and_map_losses(H, dt):
+    """GDRN.py:156-169 glue + conv_pnp_net.py:121-125 + GDRN.py:345-400, forward and backward, against autograd."""
+    from gdrnet_amd import synth
+    from oracle import gdrn_oracle as O
+
+    lib = cabi.load()
+    B, HW, nreg, hs = 2, 4096, 64, 72
+    M = B * HW
+    b = synth.make_batch(B, seed=9)
+    b["roi_mask_visib"][1, :8] = 0
+    head = (H.randn(100, B, 69, 64, 64) * 1.5).requires_grad_(True)
+    mask, cx, cy, cz, region = head[:, :1], head[:, 1:2], head[:, 2:3], head[:, 3:4], head[:, 4:]
+    coor_feat = torch.cat([cx, cy, cz, b["roi_coord_2d"]], 1)
+    sm = torch.softmax(region[:, 1:], 1)
+    xyz = (coor_feat[:, :3] - 0.5) * b["roi_extent"].view(B, 3, 1, 1)
+    pnp_ref = torch.cat([xyz, coor_feat[:, 3:], sm], 1)
+    d_pnp = H.rounded(H.randn(101, B, 69, 64, 64) * 0.01, dt)
+    dummy_rot = torch.eye(3).expand(B, 3, 3)
+    L = O.gdrn_loss(mask, cx, cy, cz, region, dummy_rot, torch.zeros(B, 3), dict(b, ego_rot=dummy_rot))
+    gw = torch.tensor([1.0, 0.5, 2.0, 1.5, 0.7])
+    tot = gw[0] * L["loss_coor_x"] + gw[1] * L["loss_coor_y"] + gw[2] * L["loss_coor_z"] + gw[3] * L["loss_mask"] + gw[4] * L["loss_region"]
+    (tot + (pnp_ref * d_pnp).sum()).backward()
+
+    dev, st = H.DEV, H.stream()
+    head_d = torch.zeros(M, hs, device=dev)
+    head_d[:, :69] = head.detach().permute(0, 2, 3, 1).reshape(M, 69).to(dev)
+    f = lambda t: t.to(dev).float().contiguous()
+    c2d, ext, gxyz, mv, mt = f(b["roi_coord_2d"]), f(b["roi_extent"]), f(b["roi_xyz"]), f(b["roi_mask_visib"]), f(b["roi_mask_trunc"])
+    greg = b["roi_region"].to(dev).contiguous()
+    pnp = torch.full((M, 128), float("nan"), dtype=H.tdt(dt), device=dev)
+    check(lib.gdrn_head_tail_fwd(ptr(head_d), hs, ptr(c2d), ptr(ext), ptr(pnp), 128, B, HW, nreg, dt, st), "head_tail_fwd")
+    got = pnp.float().cpu().view(B, 64, 64, 128)
+    assert H.rel(got[..., :69].permute(0, 3, 1, 2), pnp_ref.detach()) < TOL[dt]
+    assert float(got[..., 69:].abs().max()) == 0.0
+    acc = torch.zeros(8, dtype=torch.float64, device=dev)
+    losses = torch.zeros(8, device=dev)
+    check(lib.gdrn_map_loss_fwd(ptr(head_d), hs, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), B, HW, nreg, ptr(acc), st), "map_loss_fwd")
+    check(lib.gdrn_map_loss_finalize(ptr(acc), B, HW, ptr(losses), st), "map_loss_finalize")
+    ref = torch.stack([L[k] for k in ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region")]).detach()
+    np.testing.assert_allclose(losses[:5].cpu().numpy(), ref.numpy(), rtol=2e-5)
+    dpn = torch.zeros(M, 128, dtype=H.tdt(dt), device=dev)
+    dpn[:, :69] = d_pnp.permute(0, 2, 3, 1).reshape(M, 69).to(dev).to(H.tdt(dt))
+    dh = torch.full((M, 128), float("nan"), dtype=H.tdt(dt), device=dev)
+    check(lib.gdrn_head_tail_bwd(ptr(head_d), hs, ptr(pnp), ptr(dpn), 128, ptr(ext), ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc),
+                                 ptr(gw.to(dev)), ptr(dh), 128, B, HW, nreg, dt, st), "head_tail_bwd")
+    gotd = dh.float().cpu().view(B, 64, 64, 128)
+    assert H.rel(gotd[..., :69].permute(0, 3, 1, 2), head.grad) < (1e-4 if dt == F32 else 2e-2)
+    assert float(gotd[..., 69:].abs().max()) == 0.0
