@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4_t mma_step<float>(uint4 a, uint4 b, f32x4_t c) 
 }
 
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const gdrn_conv_params p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);  // elements of K per stage row
     constexpr int A_LD = BN / 32;               // weight-tile 16B loads per thread
     constexpr int B_LD = BM / 32;               // pixel-tile 16B loads per thread
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const gdrn_conv_params p
     const int g = lane >> 4, r16 = lane & 15;
 
     const int NT = (p.Cout + BN - 1) / BN;
-    const int mt = blockIdx.x / NT, nt = blockIdx.x % NT;
+    // XCD-aware tile order: hardware places workgroup b on XCD b % 8 (each XCD has a private 4 MiB L2).
+    // Give every XCD a contiguous run of tiles, so the N-tiles of one pixel tile and the neighbouring
+    // pixel tiles (which share 3x3 halo rows) hit the same L2.  Bijective for any grid size.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int mt = bid / NT, nt = bid % NT;
     const int co0 = nt * BN;
 
     // ---- tile -> pixel mapping -------------------------------------------------------------
@@ -122,54 +130,79 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const gdrn_conv_params p
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rw[A_LD], rx[B_LD];
+    // Staging registers.  Loads are branch-free (out-of-image taps read a clamped in-bounds address and
+    // are then zeroed) with 32-bit byte offsets from a uniform base, so that nothing spills and the
+    // loads of stage s+1 stay in flight under the MFMAs of stage s.
+    // (named scalars instead of arrays: hipcc left a uint4 staging array in scratch memory, which put a
+    //  vmcnt(0) + scratch round trip between the global loads and the MFMAs of every stage.)
+    uint4 rw0, rw1, rw2, rw3, rx0, rx1, rx2, rx3;
+    rw0 = rw1 = rw2 = rw3 = rx0 = rx1 = rx2 = rx3 = make_uint4(0, 0, 0, 0);
     const char* xg = reinterpret_cast<const char*>(p.x);
     const char* wg = reinterpret_cast<const char*>(p.w);
+    // weight buffer is zero-padded to a multiple of BN rows
+    const unsigned wrow0 = (unsigned)(co0 + lrow) * (unsigned)(KK * p.Cin) * (unsigned)sizeof(T) + seg * 16;
+    const unsigned wstep = 32u * (unsigned)(KK * p.Cin) * (unsigned)sizeof(T);
+    const int HiM = p.Hi - 1, WiM = p.Wi - 1;
 
-    auto load_stage = [&](int s) {
-        const int ti = s / kch, kc = s - ti * kch;
-        const int tap = s_taps[ti];
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int co = co0 + lrow + 32 * i;  // weight buffer is zero-padded to a multiple of BN rows
-            const size_t off = ((size_t)(co * KK + tap) * p.Cin + (size_t)kc * EPS) * sizeof(T) + seg * 16;
-            rw[i] = *reinterpret_cast<const uint4*>(wg + off);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            int iy, ix;
-            if (p.mode == 1) { iy = (pya[i] - ky) >> 1; ix = (pxa[i] - kx) >> 1; }
-            else { iy = pya[i] + ky; ix = pxa[i] + kx; }
-            const bool ok = pval[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const size_t off = ((size_t)(pbase[i] + iy * p.Wi + ix) * p.x_cs + (size_t)kc * EPS) * sizeof(T) + seg * 16;
-                v = *reinterpret_cast<const uint4*>(xg + off);
-            }
-            rx[i] = v;
-        }
-    };
-    auto write_stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<uint4*>(sW + (size_t)buf * BN * ROWB + (lrow + 32 * i) * ROWB + pseg * 16) = rw[i];
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<uint4*>(sX + (size_t)buf * BM * ROWB + (lrow + 32 * i) * ROWB + pseg * 16) = rx[i];
-    };
+    // stage s <-> (channel chunk kc, valid-tap index ti): chunk outer, tap inner -- the taps of one
+    // 128-byte channel chunk re-read the same few input rows back to back (L1/L2 hits).
+    int n_kc = 0, n_ti = 0;  // coordinates of the NEXT stage to load
+#define GDRN_LDW(i, dst) dst = *reinterpret_cast<const uint4*>(wg + (wrow0 + (i) * wstep + wo_));
+#define GDRN_LDX(i, dst)                                                                                       \
+    {                                                                                                         \
+        int iy_, ix_;                                                                                         \
+        if (p.mode == 1) { iy_ = (pya[i] - ky_) >> 1; ix_ = (pxa[i] - kx_) >> 1; }                            \
+        else { iy_ = pya[i] + ky_; ix_ = pxa[i] + kx_; }                                                      \
+        const bool ok_ = pval[i] && iy_ >= 0 && iy_ <= HiM && ix_ >= 0 && ix_ <= WiM;                         \
+        const int iyc_ = min(max(iy_, 0), HiM), ixc_ = min(max(ix_, 0), WiM);                                 \
+        const unsigned off_ = ((unsigned)(pbase[i] + iyc_ * p.Wi + ixc_) * (unsigned)p.x_cs + (unsigned)(n_kc * EPS)) * \
+                                  (unsigned)sizeof(T) + seg * 16;                                             \
+        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + off_);                                          \
+        dst = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                              \
+    }
+#define GDRN_LOAD_STAGE()                                                                                     \
+    do {                                                                                                      \
+        const int tap_ = s_taps[n_ti];                                                                        \
+        const int ky_ = tap_ / p.KW, kx_ = tap_ - ky_ * p.KW;                                                 \
+        const unsigned wo_ = (unsigned)(tap_ * p.Cin + n_kc * EPS) * (unsigned)sizeof(T);                     \
+        GDRN_LDW(0, rw0) GDRN_LDW(1, rw1)                                                                     \
+        if constexpr (A_LD > 2) { GDRN_LDW(2, rw2) GDRN_LDW(3, rw3) }                                         \
+        GDRN_LDX(0, rx0) GDRN_LDX(1, rx1)                                                                     \
+        if constexpr (B_LD > 2) { GDRN_LDX(2, rx2) GDRN_LDX(3, rx3) }                                         \
+        if (++n_ti == ntap) { n_ti = 0; ++n_kc; }                                                             \
+    } while (0)
+#define GDRN_STW(i, src) *reinterpret_cast<uint4*>(sW + (buf_) * (BN * ROWB) + (lrow + 32 * (i)) * ROWB + pseg * 16) = src;
+#define GDRN_STX(i, src) *reinterpret_cast<uint4*>(sX + (buf_) * (BM * ROWB) + (lrow + 32 * (i)) * ROWB + pseg * 16) = src;
+#define GDRN_WRITE_STAGE(b__)                                                                                 \
+    do {                                                                                                      \
+        const int buf_ = (b__);                                                                               \
+        GDRN_STW(0, rw0) GDRN_STW(1, rw1)                                                                     \
+        if constexpr (A_LD > 2) { GDRN_STW(2, rw2) GDRN_STW(3, rw3) }                                         \
+        GDRN_STX(0, rx0) GDRN_STX(1, rx1)                                                                     \
+        if constexpr (B_LD > 2) { GDRN_STX(2, rx2) GDRN_STX(3, rx3) }                                         \
+    } while (0)
 
     if (nstage > 0) {
-        load_stage(0);
-        write_stage(0);
+        GDRN_LOAD_STAGE();
+        GDRN_WRITE_STAGE(0);
     }
     __syncthreads();
 
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nstage) load_stage(s + 1);
+        if (s + 1 < nstage) GDRN_LOAD_STAGE();
         const unsigned char* aW = sW + (size_t)buf * BN * ROWB;
         const unsigned char* aX = sX + (size_t)buf * BM * ROWB;
+        // fp32 (parity) mode: accumulate each 32-deep stage in a fresh register tile and add it to the
+        // running sum, so no fp32 addition chain is longer than 32 + #stages (instead of K = taps*Cin):
+        // keeps the rounding error of K = 2304..4608 reductions at the level of a blocked CPU sum.
+        f32x4_t part[FN][FM];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) part[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 fa[FN], fb[FM];
@@ -187,11 +220,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const gdrn_conv_params p
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b] = mma_step<T>(fa[a], fb[b], acc[a][b]);
+                for (int b = 0; b < FM; ++b) {
+                    if constexpr (sizeof(T) == 4) part[a][b] = mma_step<T>(fa[a], fb[b], part[a][b]);
+                    else acc[a][b] = mma_step<T>(fa[a], fb[b], acc[a][b]);
+                }
         }
-        if (s + 1 < nstage) write_stage(buf ^ 1);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] += part[a][b];
+        }
+        if (s + 1 < nstage) GDRN_WRITE_STAGE(buf ^ 1);
         __syncthreads();
     }
+#undef GDRN_LOAD_STAGE
+#undef GDRN_WRITE_STAGE
+#undef GDRN_LDW
+#undef GDRN_LDX
+#undef GDRN_STW
+#undef GDRN_STX
 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane holds D[i = g*4+j][col = r16] of fragment (a,b): channel co0 + wn*WN + a*16 + g*4 + j,

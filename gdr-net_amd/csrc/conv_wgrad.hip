@@ -37,16 +37,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
     const int wa = wave >> 1, wb = wave & 1;
     const int g = lane >> 4, r16 = lane & 15;
 
-    const int co0 = blockIdx.x * BCO;
-    const int ncit = p.Cin / BCI;
-    const int tap = blockIdx.y / ncit, ci0 = (blockIdx.y % ncit) * BCI;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    // 1-D grid = splits x tiles, tile fastest, remapped so that each XCD (private L2; hardware puts
+    // workgroup b on XCD b % 8) owns a contiguous run: all (co, tap, ci) tiles of one pixel range then
+    // run on the same XCD at the same time and share its dY / X rows through that L2.
     const int KK = p.KH * p.KW;
+    const int ncit = p.Cin / BCI;
+    const int ncot = (p.Cout + BCO - 1) / BCO;
+    const int ntile = ncot * ncit * KK;
+    const int nsplit = (int)gridDim.x / ntile;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int split = bid / ntile;
+    int tile = bid - split * ntile;
+    const int cot = tile % ncot; tile /= ncot;
+    const int cit = tile % ncit;
+    const int tap = tile / ncit;
+    const int co0 = cot * BCO, ci0 = cit * BCI;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
 
     // pixel range of this split
     const int nstage_all = (p.M + BKM - 1) / BKM;
-    const int per = (nstage_all + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int s_begin = blockIdx.z * per;
+    const int per = (nstage_all + nsplit - 1) / nsplit;
+    const int s_begin = split * per;
     const int s_end = min(nstage_all, s_begin + per);
     if (s_begin >= s_end) return;
 
@@ -109,28 +124,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
 #pragma unroll
             for (int ks = 0; ks < BKM / 32; ++ks) {
                 bf16x8_t fa[FA], fb[FB];
-                const int mrow = ks * 32 + g * 8;  // this lane group's 8 reduction rows
                 if (p.variant == 0) {
                     // ds_read_b64_tr_b16: lane q of a 16-lane group supplies the address of 4 contiguous
                     // bf16 of row (q>>2), columns (q&3)*4.. of a [4 m][16 ch] block and receives
-                    // channel q for those 4 rows.
-                    const int trow = mrow + (r16 >> 2), tcol = (r16 & 3) * 4;
+                    // channel q for those 4 rows.  Lane group g takes reduction rows {4g..4g+3} with the
+                    // first read and {16+4g..} with the second (the same map for both operands, so the
+                    // k order is consistent): the two groups of a 32-lane half then touch 8 consecutive
+                    // rows, which the 32-byte row padding spreads over all 64 banks (conflict-free).
+                    const int trow = ks * 32 + g * 4 + (r16 >> 2), tcol = (r16 & 3) * 4;
 #pragma unroll
                     for (int a = 0; a < FA; ++a) {
                         const unsigned char* q0 = tA + trow * PA + (wa * WCO + a * 16 + tcol) * 2;
                         bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0));
-                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 4 * PA));
+                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 16 * PA));
                         fa[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
 #pragma unroll
                     for (int b = 0; b < FB; ++b) {
                         const unsigned char* q0 = tB + trow * PB + (wb * WCI + b * 16 + tcol) * 2;
                         bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0));
-                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 4 * PB));
+                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 16 * PB));
                         fb[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 } else {
                     // reference variant: 8 scalar 16-bit LDS reads per fragment (slow, layout-obvious)
+                    const int mrow = ks * 32 + g * 8;  // this lane group's 8 reduction rows
 #pragma unroll
                     for (int a = 0; a < FA; ++a) {
                         unsigned short e[8];
@@ -211,10 +229,10 @@ int launch(const gdrn_wgrad_params& p, hipStream_t st) {
     int splits = p.splits;
     if (splits <= 0) {
         const int nst = cdiv(p.M, BKM);
-        splits = max(1, min(nst / 4 > 0 ? nst / 4 : 1, cdiv(1536, tiles)));
+        // every split adds one fp32 atomic per output element: keep >= 8 stages per block and ~4 blocks per CU
+        splits = max(1, min(nst / 8 > 0 ? nst / 8 : 1, cdiv(1024, tiles)));
     }
-    dim3 grid(cdiv(p.Cout, BCO), (p.Cin / BCI) * p.KH * p.KW, splits);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI>), dim3(tiles * splits), dim3(256), smem, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -279,6 +279,13 @@ class Plan:
             if s:
                 check(s, f"conv_wgrad {L.key}")
 
+        if L.kind == "stem":
+            macs = self.B * 128 * 128 * 64 * 3 * 49
+        elif L.kind == "convT":
+            macs = self.B * 64 * L.O * L.I * L.KK
+        else:
+            macs = self.B * Ho * Wo * L.O * L.I * L.KK
+        run.meta = dict(kernel=f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'}>", flops=2.0 * macs, layer=L.key + ":wgrad")
         return run
 
     def _unpack(self, L):
@@ -341,7 +348,15 @@ class Plan:
     def _build(self):
         e, lib, B = self.e, self.e.lib, self.B
         S, T, WL = self.bn_train, self.has_backward, self.with_loss  # batch stats | backward graph | losses
-        E = e._empty
+
+        def E(*shape, dtype=None):
+            # every plan buffer is pinned in self.keep: the pre-bound C structs hold RAW device pointers, so a
+            # buffer referenced only through them would otherwise be returned to the caching allocator when
+            # _build() returns and be handed out again while the kernels still write to it
+            t = e._empty(*shape, dtype=dtype)
+            self.keep.append(t)
+            return t
+
         F32t = torch.float32
         self.stats = E(B * 32768 + 65536, dtype=F32t)  # per-M-tile BN partial sums (max over layers)
         nreg = e.nreg

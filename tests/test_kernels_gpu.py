@@ -207,8 +207,9 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     mk = lambda: torch.zeros(C_, device=dev)
     mean, invstd, scale, shift = mk(), mk(), mk(), mk()
     rmd, rvd, nbt = torch.zeros(C_, device=dev), torch.ones(C_, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    gam_d, bet_d = gam.detach().to(dev), bet.detach().to(dev)  # keep alive: the launches are asynchronous
     st = H.stream()
-    check(lib.gdrn_bn_finalize(ptr(part), 2, C_, float(npix), ptr(gam.detach().to(dev)), ptr(bet.detach().to(dev)), ptr(rmd), ptr(rvd), ptr(nbt),
+    check(lib.gdrn_bn_finalize(ptr(part), 2, C_, float(npix), ptr(gam_d), ptr(bet_d), ptr(rmd), ptr(rvd), ptr(nbt),
                                0.1, 1e-5, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st), "bn_finalize")
     y = torch.empty_like(xd)
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), ptr(resd), ptr(y), npix, C_, 1, dt, st), "bn_apply")
@@ -219,14 +220,14 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     dg, db = mk(), mk()
     yd = H.nhwc(yref.detach(), dt)  # mask source: the stored activation
     check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), npix, C_, ptr(sums), dt, st), "bn_bwd_reduce")
-    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam.detach().to(dev)), ptr(sums), npix, C_, ptr(dx),
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), npix, C_, ptr(dx),
                                 ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
     tol = 2e-4 if dt == F32 else 1e-2
     assert H.rel(H.nchw(dx), x.grad) < tol
     assert H.rel(dg, gam.grad) < tol and H.rel(db, bet.grad) < tol
     assert H.rel(H.nchw(gout), dy * (yref > 0)) < TOL[dt]
     # eval-mode scale/shift
-    check(lib.gdrn_bn_eval_params(ptr(gam.detach().to(dev)), ptr(bet.detach().to(dev)), ptr(rmd), ptr(rvd), 1e-5, C_, ptr(scale), ptr(shift), st), "bn_eval")
+    check(lib.gdrn_bn_eval_params(ptr(gam_d), ptr(bet_d), ptr(rmd), ptr(rvd), 1e-5, C_, ptr(scale), ptr(shift), st), "bn_eval")
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), None, ptr(y), npix, C_, 0, dt, st), "bn_apply")
     assert H.rel(H.nchw(y), F.batch_norm(x.detach(), rm, rv, gam.detach(), bet.detach(), False, 0.1, 1e-5)) < TOL[dt]
 
@@ -363,8 +364,9 @@ def test_head_tail_and_map_losses(H, dt):
     dpn = torch.zeros(M, 128, dtype=H.tdt(dt), device=dev)
     dpn[:, :69] = d_pnp.permute(0, 2, 3, 1).reshape(M, 69).to(dev).to(H.tdt(dt))
     dh = torch.full((M, 128), float("nan"), dtype=H.tdt(dt), device=dev)
+    gw_d = gw.to(dev)
     check(lib.gdrn_head_tail_bwd(ptr(head_d), hs, ptr(pnp), ptr(dpn), 128, ptr(ext), ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc),
-                                 ptr(gw.to(dev)), ptr(dh), 128, B, HW, nreg, dt, st), "head_tail_bwd")
+                                 ptr(gw_d), ptr(dh), 128, B, HW, nreg, dt, st), "head_tail_bwd")
     gotd = dh.float().cpu().view(B, 64, 64, 128)
     assert H.rel(gotd[..., :69].permute(0, 3, 1, 2), head.grad) < (1e-4 if dt == F32 else 2e-2)
     assert float(gotd[..., 69:].abs().max()) == 0.0
