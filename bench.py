@@ -96,6 +96,11 @@ def measure_roofline(model, plan, kctx, dtype):
     plan.gw.fill_(1.0)
     run(plan.bwd)
     torch.cuda.synchronize()
+    # dominant kernel = the conv instantiation with the largest share of this step's conv time
+    per_k = {}
+    for a, b, m in allev:
+        per_k[m["kernel"]] = per_k.get(m["kernel"], 0.0) + a.elapsed_time(b)
+    dom = max(per_k, key=per_k.get)
     ev = [x for x in allev if x[2]["kernel"] == dom]
     if os.environ.get("GDRN_LAYER_TABLE"):
         rows = sorted(((a.elapsed_time(b) * 1e3, m) for a, b, m in allev), key=lambda r: -r[0])

@@ -58,6 +58,10 @@ _SIGS = {
     "gdrn_conv_gemm": [C.POINTER(ConvParams), P],
     "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],
+    "gdrn_pack_wfrag": [P, P, I, I, I, P],
+    "gdrn_conv3x3_halo": [C.POINTER(ConvParams), P],
+    "gdrn_conv3x3_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
+    "gdrn_conv3x3_stats_rows": [C.POINTER(ConvParams)],
     "gdrn_conv_wgrad": [C.POINTER(WgradParams), P],
     "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
     "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],

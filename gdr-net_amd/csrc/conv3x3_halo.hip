@@ -1,0 +1,361 @@
+// Halo-tiled 3x3 stride-1 pad-1 convolution on MFMA for gfx950 (NHWC, fp32 accumulate) -- the layers that
+// carry ~90 % of the path's MACs: every BasicBlock conv of ResNet-34 except the three stride-2 ones
+// (resnet_backbone.py:69-80) and the six 256->256 head convs (cdpn_rot_head_region.py:103-123), forward
+// and data-gradient (the latter with tap-flipped, transposed weights).
+//
+// Structure (what the PMC counters of the generic gather kernel asked for: it spent 41 % of its wave
+// cycles parked at s_waitcnt / s_barrier and issued 4 VALU per MFMA for swizzled LDS addressing):
+//   * a workgroup (4 waves) owns a TH x TW patch of output pixels of one image and BN output channels;
+//     wave w owns ALL pixels x channels [w*BN/4, (w+1)*BN/4): no weight is loaded twice in a workgroup;
+//   * the (TH+2) x (TW+2) input patch of one 128-byte channel chunk lives in LDS (zero-filled halo, rows of
+//     144 bytes = 128 + 16 pad: 16 consecutive pixels hit 16 distinct 16-byte bank slots).  The nine taps
+//     read it at shifted positions -- every ds_read_b128 is `lane base + immediate`, no address VALU;
+//   * the weights never touch LDS: they are pre-packed FRAGMENT-MAJOR (gdrn_pack_wfrag: one contiguous
+//     1 KiB block per (16 channels, tap, chunk, k-step) holding exactly what the 64 lanes of an MFMA A
+//     operand need), so a wave fetches its operand with one fully coalesced global_load_dwordx4 from L2,
+//     three stages ahead of use in a register ring;
+//   * hence NO barrier inside a channel chunk: one __syncthreads per 9 taps (patch double buffer swap).
+// MFMA: v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32, weights = A operand, pixels = B operand, so a
+// lane ends with 4 consecutive output channels of one pixel (8/16-byte stores).
+#include <algorithm>
+
+#include "common.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+constexpr int ROWB = 128;   // bytes of K per stage row
+constexpr int PITCH = 144;  // LDS pixel pitch
+
+template <typename T>
+__device__ __forceinline__ f32x4_t mma_step(uint4 a, uint4 b, f32x4_t c);
+template <>
+__device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mma_step<float>(uint4 a, uint4 b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+
+// fragment-major weight packing: granule (16 B) permutation of the row-major [rows][9][Cin] operand
+template <typename T>
+__global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int Cin) {
+    constexpr int EPS = ROWB / (int)sizeof(T);
+    constexpr int GE = 16 / (int)sizeof(T);  // elements per 16-byte granule
+    const int kch = Cin / EPS;
+    const long long total = (long long)rows * 9 * Cin / GE;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // destination granule index: ((((cb*9 + tap)*kch + kc)*2 + ks)*64 + lane)
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int ks = (int)(r & 1); r >>= 1;
+        const int kc = (int)(r % kch); r /= kch;
+        const int tap = (int)(r % 9);
+        const int cb = (int)(r / 9);
+        const int co = cb * 16 + (lane & 15), g = lane >> 4;
+        const size_t so = ((size_t)(co * 9 + tap) * Cin + (size_t)kc * EPS) + (size_t)(ks * 4 + g) * GE;
+        *reinterpret_cast<uint4*>(dst + i * GE) = *reinterpret_cast<const uint4*>(src + so);
+    }
+}
+
+template <typename T, int TH, int TW, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
+    constexpr int EPS = ROWB / (int)sizeof(T);
+    constexpr int BM = TH * TW;
+    constexpr int PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
+    constexpr int PBYTES = PPIX * PITCH;
+    constexpr int PSEG = PPIX * 8;            // 16-byte segments of one patch chunk
+    constexpr int PSLICE = (PSEG + 8) / 9;    // segments fetched per tap stage
+    static_assert(PSLICE <= 256, "one patch segment per thread per stage");
+    constexpr int FM = BM / 16;               // pixel fragments per wave (all pixels)
+    constexpr int FN = BN / 64;               // 16-channel fragments per wave
+    constexpr int WQ = FN * 2;                // weight 1-KiB loads per wave per stage (FN frags x 2 k-steps)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x patch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+
+    const int NTn = (p.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: neighbouring patches / the N tiles of a patch share one L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = bid % NTn;
+    const int mt = bid / NTn;  // pixel-tile index (stats row)
+    int t = mt;
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int co0 = nt * BN;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int kch = p.Cin / EPS;
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    // this wave's fragment-major weight stream: block index ((cb*9 + tap)*kch + kc)*2 + ks, 1 KiB each
+    const int cb0 = (co0 + wave * (BN / 4)) / 16;
+    const char* wl = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
+
+    // ---- patch slice geometry of this thread (slice st = linear segment ids [st*PSLICE, (st+1)*PSLICE))
+    unsigned poff[9];
+    int pdst[9];
+    unsigned pokm = 0;
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+        const int id = st * PSLICE + tid;
+        const int pp = id >> 3, sg = id & 7;
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        const bool inpatch = tid < PSLICE && id < PSEG;
+        const bool ok = inpatch && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+        poff[st] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * (unsigned)sizeof(T) + sg * 16;
+        pdst[st] = inpatch ? (pp * PITCH + sg * 16) : -1;
+        pokm |= ok ? (1u << st) : 0u;
+    }
+
+    // ---- pixel-fragment lane base inside a patch: fragment b, lane column r16 -> pixel (oy, ox)
+    int lbase;
+    if constexpr (TW == 16) lbase = r16 * PITCH + g * 16;                             // oy = b, ox = r16
+    else lbase = ((r16 >> 3) * PW + (r16 & 7)) * PITCH + g * 16;                      // oy = 2b + (r16>>3)
+    constexpr int FROW = (TW == 16) ? PW * PITCH : 2 * PW * PITCH;                    // byte step per fragment b
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // weight stream: stage s = kc*9 + tap; per stage WQ loads of 1 KiB
+    auto wptr = [&](int kc, int tap, int a, int ks) -> const uint4* {
+        return reinterpret_cast<const uint4*>(wl + ((size_t)((((cb0 + a) * 9 + tap) * kch + kc) * 2 + ks) << 10));
+    };
+    uint4 wq0[WQ], wq1[WQ], wq2[WQ];  // 3-stage register ring (slot = tap % 3)
+    uint4 rp = make_uint4(0, 0, 0, 0);
+
+#define LOADW(dst, kc_, tap_)                                                   \
+    {                                                                           \
+        _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_) {                     \
+            dst[a_ * 2 + 0] = *wptr(kc_, tap_, a_, 0);                          \
+            dst[a_ * 2 + 1] = *wptr(kc_, tap_, a_, 1);                          \
+        }                                                                       \
+    }
+#define LOADP(dst, kc_, st_)                                                    \
+    {                                                                           \
+        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + (poff[st_] + (unsigned)((kc_) * ROWB))); \
+        dst = ((pokm >> (st_)) & 1u) ? v_ : make_uint4(0, 0, 0, 0);            \
+    }
+#define WRITEP(src, pb_, st_)                                                   \
+    {                                                                           \
+        if (pdst[st_] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[st_]) = src; \
+    }
+
+    // ---- prologue: patch of chunk 0 (nine slices in flight together), weights of stages 0..2
+    {
+        uint4 q0, q1, q2, q3, q4, q5, q6, q7, q8;
+        LOADP(q0, 0, 0) LOADP(q1, 0, 1) LOADP(q2, 0, 2) LOADP(q3, 0, 3) LOADP(q4, 0, 4)
+        LOADP(q5, 0, 5) LOADP(q6, 0, 6) LOADP(q7, 0, 7) LOADP(q8, 0, 8)
+        LOADW(wq0, 0, 0) LOADW(wq1, 0, 1) LOADW(wq2, 0, 2)
+        WRITEP(q0, 0, 0) WRITEP(q1, 0, 1) WRITEP(q2, 0, 2) WRITEP(q3, 0, 3) WRITEP(q4, 0, 4)
+        WRITEP(q5, 0, 5) WRITEP(q6, 0, 6) WRITEP(q7, 0, 7) WRITEP(q8, 0, 8)
+    }
+    __syncthreads();
+
+    // one tap stage: 2 k-steps x (FN weight frags in registers) x (FM pixel frags from LDS at immediate offsets)
+#define STAGE(WQ_, TAP_)                                                                                        \
+    {                                                                                                           \
+        constexpr int tsh_ = ((TAP_) / 3) * PW * PITCH + ((TAP_) % 3) * PITCH;                                  \
+        f32x4_t part[FN][FM];                                                                                   \
+        if constexpr (sizeof(T) == 4) {                                                                         \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) part[a_][b_] = f32x4_t{0.f, 0.f, 0.f, 0.f};   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                   \
+            uint4 fb_[FM];                                                                                      \
+            _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                                   \
+                fb_[b_] = *reinterpret_cast<const uint4*>(pcur + (b_ * FROW + tsh_ + ks_ * 64));               \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) {                                             \
+                    if constexpr (sizeof(T) == 4) part[a_][b_] = mma_step<T>(WQ_[a_ * 2 + ks_], fb_[b_], part[a_][b_]); \
+                    else acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + ks_], fb_[b_], acc[a_][b_]);                    \
+                }                                                                                               \
+        }                                                                                                       \
+        if constexpr (sizeof(T) == 4) {                                                                         \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) acc[a_][b_] += part[a_][b_];                  \
+        }                                                                                                       \
+    }
+    // stage TAP_ of chunk kc: compute, refill the ring slot for stage +3, move one slice of the next patch
+#define STEP(WQ_, TAP_)                                                                                         \
+    {                                                                                                           \
+        if (more_p) {                                                                                           \
+            if constexpr ((TAP_) > 0) WRITEP(rp, pb ^ 1, (TAP_) - 1)                                            \
+            LOADP(rp, kc + 1, TAP_)                                                                             \
+        }                                                                                                       \
+        STAGE(WQ_, TAP_)                                                                                        \
+        {                                                                                                       \
+            constexpr int nt_ = ((TAP_) + 3) % 9;                                                               \
+            const int nk_ = kc + (((TAP_) + 3) >= 9 ? 1 : 0);                                                   \
+            if (nk_ < kch) LOADW(WQ_, nk_, nt_)                                                                 \
+        }                                                                                                       \
+    }
+
+    for (int kc = 0; kc < kch; ++kc) {
+        const int pb = kc & 1;
+        const bool more_p = kc + 1 < kch;
+        const unsigned char* pcur = smem + pb * PBYTES + lbase;
+        STEP(wq0, 0) STEP(wq1, 1) STEP(wq2, 2)
+        STEP(wq0, 3) STEP(wq1, 4) STEP(wq2, 5)
+        STEP(wq0, 6) STEP(wq1, 7) STEP(wq2, 8)
+        if (more_p) WRITEP(rp, pb ^ 1, 8)
+        __syncthreads();
+    }
+#undef LOADW
+#undef LOADP
+#undef WRITEP
+#undef STAGE
+#undef STEP
+
+    // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) { const float v = acc[a][b][j]; s1 += v; s2 += v * v; }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                const int c = co0 + wave * (BN / 4) + a * 16 + g * 4 + j;
+                if (r16 == 0 && c < p.Cout) {
+                    p.stats[((size_t)mt * 2 + 0) * p.Cout + c] = s1;
+                    p.stats[((size_t)mt * 2 + 1) * p.Cout + c] = s2;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = b * 16 + r16;
+        const size_t orow = (size_t)(n * p.Ho + y0 + m / TW) * p.Wo + x0 + (m % TW);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int c0 = co0 + wave * (BN / 4) + a * 16 + g * 4;
+            if (c0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
+            const bool full = (c0 + 3 < p.Cout);
+            if (p.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) v[j] += p.bias[c0 + j];
+            }
+            if (p.addend != nullptr) {
+                const T* ap = reinterpret_cast<const T*>(p.addend) + orow * p.add_cs + c0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) v[j] += ld1<T>(ap + j);
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.1f * v[j];
+            }
+            if (p.out_f32 || sizeof(T) == 4) {
+                float* yp = reinterpret_cast<float*>(p.y) + orow * p.y_cs + c0;
+                if (full) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) yp[j] = v[j];
+            } else {
+                bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + orow * p.y_cs + c0;
+                if (full) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (c0 + j < p.Cout) yp[j] = f2bf(v[j]);
+            }
+        }
+    }
+}
+
+template <typename T, int TH, int TW, int BN>
+int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
+    constexpr size_t smem = 2 * (size_t)(TH + 2) * (TW + 2) * PITCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return GDRN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int grid = N * (p.Ho / TH) * (p.Wo / TW) * cdiv(p.Cout, BN);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN>), dim3(grid), dim3(256), smem, st, p);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+}  // namespace
+
+// tile of the halo kernel for a shape: th x tw output pixels, bn channels; 0 if the shape is not covered
+extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn) {
+    if (!p || !th || !tw || !bn) return GDRN_ERR_ARG;
+    *th = *tw = *bn = 0;
+    if (p->mode != 0 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->Hi != p->Ho || p->Wi != p->Wo) return GDRN_OK;
+    if ((p->Ho % 8) || (p->Wo % 8)) return GDRN_OK;
+    if (p->dtype != GDRN_DT_BF16) return GDRN_OK;  // parity (fp32) mode keeps the generic kernel: its per-stage partial
+                                                    // accumulators plus the weight ring do not fit the register file
+    *th = 8;
+    *tw = (p->Wo % 16 == 0) ? 16 : 8;
+    *bn = p->Cout <= 64 ? 64 : 128;
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p) {
+    int th, tw, bn;
+    if (gdrn_conv3x3_tile(p, &th, &tw, &bn) != GDRN_OK || th == 0) return GDRN_ERR_SHAPE;
+    const int hw = p->Ho * p->Wo;
+    return (p->M / hw) * (p->Ho / th) * (p->Wo / tw);
+}
+
+extern "C" int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, void* stream) {
+    if (!src || !dst || rows <= 0 || (rows % 16) || Cin <= 0) return GDRN_ERR_ARG;
+    const int esz = dtype == GDRN_DT_BF16 ? 2 : 4;
+    if ((Cin * esz) % ROWB) return GDRN_ERR_SHAPE;
+    const long long n = (long long)rows * 9 * Cin * esz / 16;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_wfrag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Cin);
+    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(pack_wfrag_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
+    else return GDRN_ERR_ARG;
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+// p->w must be the FRAGMENT-MAJOR operand produced by gdrn_pack_wfrag from the row-major [w_rows][9][Cin] one.
+extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
+    if (!pp || !pp->x || !pp->w || !pp->y) return GDRN_ERR_ARG;
+    const gdrn_conv_params& p = *pp;
+    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    const int esz = p.dtype == GDRN_DT_BF16 ? 2 : 4;
+    int th, tw, bn;
+    gdrn_conv3x3_tile(pp, &th, &tw, &bn);
+    if (th == 0) return GDRN_ERR_SHAPE;
+    if (p.Cin <= 0 || (p.Cin * esz) % ROWB != 0 || (p.x_cs * esz) % 16 != 0 || p.Cout <= 0 || (p.y_cs & 3)) return GDRN_ERR_SHAPE;
+    const int hw = p.Ho * p.Wo;
+    if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
+    if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
+    if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
+    const int N = p.M / hw;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (tw == 16) return bn == 64 ? launch<bf16_t, 8, 16, 64>(p, N, st) : launch<bf16_t, 8, 16, 128>(p, N, st);
+    return bn == 64 ? launch<bf16_t, 8, 8, 64>(p, N, st) : launch<bf16_t, 8, 8, 128>(p, N, st);
+}

@@ -46,6 +46,9 @@ class Engine:
             raise cabi.GdrnHipError("the HIP engine needs parameters on a GPU device (no CPU fallback)")
         self.nreg = num_regions
         self.wgrad_variant = wgrad_variant
+        import os as _os
+
+        self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
         self.layers = OrderedDict()
         self._versions = {}
         self._build_layers()
@@ -117,6 +120,9 @@ class Engine:
             L.cin_d, L.rows_d = out_ch, bn_rows(in_ch)
             L.wd = self._zeros(L.rows_d, KK, out_ch)
             L.dwp_shape = (O, KK, in_ch)
+        L.wfF = L.wdF = None
+        if kind == "conv" and KK == 9 and not s2 and self.dt == BF16:  # halo-kernel operands (fragment-major)
+            L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
         self.layers[key] = L
         return L
 
@@ -192,6 +198,9 @@ class Engine:
                 check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0, self.dt, st), "pack4")
                 flip = 1 if (KK == 9 and not L.s2) else 0
                 check(lib.gdrn_pack4(ptr(w), ptr(L.wd), L.rows_d, 1, KK, L.cin_d, I, 1, O, KK, 0, 1, I * KK, flip, self.dt, st), "pack4")
+                if L.wfF is not None:
+                    check(lib.gdrn_pack_wfrag(ptr(L.wf), ptr(L.wfF), L.rows_f, L.cin_f, self.dt, st), "pack_wfrag")
+                    check(lib.gdrn_pack_wfrag(ptr(L.wd), ptr(L.wdF), L.rows_d, L.cin_d, self.dt, st), "pack_wfrag")
 
     # ------------------------------------------------------------------------------------------ plans
     def plan(self, B, bn_train, with_loss):
@@ -236,12 +245,20 @@ class Plan:
         cp.w_rows = rows or L.rows_f
         cp.dtype = e.dt
         self.keep.append(cp)
-        fn, ref = e.lib.gdrn_conv_gemm, C.byref(cp)
+        ref = C.byref(cp)
+        # 3x3 stride-1 layers (forward and data-gradient) run on the halo-tiled kernel
+        th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
+        e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
+        use_halo = e.use_halo and th.value > 0 and L.kind == "conv" and L.wfF is not None
+        if use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
+            cp.w = ptr(L.wfF if w is None else L.wdF)
+        fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
+        cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
         def run(st, ctx):
             s = fn(ref, st)
             if s:
-                check(s, f"conv_gemm {L.key}")
+                check(s, f"conv {L.key}")
 
         # metadata for the roofline measurement in bench.py: kernel instantiation + algorithmic FLOPs
         bm, bn = C.c_int(0), C.c_int(0)
@@ -256,12 +273,13 @@ class Plan:
             if L.kind == "convT":
                 sp = 8 * 8  # Hin*Win*Cin*Cout*k^2
             macs = self.B * sp * L.O * L.I * L.KK
-        run.meta = dict(kernel=f"conv_gemm_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bm.value},{bn.value}>", flops=2.0 * macs,
-                        layer=L.key)
+        dn = "bf16" if e.dt == BF16 else "f32"
+        kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value}>" if use_halo else f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
+        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key)
         return run, cp
 
     def _stats_rows(self, cp):
-        return self.e.lib.gdrn_conv_stats_rows(C.byref(cp))
+        return cp._stats_rows
 
     def _wgrad(self, L, x, dy, Hi, Wi, Ho, Wo, stride, pad, cin, cout, x_cs, dy_cs, KH=None, KW=None):
         e = self.e
@@ -285,7 +303,9 @@ class Plan:
             macs = self.B * 64 * L.O * L.I * L.KK
         else:
             macs = self.B * Ho * Wo * L.O * L.I * L.KK
-        run.meta = dict(kernel=f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'}>", flops=2.0 * macs, layer=L.key + ":wgrad")
+        bco, bci = (64 if cout <= 64 else 128), (128 if cin % 128 == 0 else 64)
+        run.meta = dict(kernel=f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>", flops=2.0 * macs,
+                        layer=L.key + ":wgrad")
         return run
 
     def _unpack(self, L):

@@ -67,6 +67,17 @@ typedef struct gdrn_conv_params {
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
 int gdrn_conv_stats_rows(const gdrn_conv_params* p);
+/* Halo-tiled variant for KH=KW=3, stride 1, pad 1, mode 0, H and W multiples of 8 (same params / epilogue contract):
+ * the input patch of a TH x TW pixel tile is staged in LDS once per 128-byte channel chunk and the nine taps read
+ * it at shifted offsets.  gdrn_conv3x3_tile reports (th, tw, bn), th = 0 when the shape is not covered;
+ * gdrn_conv3x3_stats_rows the number of per-tile partial-statistics rows it writes. */
+/* p->w of gdrn_conv3x3_halo is the FRAGMENT-MAJOR operand: gdrn_pack_wfrag permutes the 16-byte granules of the
+ * row-major [rows][9][Cin] operand into one contiguous 1 KiB block per (16 rows, tap, 128-byte chunk, k-step) =
+ * exactly the 64 lanes of an MFMA A operand, so the kernel streams weights L2 -> registers without LDS. bf16 only. */
+int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, void* stream);
+int gdrn_conv3x3_halo(const gdrn_conv_params* p, void* stream);
+int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
+int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
 
 /* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
  *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather).  variant: 0 = LDS transpose-read (bf16),

@@ -78,8 +78,12 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
-              out_f32=0, y_cs=None, want_stats=False):
+              out_f32=0, y_cs=None, want_stats=False, halo=False):
     lib = cabi.load()
+    if halo:  # the halo kernel takes the fragment-major permutation of the same operand
+        wf = torch.empty_like(w)
+        check(lib.gdrn_pack_wfrag(ptr(w), ptr(wf), w.shape[0], Cin, dt, stream()), "pack_wfrag")
+        w = wf
     y_cs = y_cs or ru(Cout, 4)
     ydt = torch.float32 if (out_f32 or dt == F32) else torch.bfloat16
     y = torch.full((B, Ho, Wo, y_cs), float("nan"), dtype=ydt, device=DEV)
@@ -95,10 +99,10 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     cp.w_rows, cp.dtype = w.shape[0], dt
     stats = None
     if want_stats:
-        rows = lib.gdrn_conv_stats_rows(C.byref(cp))
+        rows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
         stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
         cp.stats = ptr(stats)
-    check(lib.gdrn_conv_gemm(C.byref(cp), stream()), "conv_gemm")
+    check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
     torch.cuda.synchronize()
     return y, stats
 

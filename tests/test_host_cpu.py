@@ -1,0 +1,133 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/gdrn_hip.h declares, host-side
+logic (config gate, state-dict schema, synthetic inputs, Ranger scalars), and the product path refuses to run
+without a GPU (no silent CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gdrnet_amd import cabi, synth
+from gdrnet_amd.cfg import lm13_cfg, lmo_cfg, ycbv_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gdrn_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(gdrn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    if not os.path.exists(cabi.LIB_PATH):
+        from gdrnet_amd import build
+
+        build.build(verbose=False)
+    lib = cabi.load()
+    declared = _header_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/gdrn_hip.h but not exported"
+    assert sorted(cabi.EXPORTS) == declared, set(cabi.EXPORTS) ^ set(declared)
+    assert lib.gdrn_version() == 1  # host-only call (no device needed)
+
+
+def test_struct_layouts_match_the_header():
+    """field order of the ctypes mirrors == field order of the C structs."""
+    txt = open(os.path.join(ROOT, "include", "gdrn_hip.h")).read()
+    for cname, cls in (("gdrn_conv_params", cabi.ConvParams), ("gdrn_wgrad_params", cabi.WgradParams), ("gdrn_pose_params", cabi.PoseParams)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = re.sub(r"^(const\s+)?(void|float|int|double)\s*\*?", "", decl)
+            fields += [n.strip().lstrip("*").strip() for n in names.split(",")]
+        assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_state_dict_schema_and_param_count():
+    from gdrnet_amd import GDRN
+
+    model, opt = GDRN.build_model_optimizer(lm13_cfg(device="cpu"))
+    sd = model.state_dict()
+    schema = synth.param_schema()
+    assert list(sd.keys()) == list(schema.keys())
+    for k, (shape, _) in schema.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in model.parameters()) == 35054094 and len(list(model.parameters())) == 148
+    assert len(opt.param_groups) == 3 and all(abs(g["lr"] - 1e-4) < 1e-12 for g in opt.param_groups)
+    assert model.load_state_dict(synth.make_state_dict(0)).missing_keys == []
+    # reference init: N(0, 0.001^2) convs, fc_r / fc_t 0.01, BN / GN weight 1
+    m2, _ = GDRN.build_model_optimizer(lmo_cfg(device="cpu"))
+    assert 5e-4 < float(m2.backbone.layer1[0].conv1.weight.std()) < 2e-3
+    assert 5e-3 < float(m2.pnp_net.fc_r.weight.std()) < 2e-2
+    assert float(m2.rot_head_net.features[1].weight.min()) == 1.0
+    assert GDRN.get_xyz_mask_region_out_dim(m2.cfg) == (3, 1, 65)
+
+
+def test_no_cpu_fallback_and_scope_gate():
+    from gdrnet_amd import GDRN
+
+    model, _ = GDRN.build_model_optimizer(lm13_cfg(device="cpu"))
+    b = synth.make_batch(2, seed=1)
+    with pytest.raises(cabi.GdrnHipError):
+        model(b["roi_img"], **synth.model_kwargs(b, do_loss=False))
+    with pytest.raises(RuntimeError):
+        model.backbone(b["roi_img"])  # sub-modules are parameter containers
+    for mutate in (lambda c: c.MODEL.CDPN.PNP_NET.__setitem__("ROT_TYPE", "ego_quat"),
+                   lambda c: c.MODEL.CDPN.ROT_HEAD.__setitem__("XYZ_LOSS_TYPE", "CE_coor"),
+                   lambda c: c.MODEL.CDPN.BACKBONE.__setitem__("NUM_LAYERS", 50),
+                   lambda c: c.MODEL.CDPN.TRANS_HEAD.__setitem__("ENABLED", True)):
+        cfg = ycbv_cfg(device="cpu")
+        mutate(cfg)
+        with pytest.raises(NotImplementedError):
+            GDRN.build_model_optimizer(cfg)
+
+
+def test_synthetic_inputs_are_deterministic_and_shaped_like_batch_data():
+    a, b = synth.make_batch(3, seed=5, as_torch=False), synth.make_batch(3, seed=5, as_torch=False)
+    for k in a:
+        if k != "sym_info":
+            assert np.array_equal(a[k], b[k]), k
+    assert a["roi_img"].shape == (3, 3, 256, 256) and a["roi_img"].dtype == np.float32
+    assert a["roi_coord_2d"].shape == (3, 2, 64, 64) and a["roi_region"].dtype == np.int64
+    assert a["roi_points"].shape == (3, 3000, 3) and a["roi_mask_visib"].shape == (3, 64, 64)
+    R = a["ego_rot"].astype(np.float64)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-6)
+    assert not np.array_equal(a["roi_img"], synth.make_batch(3, seed=6, as_torch=False)["roi_img"])
+    u = synth.hash_uniform(1, "x", (100000,))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    assert abs(synth.hash_normal(1, "y", (100000,)).std() - 1.0) < 1e-2
+
+
+def test_ranger_rectification_scalars_match_reference_golden(golden_dir):
+    """radam_step_size reproduces the host arithmetic of lib/torch_utils/solver/ranger.py:154-186; a pure-numpy Ranger
+    built on it replays the reference's 7 golden steps (tests/golden/g6_ranger.npz)."""
+    from gdrnet_amd.ranger import radam_step_size
+
+    g = np.load(os.path.join(golden_dir, "g6_ranger.npz"))
+    ps = [synth.hash_normal(31, f"p{i}", s).astype(np.float32) for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
+    m = [np.zeros_like(p) for p in ps]
+    v = [np.zeros_like(p) for p in ps]
+    slow = [p.copy() for p in ps]
+    lr, b1, b2, eps = 1e-2, 0.95, 0.999, 1e-5
+    for step in range(1, 8):
+        n_sma, ss = radam_step_size(step, b1, b2, 5)
+        for i, p in enumerate(ps):
+            gr = synth.hash_normal(32 + step - 1, f"g{i}", p.shape).astype(np.float32)
+            if gr.ndim > 1:
+                gr = gr - gr.reshape(gr.shape[0], -1).mean(1).reshape((-1,) + (1,) * (gr.ndim - 1))
+            v[i] = v[i] * np.float32(b2) + np.float32(1 - b2) * gr * gr
+            m[i] = m[i] * np.float32(b1) + np.float32(1 - b1) * gr
+            if n_sma > 5:
+                p -= np.float32(ss * lr) * m[i] / (np.sqrt(v[i]) + np.float32(eps))
+            else:
+                p -= np.float32(ss * lr) * m[i]
+            if step % 6 == 0:
+                slow[i] += np.float32(0.5) * (p - slow[i])
+                p[...] = slow[i]
+            np.testing.assert_allclose(p, g[f"step{step - 1}/p{i}"], rtol=2e-5, atol=2e-7)

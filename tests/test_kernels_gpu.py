@@ -61,6 +61,33 @@ def test_conv_forward(H, dt, case):
     assert H.rel(st[1], (ref * ref).sum((0, 2, 3))) < 1e-3
 
 
+HALO_CASES = [(2, 64, 64, 16), (1, 128, 128, 32), (3, 256, 256, 16), (2, 512, 512, 8), (1, 256, 256, 64), (2, 64, 128, 24)]
+
+
+@pytest.mark.parametrize("dt", [BF16])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_forward_and_dgrad(H, dt, case):
+    """halo-tiled 3x3 s1 kernel: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights)."""
+    B, I, O, Hh = case
+    x = H.rounded(H.randn(1, B, I, Hh, Hh), dt).requires_grad_(True)
+    w = H.rounded(H.randn(2, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    add = H.rounded(H.randn(3, B, O, Hh, Hh), dt)
+    ref = F.conv2d(x, w, None, 1, 1)
+    dy = H.rounded(H.randn(4, B, O, Hh, Hh), dt)
+    ref.backward(dy)
+    xd, wp = H.nhwc(x.detach(), dt), H.pack_fwd(w, dt)
+    y, stats = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True)
+    assert H.rel(H.nchw(y, O), ref) < TOL[dt]
+    st = stats.sum(0).cpu()
+    assert H.rel(st[0], ref.detach().sum((0, 2, 3))) < 1e-3 + TOL[dt]
+    assert H.rel(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < 1e-3
+    y2, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), act=1, halo=True)
+    assert H.rel(H.nchw(y2, O), F.relu(ref.detach() + add)) < TOL[dt]
+    wd = H.pack_dgrad(w, dt, flip=1)
+    dx, _ = H.conv_gemm(H.nhwc(dy, dt), wd, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True)
+    assert H.rel(H.nchw(dx, I), x.grad) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_epilogue_bias_act_addend_f32out(H, dt):
     B, I, O, Hh = 2, 256, 69, 16
