@@ -51,6 +51,26 @@ class PoseParams(C.Structure):
     ]
 
 
+class PackTask(C.Structure):
+    _fields_ = [
+        ("src", P), ("dst", P),
+        ("A1", I), ("A2", I), ("T", I), ("B", I), ("A1v", I), ("A2v", I), ("Bv", I), ("flip", I),
+        ("s1", LL), ("s2", LL), ("st", LL), ("sb", LL), ("n", LL), ("frag", I), ("pad_", I),
+    ]
+
+
+class RangerTask(C.Structure):
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("slow", P), ("rows", I), ("cols", I), ("gc", I), ("lr", F)]
+
+
+def to_device_table(structs, device):
+    """ctypes struct list -> uint8 device tensor holding the C array."""
+    import torch
+
+    arr = (type(structs[0]) * len(structs))(*structs)
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
 # name -> argtypes (all return int status, except the two tile queries which return ints too)
 _SIGS = {
     "gdrn_version": [],
@@ -63,6 +83,8 @@ _SIGS = {
     "gdrn_conv3x3_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv3x3_stats_rows": [C.POINTER(ConvParams)],
     "gdrn_conv_wgrad": [C.POINTER(WgradParams), P],
+    "gdrn_conv3x3_wgrad": [C.POINTER(WgradParams), P],
+    "gdrn_conv3x3_wgrad_ok": [C.POINTER(WgradParams)],
     "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
     "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],
     "gdrn_pack_stem_w": [P, P, I, P],
@@ -91,6 +113,10 @@ _SIGS = {
     "gdrn_pose_loss": [C.POINTER(PoseParams), P],
     "gdrn_combine3": [P, P, P, I, P],
     "gdrn_ranger_step": [P, P, P, P, P, I, I, I, F, F, F, F, F, F, I, I, F, P],
+    "gdrn_pack_chunk": [],
+    "gdrn_pack_multi": [P, P, I, I, I, P],
+    "gdrn_unpack_multi": [P, P, I, I, P],
+    "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, P],
 }
 
 EXPORTS = tuple(_SIGS.keys())

@@ -1,0 +1,203 @@
+// Halo-tiled weight gradient of the 3x3 stride-1 pad-1 convolutions on MFMA for gfx950 (bf16 operands, fp32
+// accumulate):   dWp[co][tap][ci] += sum_{pixels} dY[pix][co] * X[pix + tap][ci]
+// (autograd backward-weight of the BasicBlock / head 3x3 convs, reference: engine.py:279).
+//
+// The generic kernel (conv_wgrad.hip) handles one tap per workgroup and re-reads dY and X once per tap.  Here a
+// workgroup owns a 64(co) x 64(ci) tile of ALL NINE taps: per stage it stages an 8x8 pixel patch of dY and the
+// 10x10 halo patch of X in LDS once and runs the nine taps against them (227 FLOP per byte moved instead of 64,
+// 9x fewer atomics per MAC).  Both MFMA operands need the pixel (reduction) axis transposed: ds_read_b64_tr_b16
+// with `lane base + immediate` addresses (row pitch 160 B: the 8 pixel rows of a 32-lane half hit disjoint banks).
+// Accumulators: 9 taps x (2x2 fragments) x 4 = 144 VGPRs per lane; the dY fragments of a k-step are loaded once
+// and reused by the nine taps.  Pixel patches are split over workgroups; partial tiles are added with fp32 atomics.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+constexpr int PITCH = 160;               // bytes per LDS pixel row (64 ch * 2 B + 32 pad)
+constexpr int DYB = 64 * PITCH;          // dY patch: 8x8 pixels
+constexpr int XB = 100 * PITCH;          // X patch: 10x10 pixels
+constexpr int STAGEB = DYB + XB;
+
+__device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p0);
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (dY patch | X patch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int g = lane >> 4, q = lane & 15;
+
+    const int ncot = p.Cout / 64, ncit = p.Cin / 64, ntile = ncot * ncit;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: all tiles of one pixel range run on the same XCD and share its L2
+        const int nwg = gridDim.x, qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
+    }
+    const int split = bid / ntile, tile = bid - split * ntile;
+    const int co0 = (tile % ncot) * 64, ci0 = (tile / ncot) * 64;
+    const int per = (npatch + nsplit - 1) / nsplit;
+    const int p_begin = split * per, p_end = min(npatch, p_begin + per);
+    if (p_begin >= p_end) return;
+    const int tiles_x = p.Wo >> 3, tiles_y = p.Ho >> 3;
+
+    // ---- staging geometry (constant per thread)
+    // dY: 64 px x 8 segs = 512 -> ids tid, tid+256 ; X: 100 px x 8 segs = 800 -> ids tid + 256*i, i < 4
+    const int dseg = tid & 7, dpix0 = tid >> 3;                       // pixels dpix0, dpix0 + 32
+    const char* dyg = reinterpret_cast<const char*>(p.dy) + (size_t)co0 * 2 + dseg * 16;
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * 2;
+
+    uint4 d0, d1, x0, x1, x2, x3;
+    d0 = d1 = x0 = x1 = x2 = x3 = make_uint4(0, 0, 0, 0);
+
+#define LDX(i, dst)                                                                                   \
+    {                                                                                                 \
+        const int id_ = tid + 256 * (i);                                                              \
+        const int pp_ = id_ >> 3, sg_ = id_ & 7;                                                      \
+        const int py_ = pp_ / 10, px_ = pp_ - py_ * 10;                                               \
+        const int iy_ = y0_ + py_ - 1, ix_ = x0_ + px_ - 1;                                           \
+        const bool ok_ = id_ < 800 && iy_ >= 0 && iy_ < p.Hi && ix_ >= 0 && ix_ < p.Wi;               \
+        const int iyc_ = min(max(iy_, 0), p.Hi - 1), ixc_ = min(max(ix_, 0), p.Wi - 1);               \
+        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + ((size_t)((n_ * p.Hi + iyc_) * p.Wi + ixc_) * p.x_cs * 2 + sg_ * 16)); \
+        dst = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                      \
+    }
+#define LOAD_PATCH(pi)                                                                                \
+    {                                                                                                 \
+        int t_ = (pi);                                                                                \
+        const int tx_ = t_ % tiles_x; t_ /= tiles_x;                                                  \
+        const int ty_ = t_ % tiles_y;                                                                 \
+        const int n_ = t_ / tiles_y;                                                                  \
+        const int y0_ = ty_ << 3, x0_ = tx_ << 3;                                                     \
+        {                                                                                             \
+            const int pa_ = dpix0, pb_ = dpix0 + 32;                                                  \
+            const size_t ra_ = (size_t)((n_ * p.Ho + y0_ + (pa_ >> 3)) * p.Wo + x0_ + (pa_ & 7));     \
+            const size_t rb_ = (size_t)((n_ * p.Ho + y0_ + (pb_ >> 3)) * p.Wo + x0_ + (pb_ & 7));     \
+            d0 = *reinterpret_cast<const uint4*>(dyg + ra_ * p.dy_cs * 2);                            \
+            d1 = *reinterpret_cast<const uint4*>(dyg + rb_ * p.dy_cs * 2);                            \
+        }                                                                                             \
+        LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)                                                   \
+    }
+#define STX(i, src)                                                                                   \
+    {                                                                                                 \
+        const int id_ = tid + 256 * (i);                                                              \
+        if (id_ < 800) *reinterpret_cast<uint4*>(sb_ + DYB + (id_ >> 3) * PITCH + (id_ & 7) * 16) = src; \
+    }
+#define WRITE_PATCH(buf)                                                                              \
+    {                                                                                                 \
+        unsigned char* sb_ = smem + (buf) * STAGEB;                                                   \
+        *reinterpret_cast<uint4*>(sb_ + dpix0 * PITCH + dseg * 16) = d0;                              \
+        *reinterpret_cast<uint4*>(sb_ + (dpix0 + 32) * PITCH + dseg * 16) = d1;                       \
+        STX(0, x0) STX(1, x1) STX(2, x2) STX(3, x3)                                                   \
+    }
+
+    f32x4_t acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read lane bases.  k (pixel) map of one 32-pixel k-step (4 image rows x 8): read r of lane group g
+    // covers pixels (row = 2r + (g>>1), col = (g&1)*4 + 0..3); lane q supplies pixel col + (q>>2), channels (q&3)*4..
+    const int lpy = g >> 1, lpx = (g & 1) * 4 + (q >> 2);
+    const int baseA = (lpy * 8 + lpx) * PITCH + (wa * 32 + (q & 3) * 4) * 2;             // dY patch: 8 px per row
+    const int baseB = DYB + (lpy * 10 + lpx) * PITCH + (wb * 32 + (q & 3) * 4) * 2;      // X patch: 10 px per row
+
+    LOAD_PATCH(p_begin)
+    WRITE_PATCH(0)
+    __syncthreads();
+
+    for (int pi = p_begin; pi < p_end; ++pi) {
+        const int buf = (pi - p_begin) & 1;
+        const bool more = pi + 1 < p_end;
+        if (more) LOAD_PATCH(pi + 1)
+        const unsigned char* sa = smem + buf * STAGEB + baseA;
+        const unsigned char* sx = smem + buf * STAGEB + baseB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // dY fragments (A operand, i = co): rows (ks*4 + 2r + lpy) of the 8-wide patch
+            bf16x8_t fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[a] = tr_pair(sa + (ks * 4) * 8 * PITCH + a * 32, sa + (ks * 4 + 2) * 8 * PITCH + a * 32);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sh = ((ks * 4 + t / 3) * 10 + (t % 3)) * PITCH;  // tap shift inside the 10-wide halo patch
+                bf16x8_t fb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fb[b] = tr_pair(sx + sh + b * 32, sx + sh + 2 * 10 * PITCH + b * 32);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[t][a][b], 0, 0, 0);
+            }
+        }
+        if (more) WRITE_PATCH(buf ^ 1)
+        __syncthreads();
+    }
+#undef LDX
+#undef LOAD_PATCH
+#undef STX
+#undef WRITE_PATCH
+
+    // D[i = g*4 + j (co)][col = q (ci)]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wa * 32 + a * 16 + g * 4 + j;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ci = ci0 + wb * 32 + b * 16 + q;
+                    unsafeAtomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t][a][b][j]);
+                }
+            }
+}
+
+}  // namespace
+
+// 1 if the shape is covered by the halo weight-gradient kernel
+extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
+    if (!p) return 0;
+    return p->dtype == GDRN_DT_BF16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->Hi == p->Ho &&
+           p->Wi == p->Wo && (p->Ho % 8) == 0 && (p->Wo % 8) == 0 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
+           (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0;
+}
+
+extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
+    if (!pp || !pp->x || !pp->dy || !pp->dw) return GDRN_ERR_ARG;
+    if (!gdrn_conv3x3_wgrad_ok(pp)) return GDRN_ERR_SHAPE;
+    const gdrn_wgrad_params& p = *pp;
+    const int hw = p.Ho * p.Wo;
+    if (p.M <= 0 || p.M % hw) return GDRN_ERR_SHAPE;
+    const int npatch = (p.M / hw) * (p.Ho / 8) * (p.Wo / 8);
+    const int tiles = (p.Cout / 64) * (p.Cin / 64);
+    int splits = p.splits;
+    // every split costs one fp32 atomic per output element (measured ~0.3 T atomic lanes/s): one workgroup per CU
+    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(256, tiles)));
+    splits = std::min(splits, npatch);
+    constexpr size_t smem = 2 * (size_t)STAGEB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return GDRN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch,
+                       splits);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}

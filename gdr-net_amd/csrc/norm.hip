@@ -59,24 +59,35 @@ __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, con
     }
 }
 
+// Channel-stationary mapping for the HBM-bound BN passes: thread = (channel vector cv, row lane rl); the per-channel
+// constants live in registers and a thread walks rows with a fixed stride -- no per-element index division, no
+// per-element scale/shift loads (the first version spent its time in 64-bit modulo and reached only 1.6 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res,
-                                                       T* __restrict__ y, long long nvec, int C, int relu) {
+                                                       T* __restrict__ y, long long npix, int C, int relu, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * V) % C);
-        float v[V], r[V];
-        Vec16<T>::load(x + i * V, v);
-        if (res != nullptr) Vec16<T>::load(res + i * V, r);
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = scale[cv * V + j]; sh[j] = shift[cv * V + j]; }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(npix, r0 + rows_per_block);
+    if (rl >= rpp) return;
+    for (long long r = r0 + rl; r < r1; r += rpp) {
+        const size_t o = (size_t)r * C + cv * V;
+        float v[V], q[V];
+        Vec16<T>::load(x + o, v);
+        if (res != nullptr) Vec16<T>::load(res + o, q);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float t = v[j] * scale[c + j] + shift[c + j];
-            if (res != nullptr) t += r[j];
+            float t = v[j] * sc[j] + sh[j];
+            if (res != nullptr) t += q[j];
             if (relu) t = fmaxf(t, 0.f);
             v[j] = t;
         }
-        Vec16<T>::store(y + i * V, v);
+        Vec16<T>::store(y + o, v);
     }
 }
 
@@ -125,30 +136,44 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, long long nvec, int C, float inv_n,
+                                                           const float* __restrict__ sums, long long npix, int C, float inv_n,
                                                            T* __restrict__ dx, T* __restrict__ gout, float* dgamma,
-                                                           float* dbeta) {
+                                                           float* dbeta, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
     if (blockIdx.x == 0 && dgamma != nullptr) {
         for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
     }
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * V) % C);
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    // dx = a*(g - m1) - a*xhat*m2  with xhat = (x - mu)*is  ->  dx = a*g + (b*x + c), b = -a*is*m2, c = -a*m1 - b*mu
+    float ka[V], kb[V], kc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        const float is = invstd[c], a = gamma[c] * is;
+        const float m1 = sums[c] * inv_n, m2 = sums[C + c] * inv_n;
+        ka[j] = a;
+        kb[j] = -a * is * m2;
+        kc[j] = -a * m1 - kb[j] * mean[c];
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(npix, r0 + rows_per_block);
+    if (rl >= rpp) return;
+    for (long long r = r0 + rl; r < r1; r += rpp) {
+        const size_t off = (size_t)r * C + cv * V;
         float g[V], xv[V], yv[V], o[V];
-        Vec16<T>::load(dy + i * V, g);
-        Vec16<T>::load(x + i * V, xv);
-        if (ym != nullptr) Vec16<T>::load(ym + i * V, yv);
+        Vec16<T>::load(dy + off, g);
+        Vec16<T>::load(x + off, xv);
+        if (ym != nullptr) Vec16<T>::load(ym + off, yv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float gg = g[j];
             if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
             g[j] = gg;
-            const float is = invstd[c + j];
-            const float xh = (xv[j] - mean[c + j]) * is;
-            o[j] = gamma[c + j] * is * (gg - sums[c + j] * inv_n - xh * sums[C + c + j] * inv_n);
+            o[j] = ka[j] * gg + (kb[j] * xv[j] + kc[j]);
         }
-        Vec16<T>::store(dx + i * V, o);
-        if (gout != nullptr) Vec16<T>::store(gout + i * V, g);
+        Vec16<T>::store(dx + off, o);
+        if (gout != nullptr) Vec16<T>::store(gout + off, g);
     }
 }
 
@@ -487,6 +512,16 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
     for (int c = threadIdx.x; c < C; c += 256) unsafeAtomicAdd(&db[c], acc[c]);
 }
 
+// rows per block / block count for the channel-stationary row-walking kernels (~8 blocks per CU)
+inline void ew_rows(long long npix, int tpr, int* rpb, int* blocks) {
+    const int rpp = 256 / tpr;
+    long long r = (npix + 2047) / 2048;
+    r = (r + rpp - 1) / rpp * rpp;
+    if (r < 4LL * rpp) r = 4LL * rpp;
+    *rpb = (int)r;
+    *blocks = (int)((npix + r - 1) / r);
+}
+
 inline int ew_grid(long long n) { return (int)std::min<long long>((n + 255) / 256, 256LL * 16); }
 
 }  // namespace
@@ -520,11 +555,15 @@ extern "C" int gdrn_bn_eval_params(const float* gamma, const float* beta, const 
 extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                              long long npix, int C, int relu, int dtype, void* stream) {
     if (!x || !scale || !shift || !y || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
+    int rpb, blocks;
+    ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(npix * C / 4)), dim3(256), 0, ST, (const float*)x, scale,
-                                shift, (const float*)residual, (float*)y, npix * C / 4, C, relu),
-             hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(npix * C / 8)), dim3(256), 0, ST, (const bf16_t*)x,
-                                scale, shift, (const bf16_t*)residual, (bf16_t*)y, npix * C / 8, C, relu));
+             hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)x, scale,
+                                shift, (const float*)residual, (float*)y, npix, C, relu, rpb),
+             hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)x,
+                                scale, shift, (const bf16_t*)residual, (bf16_t*)y, npix, C, relu, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -553,13 +592,17 @@ extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* 
                                  float* dgamma, float* dbeta, int dtype, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
     const float inv_n = (float)(1.0 / (double)npix);
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
+    int rpb, blocks;
+    ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(npix * C / 4)), dim3(256), 0, ST, (const float*)dy,
-                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, npix * C / 4, C, inv_n,
-                                (float*)dx, (float*)g_out, dgamma, dbeta),
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(npix * C / 8)), dim3(256), 0, ST, (const bf16_t*)dy,
-                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, npix * C / 8, C, inv_n,
-                                (bf16_t*)dx, (bf16_t*)g_out, dgamma, dbeta));
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
+                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, npix, C, inv_n,
+                                (float*)dx, (float*)g_out, dgamma, dbeta, rpb),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, npix, C, inv_n,
+                                (bf16_t*)dx, (bf16_t*)g_out, dgamma, dbeta, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

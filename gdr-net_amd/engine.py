@@ -165,42 +165,60 @@ class Engine:
     def _src_version(self, L):
         return tuple(self.P[n]._version for n in L.src) + tuple(self.P[n].data_ptr() for n in L.src)
 
+    def _pack_args(self, L, which):
+        """pack4 argument tuple (A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip) of operand `which` in ("f", "d")."""
+        O, I, KK = L.O, L.I, L.KK
+        if L.kind == "convT":  # weight[ci=I][co=O][k]; fwd rows = co, b = ci ; dgrad rows = ci, b = co
+            return ((L.rows_f, 1, KK, L.cin_f, O, 1, I, KK, 0, 1, O * KK, 0) if which == "f"
+                    else (L.rows_d, 1, KK, L.cin_d, I, 1, O, O * KK, 0, 1, KK, 0))
+        if L.kind == "fc1":    # dgrad rows (p, c) -> src[o*I*KK + c*KK + p]
+            return ((L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0) if which == "f"
+                    else (KK, L.in_ch, 1, L.cin_d, KK, I, O, 1, KK, 0, I * KK, 0))
+        flip = 1 if (KK == 9 and not L.s2) else 0
+        return ((L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0) if which == "f"
+                else (L.rows_d, 1, KK, L.cin_d, I, 1, O, KK, 0, 1, I * KK, flip))
+
+    def _build_pack_table(self):
+        """Device task table for gdrn_pack_multi: every operand copy of every layer (stem excluded) in ONE launch."""
+        from .cabi import PackTask, to_device_table
+
+        chunk = self.lib.gdrn_pack_chunk()
+        tasks, starts = [], [0]
+        for key, L in self.layers.items():
+            if L.kind == "stem":
+                continue
+            src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
+            for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, 1), ("d", L.wdF, 1)):
+                if dst is None:
+                    continue
+                A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip = self._pack_args(L, which)
+                t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
+                             s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=0)
+                tasks.append(t)
+                starts.append(starts[-1] + (t.n + chunk - 1) // chunk)
+        self._pack_tasks = to_device_table(tasks, self.dev)
+        self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.dev)
+        self._pack_n = (len(tasks), starts[-1])
+
     def repack(self, force=False):
-        """(Re)build the kernel-layout operand copies of every weight whose parameter changed."""
+        """(Re)build the kernel-layout operand copies of the weights after a parameter update: one multi-tensor
+        launch (+ the stem's special layout) instead of ~170 per-tensor launches."""
+        sig = tuple(p._version for p in self.P.values())
+        if not force and self._versions.get("sig") == sig:
+            return
+        self._versions["sig"] = sig
         st = self._stream()
         lib = self.lib
-        for key, L in self.layers.items():
-            v = self._src_version(L)
-            if not force and self._versions.get(key) == v:
-                continue
-            self._versions[key] = v
-            if key == "pnp_net.fc_rt":
-                with torch.no_grad():
-                    self.rt_w[:6].copy_(self.P["pnp_net.fc_r.weight"])
-                    self.rt_w[6:].copy_(self.P["pnp_net.fc_t.weight"])
-                    self.rt_b[:6].copy_(self.P["pnp_net.fc_r.bias"])
-                    self.rt_b[6:].copy_(self.P["pnp_net.fc_t.bias"])
-                w = self.rt_w
-            else:
-                w = self.P[L.src[0]].detach()
-            O, I, KK = L.O, L.I, L.KK
-            if L.kind == "stem":
-                check(lib.gdrn_pack_stem_w(ptr(w), ptr(L.wf), self.dt, st), "pack_stem_w")
-            elif L.kind == "convT":
-                # weight[ci=I][co=O][k]; fwd rows = co, b = ci ; dgrad rows = ci, b = co
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, KK, 0, 1, O * KK, 0, self.dt, st), "pack4")
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), L.rows_d, 1, KK, L.cin_d, I, 1, O, O * KK, 0, 1, KK, 0, self.dt, st), "pack4")
-            elif L.kind == "fc1":
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0, self.dt, st), "pack4")
-                # dgrad rows (p, c) -> src[o*I*KK + c*KK + p]
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), KK, L.in_ch, 1, L.cin_d, KK, I, O, 1, KK, 0, I * KK, 0, self.dt, st), "pack4")
-            else:
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wf), L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0, self.dt, st), "pack4")
-                flip = 1 if (KK == 9 and not L.s2) else 0
-                check(lib.gdrn_pack4(ptr(w), ptr(L.wd), L.rows_d, 1, KK, L.cin_d, I, 1, O, KK, 0, 1, I * KK, flip, self.dt, st), "pack4")
-                if L.wfF is not None:
-                    check(lib.gdrn_pack_wfrag(ptr(L.wf), ptr(L.wfF), L.rows_f, L.cin_f, self.dt, st), "pack_wfrag")
-                    check(lib.gdrn_pack_wfrag(ptr(L.wd), ptr(L.wdF), L.rows_d, L.cin_d, self.dt, st), "pack_wfrag")
+        with torch.no_grad():
+            self.rt_w[:6].copy_(self.P["pnp_net.fc_r.weight"])
+            self.rt_w[6:].copy_(self.P["pnp_net.fc_t.weight"])
+            self.rt_b[:6].copy_(self.P["pnp_net.fc_r.bias"])
+            self.rt_b[6:].copy_(self.P["pnp_net.fc_t.bias"])
+        Ls = self.layers["backbone.conv1"]
+        check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
+        if not hasattr(self, "_pack_tasks"):
+            self._build_pack_table()
+        check(lib.gdrn_pack_multi(ptr(self._pack_tasks), ptr(self._pack_starts), self._pack_n[0], self._pack_n[1], self.dt, st), "pack_multi")
 
     # ------------------------------------------------------------------------------------------ plans
     def plan(self, B, bn_train, with_loss):
@@ -225,7 +243,11 @@ class Plan:
         self.bwd_groups = []   # list of lists, appended in forward order, executed reversed
         self.keep = []         # keep ctypes structs alive
         self.bn = {}           # bn key -> NS(mean, invstd, scale, shift, sums)
+        self._unpack_pending = []  # (forward group index, layer)
         self._build()
+        if self.has_backward:
+            self._finish_unpack()
+        self.bwd_groups = [[op for op in g if op is not None] for g in self.bwd_groups]
         self.bwd = [op for g in reversed(self.bwd_groups) for op in g]
 
     # ---- op builders -------------------------------------------------------------------------
@@ -290,7 +312,9 @@ class Plan:
         wp.KH, wp.KW, wp.stride, wp.pad = KH or L.KH, KW or L.KW, stride, pad
         wp.M, wp.dtype, wp.splits, wp.variant = self.B * Ho * Wo, e.dt, 0, e.wgrad_variant
         self.keep.append(wp)
-        fn, ref = e.lib.gdrn_conv_wgrad, C.byref(wp)
+        ref = C.byref(wp)
+        use_halo = e.use_halo and L.kind == "conv" and bool(e.lib.gdrn_conv3x3_wgrad_ok(ref))
+        fn = e.lib.gdrn_conv3x3_wgrad if use_halo else e.lib.gdrn_conv_wgrad
 
         def run(st, ctx):
             s = fn(ref, st)
@@ -304,29 +328,21 @@ class Plan:
         else:
             macs = self.B * Ho * Wo * L.O * L.I * L.KK
         bco, bci = (64 if cout <= 64 else 128), (128 if cin % 128 == 0 else 64)
-        run.meta = dict(kernel=f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>", flops=2.0 * macs,
-                        layer=L.key + ":wgrad")
+        kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>"
+        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + ":wgrad")
         return run
 
     def _unpack(self, L):
+        """packed fp32 weight gradient -> the parameter's .grad layout.  Every layer except the stem is deferred to one
+        multi-tensor launch per gradient bucket (see _finish_unpack); the returned op is then a no-op marker."""
         e = self.e
         lib = e.lib
         O, I, KK = L.O, L.I, L.KK
         if L.kind == "stem":
             g = e.grads[L.src[0]]
             return lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w")
-        if L.key == "pnp_net.fc_rt":
-            gr, gt = e.grads["pnp_net.fc_r.weight"], e.grads["pnp_net.fc_t.weight"]
-
-            def run(st, ctx):
-                check(lib.gdrn_unpack4(ptr(L.dwp), ptr(gr), 9, 1, 1, L.in_ch, 6, 1, 256, 256, 0, 0, 1, 0, st), "unpack4")
-                check(lib.gdrn_unpack4(L.dwp.data_ptr() + 6 * L.in_ch * 4, ptr(gt), 3, 1, 1, L.in_ch, 3, 1, 256, 256, 0, 0, 1, 0, st), "unpack4")
-
-            return run
-        g = e.grads[L.src[0]]
-        if L.kind == "convT":  # dwp [ci=I][KK][co(out_ch)] -> weight[ci][co][k]
-            return lambda st, ctx: check(lib.gdrn_unpack4(ptr(L.dwp), ptr(g), I, 1, KK, L.out_ch, I, 1, O, O * KK, 0, 1, KK, 0, st), "unpack4")
-        return lambda st, ctx: check(lib.gdrn_unpack4(ptr(L.dwp), ptr(g), O, 1, KK, L.in_ch, O, 1, I, I * KK, 0, 1, KK, 0, st), "unpack4")
+        self._unpack_pending.append((len(self.bwd_groups), L))
+        return None
 
     def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
         """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
@@ -363,6 +379,50 @@ class Plan:
                                                         ptr(s.sums), s.npix, s.C, ptr(dx), ptr(g_out), ptr(dg), ptr(db), e.dt, st),
                                   "bn_bwd_apply"),
         ]
+
+    def _unpack_task(self, L, packed_ptr, grad, rows_valid, rows_off=0):
+        from .cabi import PackTask
+
+        O, I, KK = L.O, L.I, L.KK
+        if L.kind == "convT":  # dwp [ci=I][KK][co(out_ch)] -> weight[ci][co][k]
+            a = (I, 1, KK, L.out_ch, I, 1, O, O * KK, 0, 1, KK)
+        else:
+            a = (rows_valid, 1, KK, L.in_ch, rows_valid, 1, I, I * KK, 0, 1, KK)
+        A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb = a
+        return PackTask(src=packed_ptr, dst=grad.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=0, s1=s1, s2=s2,
+                        st=st, sb=sb, n=A1v * A2v * T * Bv, frag=0, pad_=0)
+
+    def _finish_unpack(self):
+        """One gdrn_unpack_multi per gradient bucket (pnp | head | layer4+3 | rest), appended to the backward group that
+        completes the bucket, so the RCCL exchange of a bucket still starts as soon as its gradients exist."""
+        from .cabi import to_device_table
+
+        e, lib = self.e, self.e.lib
+        chunk = lib.gdrn_pack_chunk()
+        ng = len(self.bwd_groups)
+        assert ng == 29, ng
+        first_group = (25, 17, 8, 0)  # forward index of the LAST-executed group of buckets 0..3
+        per_bucket = {0: [], 1: [], 2: [], 3: []}
+        for gi, L in self._unpack_pending:
+            bkt = 0 if gi >= 25 else (1 if gi >= 17 else (2 if gi >= 8 else 3))
+            if L.key == "pnp_net.fc_rt":
+                per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr(), e.grads["pnp_net.fc_r.weight"], 6))
+                per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr() + 6 * L.in_ch * 4, e.grads["pnp_net.fc_t.weight"], 3))
+            else:
+                per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr(), e.grads[L.src[0]], L.O))
+        self._unpack_tables = []
+        for bkt, tasks in per_bucket.items():
+            if not tasks:
+                continue
+            starts = [0]
+            for t in tasks:
+                starts.append(starts[-1] + (t.n + chunk - 1) // chunk)
+            tab = to_device_table(tasks, e.dev)
+            stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
+            self._unpack_tables.append((tab, stt))
+            nt, nb = len(tasks), starts[-1]
+            self.bwd_groups[first_group[bkt]].append(
+                lambda st, ctx, tab=tab, stt=stt, nt=nt, nb=nb: check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi"))
 
     # ---- graph -------------------------------------------------------------------------------
     def _build(self):

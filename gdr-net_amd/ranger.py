@@ -55,13 +55,50 @@ class Ranger(Optimizer):
         self.use_gc = use_gc
         self.gc_gradient_threshold = 3 if gc_conv_only else 1
 
+    def _init_state(self, p):
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = 0
+            state["exp_avg"] = torch.zeros_like(p)
+            state["exp_avg_sq"] = torch.zeros_like(p)
+            state["slow_buffer"] = p.detach().clone()
+        return state
+
+    def _gc_shape(self, p, g):
+        gc = 1 if (self.use_gc and g.dim() > self.gc_gradient_threshold) else 0
+        rows = p.shape[0] if (gc and p.dim() > 1) else 1
+        return gc, rows, p.numel() // rows
+
+    def _multi_table(self, gi, items, lr):
+        """device task table of one param group for gdrn_ranger_multi, cached on the buffers' addresses."""
+        key = (lr,) + tuple((p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["slow_buffer"].data_ptr())
+                            for p, g in items)
+        cache = self.__dict__.setdefault("_multi_cache", {})
+        hit = cache.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1:]
+        tasks, starts = [], [0]
+        for p, g in items:
+            st = self.state[p]
+            gc, rows, cols = self._gc_shape(p, g)
+            tasks.append(cabi.RangerTask(p=p.data_ptr(), g=g.data_ptr(), m=st["exp_avg"].data_ptr(), v=st["exp_avg_sq"].data_ptr(),
+                                         slow=st["slow_buffer"].data_ptr(), rows=rows, cols=cols, gc=gc, lr=lr))
+            starts.append(starts[-1] + rows)
+        dev = items[0][0].device
+        tab = cabi.to_device_table(tasks, dev)
+        stt = torch.tensor(starts, dtype=torch.int32, device=dev)
+        cache[gi] = (key, tab, stt, len(tasks), starts[-1])
+        return cache[gi][1:]
+
     @torch.no_grad()
     def step(self, closure=None, grads=None):
         """grads: optional dict param -> fp32 gradient tensor (used by the fused train step to read the
-        engine's flat gradient buffer directly instead of ``p.grad``)."""
+        engine's flat gradient buffer directly instead of ``p.grad``).  One multi-tensor launch per param group
+        when every tensor of the group is at the same step count (the normal case); per-tensor launches otherwise."""
         lib = cabi.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
+            items = []
             for p in group["params"]:
                 g = grads.get(p) if grads is not None else p.grad
                 if g is None:
@@ -71,25 +108,37 @@ class Ranger(Optimizer):
                 g = g.detach()
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.float().contiguous()
-                state = self.state[p]
-                if len(state) == 0:
-                    state["step"] = 0
-                    state["exp_avg"] = torch.zeros_like(p)
-                    state["exp_avg_sq"] = torch.zeros_like(p)
-                    state["slow_buffer"] = p.detach().clone()
-                state["step"] += 1
-                step = state["step"]
+                items.append((p, g))
+            if not items:
+                continue
+            states = [self._init_state(p) for p, _ in items]
+            for s in states:
+                s["step"] += 1
+            st = torch.cuda.current_stream(items[0][0].device).cuda_stream
+            steps = {s["step"] for s in states}
+            if len(steps) == 1 and len(items) > 1:
+                step = steps.pop()
                 n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
-                gc = 1 if (self.use_gc and g.dim() > self.gc_gradient_threshold) else 0
-                rows = p.shape[0] if (gc and p.dim() > 1) else 1
-                cols = p.numel() // rows
-                st = torch.cuda.current_stream(p.device).cuda_stream
+                tab, stt, nt, nrows = self._multi_table(gi, items, float(group["lr"]))
+                self._keep = [g for _, g in items]  # temporaries (non-fp32 grads) must outlive the launch
                 cabi.check(
-                    lib.gdrn_ranger_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                         state["slow_buffer"].data_ptr(), rows, cols, gc, group["lr"], beta1, beta2, group["eps"],
-                                         group["weight_decay"], step_size, 1 if n_sma > self.N_sma_threshhold else 0,
-                                         1 if step % group["k"] == 0 else 0, self.alpha, st),
-                    "ranger_step",
+                    lib.gdrn_ranger_multi(tab.data_ptr(), stt.data_ptr(), nt, nrows, beta1, beta2, group["eps"], group["weight_decay"],
+                                          step_size, 1 if n_sma > self.N_sma_threshhold else 0, 1 if step % group["k"] == 0 else 0,
+                                          self.alpha, st),
+                    "ranger_multi",
                 )
+            else:
+                for (p, g), state in zip(items, states):
+                    step = state["step"]
+                    n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
+                    gc, rows, cols = self._gc_shape(p, g)
+                    cabi.check(
+                        lib.gdrn_ranger_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                             state["slow_buffer"].data_ptr(), rows, cols, gc, group["lr"], beta1, beta2, group["eps"],
+                                             group["weight_decay"], step_size, 1 if n_sma > self.N_sma_threshhold else 0,
+                                             1 if step % group["k"] == 0 else 0, self.alpha, st),
+                        "ranger_step",
+                    )
+            for p, _ in items:
                 _bump_version(p)  # updated in place behind autograd's back: tell repack() the weights changed
         return None

@@ -93,6 +93,11 @@ typedef struct gdrn_wgrad_params {
     int M, dtype, splits, variant;
 } gdrn_wgrad_params;
 int gdrn_conv_wgrad(const gdrn_wgrad_params* p, void* stream);
+/* Halo-tiled variant for KH=KW=3, stride 1, pad 1, bf16, H and W multiples of 8, Cin and Cout multiples of 64: a workgroup
+ * accumulates a 64 x 64 (co x ci) tile of all nine taps from one staged 8x8 pixel patch per stage.  Same dw layout and
+ * accumulate-with-atomics contract.  gdrn_conv3x3_wgrad_ok returns 1 when the shape is covered. */
+int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* p, void* stream);
+int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight / layout packing.
@@ -225,6 +230,39 @@ int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* losses, void
 int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* slow, int rows, int cols,
                      int gc, float lr, float beta1, float beta2, float eps, float weight_decay, float step_size,
                      int adaptive, int lookahead, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-tensor variants: ONE launch for all parameter tensors.  Task tables are arrays in DEVICE memory built once by
+ * the host; `*_start` are int prefix arrays [ntasks + 1] (workgroups for pack/unpack: ceil(n / gdrn_pack_chunk()) per
+ * task; rows for Ranger).
+ * gdrn_pack_task: gdrn_pack4 semantics (dst[a1][a2][t][b] = src[a1*s1 + a2*s2 + t'*st + b*sb], zero padded); frag != 0:
+ *   dst is the fragment-major permutation (gdrn_pack_wfrag) of that [A1][1][9][B] operand.  For gdrn_unpack_multi the
+ *   same struct describes gdrn_unpack4 (src = packed fp32, dst = parameter-layout gradient, n = A1v*A2v*T*Bv). */
+typedef struct gdrn_pack_task {
+    const float* src;
+    void* dst;
+    int A1, A2, T, B, A1v, A2v, Bv;
+    int flip;
+    long long s1, s2, st, sb;
+    long long n;
+    int frag;
+    int pad_;
+} gdrn_pack_task;
+typedef struct gdrn_ranger_task {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* slow;
+    int rows, cols, gc;
+    float lr;
+} gdrn_ranger_task;
+int gdrn_pack_chunk(void);
+int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream);
+int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
+                      float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha,
+                      void* stream);
 
 #ifdef __cplusplus
 }

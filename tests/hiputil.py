@@ -107,7 +107,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     return y, stats
 
 
-def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0):
+def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0, halo=False):
     lib = cabi.load()
     dw = torch.zeros(Cout, KH * KW, Cin, dtype=torch.float32, device=DEV)
     wp = WgradParams()
@@ -116,7 +116,9 @@ def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride,
     wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Ho, Wo, Cout, dy_cs
     wp.KH, wp.KW, wp.stride, wp.pad = KH, KW, stride, pad
     wp.M, wp.dtype, wp.splits, wp.variant = B * Ho * Wo, dt, splits, variant
-    check(lib.gdrn_conv_wgrad(C.byref(wp), stream()), "conv_wgrad")
+    if halo:
+        assert lib.gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 1
+    check((lib.gdrn_conv3x3_wgrad if halo else lib.gdrn_conv_wgrad)(C.byref(wp), stream()), "conv_wgrad")
     torch.cuda.synchronize()
     return dw
 

@@ -215,7 +215,9 @@ def test_pose_decode_kernel_vs_reference_golden(golden_dir):
         np.testing.assert_allclose(rot.cpu().numpy().reshape(N, 3, 3), g[rkey], rtol=0, atol=5e-6)
 
 
-def test_ranger_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("multi", [True, False])
+def test_ranger_vs_reference_golden(golden_dir, multi):
+    """multi: one gdrn_ranger_multi launch for the group; otherwise one param per group -> per-tensor gdrn_ranger_step."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from gdrnet_amd.ranger import Ranger
@@ -223,7 +225,7 @@ def test_ranger_vs_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "g6_ranger.npz"))
     ps = [torch.nn.Parameter(torch.from_numpy(synth.hash_normal(31, f"p{i}", s).astype(np.float32)).to(DEV))
           for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
-    opt = Ranger(ps, lr=1e-2, weight_decay=0)
+    opt = Ranger(ps if multi else [{"params": [p]} for p in ps], lr=1e-2, weight_decay=0)
     for step in range(7):
         for i, p in enumerate(ps):
             p.grad = torch.from_numpy(synth.hash_normal(32 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)

@@ -210,6 +210,20 @@ def test_conv_wgrad(H, dt, case, variant):
     assert H.rel(got, w.grad) < (5e-5 if dt == F32 else 1e-2)
 
 
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (5, 512, 512, 8)])
+def test_conv3x3_wgrad_halo(H, case, splits):
+    """halo-tiled weight gradient (nine taps from one staged pixel patch) against autograd."""
+    B, I, O, Hh = case
+    dt = BF16
+    x = H.rounded(H.randn(43, B, I, Hh, Hh), dt)
+    w = H.randn(44, O, I, 3, 3).requires_grad_(True)
+    dy = H.rounded(H.randn(45, B, O, Hh, Hh), dt)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    dw = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True)
+    assert H.rel(dw.view(O, 3, 3, I).permute(0, 3, 1, 2), w.grad) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])

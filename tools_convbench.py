@@ -1,31 +1,34 @@
-"""Micro-benchmark of the conv kernels on the dominant layer shape (bring-up / profiling aid, not product)."""
+"""Micro-benchmarks of the conv kernels on selected layer shapes (bring-up / profiling aid, not product)."""
+import os
 import sys
 import time
 
 import torch
 
-import os
 R = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import hiputil as H  # noqa: E402
 from gdrnet_amd.cabi import BF16  # noqa: E402
 
-B, C_, Hh = 64, 256, 64
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-x = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
-w = torch.randn(C_, C_, 3, 3) / 48
-wp = H.pack_fwd(w, BF16)
-for halo in (True, False):
-    for _ in range(reps):
-        y, _ = H.conv_gemm(x, wp, B, Hh, Hh, C_, C_, Hh, Hh, C_, 3, 3, 1, 1, BF16, halo=halo)
+reps = 5
+B = 64
+
+
+def timeit(fn):
+    fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        y, _ = H.conv_gemm(x, wp, B, Hh, Hh, C_, C_, Hh, Hh, C_, 3, 3, 1, 1, BF16, halo=halo)
+        fn()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print("halo" if halo else "generic", "%.1f us  %.1f TF" % (dt * 1e6, 2 * B * Hh * Hh * C_ * C_ * 9 / dt / 1e12), flush=True)
-dy = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
-for _ in range(reps):
-    dw = H.conv_wgrad(x, dy, B, Hh, Hh, C_, C_, Hh, Hh, C_, C_, 3, 3, 1, 1, BF16)
+    return (time.perf_counter() - t0) / reps
+
+
+for (C_, Hh) in ((256, 16), (512, 8), (128, 32), (64, 64)):
+    x = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
+    fl = 2 * B * Hh * Hh * C_ * C_ * 9
+    for sp in (2, 4, 8, 16, 32, 64, 0):
+        dt = timeit(lambda: H.conv_wgrad(x, dy, B, Hh, Hh, C_, C_, Hh, Hh, C_, C_, 3, 3, 1, 1, BF16, splits=sp, halo=True))
+        print("wgrad C=%d H=%d splits=%2d : %7.1f us %7.1f TF" % (C_, Hh, sp, dt * 1e6, fl / dt / 1e12), flush=True)
