@@ -34,7 +34,7 @@ class ConvParams(C.Structure):
 
 class WgradParams(C.Structure):
     _fields_ = [
-        ("x", P), ("dy", P), ("dw", P),
+        ("x", P), ("dy", P), ("dw", P), ("ws", P),
         ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("dy_cs", I),
         ("KH", I), ("KW", I), ("stride", I), ("pad", I),
@@ -57,6 +57,10 @@ class PackTask(C.Structure):
         ("A1", I), ("A2", I), ("T", I), ("B", I), ("A1v", I), ("A2v", I), ("Bv", I), ("flip", I),
         ("s1", LL), ("s2", LL), ("st", LL), ("sb", LL), ("n", LL), ("frag", I), ("pad_", I),
     ]
+
+
+class WreduceTask(C.Structure):
+    _fields_ = [("ws", P), ("dst", P), ("nsplit", I), ("Cout", I), ("Cin", I), ("pad_", I), ("s_co", LL), ("s_ci", LL), ("s_t", LL)]
 
 
 class RangerTask(C.Structure):
@@ -85,6 +89,9 @@ _SIGS = {
     "gdrn_conv_wgrad": [C.POINTER(WgradParams), P],
     "gdrn_conv3x3_wgrad": [C.POINTER(WgradParams), P],
     "gdrn_conv3x3_wgrad_ok": [C.POINTER(WgradParams)],
+    "gdrn_conv3x3_wgrad_splits": [C.POINTER(WgradParams)],
+    "gdrn_conv3x3_wgrad_multi": [P, P, I, I, P],
+    "gdrn_wgrad_reduce_multi": [P, P, I, I, P],
     "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
     "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],
     "gdrn_pack_stem_w": [P, P, I, P],
@@ -93,7 +100,7 @@ _SIGS = {
     "gdrn_cast_from_f32": [P, P, LL, I, P],
     "gdrn_cast_to_f32": [P, P, LL, I, P],
     "gdrn_nhwc_to_nchw_f32": [P, I, I, I, P, I, I, I, P],
-    "gdrn_bn_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P, P, P],
+    "gdrn_bn_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P, P, P, P],
     "gdrn_bn_eval_params": [P, P, P, P, F, I, P, P, P],
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
     "gdrn_bn_bwd_reduce": [P, P, P, P, P, LL, I, P, I, P],

@@ -8,7 +8,11 @@
 // 9x fewer atomics per MAC).  Both MFMA operands need the pixel (reduction) axis transposed: ds_read_b64_tr_b16
 // with `lane base + immediate` addresses (row pitch 160 B: the 8 pixel rows of a 32-lane half hit disjoint banks).
 // Accumulators: 9 taps x (2x2 fragments) x 4 = 144 VGPRs per lane; the dY fragments of a k-step are loaded once
-// and reused by the nine taps.  Pixel patches are split over workgroups; partial tiles are added with fp32 atomics.
+// and reused by the nine taps.  Pixel patches are split over workgroups.  Partial tiles either go to p.dw with fp32
+// atomics (p.ws == NULL) or -- the engine's path -- are stored as plain 16-byte vectors in fragment order into the
+// workspace p.ws[split][tile][36 fragments][4 waves][64 lanes][4] and summed by gdrn_wgrad_reduce_multi, which also
+// scatters into the parameter's gradient layout.  (Measured: every layer pays 256 workgroups x 36864 atomics ~ 31 us,
+// 50+ us when all workgroups hit the same 64x64 tile as in layer1 -- more than the MFMA work of a ResNet layer.)
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>
@@ -30,18 +34,19 @@ __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p0, const unsig
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (dY patch | X patch)
+// XCD-aware order: consecutive logical ids (all tiles of one pixel range) run on the same XCD and share its L2
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
+}
+
+// one workgroup: tile `bid % ntile`, pixel-range split `bid / ntile` of the layer described by p
+__device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, int npatch, int nsplit, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int g = lane >> 4, q = lane & 15;
 
     const int ncot = p.Cout / 64, ncit = p.Cin / 64, ntile = ncot * ncit;
-    int bid = blockIdx.x;
-    {   // XCD-aware order: all tiles of one pixel range run on the same XCD and share its L2
-        const int nwg = gridDim.x, qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
-    }
     const int split = bid / ntile, tile = bid - split * ntile;
     const int co0 = (tile % ncot) * 64, ci0 = (tile / ncot) * 64;
     const int per = (npatch + nsplit - 1) / nsplit;
@@ -150,6 +155,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_
 #undef STX
 #undef WRITE_PATCH
 
+    if (p.ws != nullptr) {
+        float* wsb = p.ws + ((size_t)split * ntile + tile) * 36864 + (size_t)(wave * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4_t*>(wsb + ((t * 2 + a) * 2 + b) * 1024) = acc[t][a][b];
+        return;
+    }
     // D[i = g*4 + j (co)][col = q (ci)]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -166,6 +181,69 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_
             }
 }
 
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (dY patch | X patch)
+    wgrad_tile(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+}
+
+// Grouped launch: the weight gradients of several layers (one gradient bucket) in one grid.  Weight gradients are off
+// the critical path of the backward pass, so the engine defers them to the end of their bucket and gives every
+// workgroup the same number of pixel patches: the grid fills the chip with far fewer pixel-range splits per layer than a
+// per-layer launch needs (8x less partial-tile traffic), and there is one tail instead of one per layer.
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const gdrn_wgrad_params* __restrict__ tasks,
+                                                                    const int* __restrict__ blk_start, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int lo = 0, hi = ntasks;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_start[mid] <= bid) lo = mid; else hi = mid;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const gdrn_wgrad_params p = tasks[lo];
+    const int npatch = (p.M / (p.Ho * p.Wo)) * (p.Ho >> 3) * (p.Wo >> 3);
+    wgrad_tile(p, bid - blk_start[lo], npatch, p.splits, smem);
+}
+
+// Sum the workspace partials of one 16(co) x 16(ci) x 9(tap) unit per workgroup and write it in the parameter's layout
+// (for OIHW gradients 16 runs of 144 contiguous floats).  Wave w takes the splits w, w+4, ...; LDS combines the waves.
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wreduce_task* __restrict__ tasks,
+                                                                 const int* __restrict__ blk_start, int ntasks) {
+    __shared__ float tile_s[2304];
+    int lo = 0, hi = ntasks;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const gdrn_wreduce_task k = tasks[lo];
+    const int unit = blockIdx.x - blk_start[lo];       // (tile, wv, a, b)
+    const int b = unit & 1, a = (unit >> 1) & 1, wv = (unit >> 2) & 3, tile = unit >> 4;
+    const int ncot = k.Cout / 64, ntile = ncot * (k.Cin / 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2304; i += 256) tile_s[i] = 0.f;
+    __syncthreads();
+    f32x4_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float* base = k.ws + (size_t)tile * 36864 + (size_t)((a * 2 + b) * 4 + wv) * 256 + lane * 4;
+    for (int sp = wave; sp < k.nsplit; sp += 4) {
+        const float* src = base + (size_t)sp * ntile * 36864;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += *reinterpret_cast<const f32x4_t*>(src + t * 4096);
+    }
+    const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&tile_s[((g * 4 + j) * 16 + q) * 9 + t], acc[t][j]);
+    __syncthreads();
+    const int co0 = (tile % ncot) * 64 + (wv >> 1) * 32 + a * 16, ci0 = (tile / ncot) * 64 + (wv & 1) * 32 + b * 16;
+    for (int i = threadIdx.x; i < 2304; i += 256) {
+        const int col = i / 144, r = i - col * 144, cil = r / 9, t = r - cil * 9;
+        k.dst[(long long)(co0 + col) * k.s_co + (long long)(ci0 + cil) * k.s_ci + (long long)t * k.s_t] = tile_s[i];
+    }
+}
+
 }  // namespace
 
 // 1 if the shape is covered by the halo weight-gradient kernel
@@ -176,18 +254,33 @@ extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
            (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0;
 }
 
+// number of pixel-range splits the launcher uses for these params (p->splits <= 0: automatic); the workspace of the
+// p->ws path holds splits * Cout * Cin * 9 floats
+extern "C" int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* pp) {
+    if (!pp || !gdrn_conv3x3_wgrad_ok(pp)) return 0;
+    const gdrn_wgrad_params& p = *pp;
+    const int hw = p.Ho * p.Wo;
+    if (p.M <= 0 || p.M % hw) return 0;
+    const int npatch = (p.M / hw) * (p.Ho / 8) * (p.Wo / 8);
+    const int tiles = (p.Cout / 64) * (p.Cin / 64);
+    int splits = p.splits;
+    // one partial tile per workgroup either way: target one workgroup per CU (two when the partials are plain stores)
+    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(p.ws ? 512 : 256, tiles)));
+    splits = std::min(splits, npatch);
+    const int per = cdiv(npatch, splits);
+    return cdiv(npatch, per);  // no empty split: every workspace slab gets written
+}
+
 extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
-    if (!pp || !pp->x || !pp->dy || !pp->dw) return GDRN_ERR_ARG;
+    if (!pp || !pp->x || !pp->dy || (!pp->dw && !pp->ws)) return GDRN_ERR_ARG;
     if (!gdrn_conv3x3_wgrad_ok(pp)) return GDRN_ERR_SHAPE;
     const gdrn_wgrad_params& p = *pp;
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw) return GDRN_ERR_SHAPE;
     const int npatch = (p.M / hw) * (p.Ho / 8) * (p.Wo / 8);
     const int tiles = (p.Cout / 64) * (p.Cin / 64);
-    int splits = p.splits;
-    // every split costs one fp32 atomic per output element (measured ~0.3 T atomic lanes/s): one workgroup per CU
-    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(256, tiles)));
-    splits = std::min(splits, npatch);
+    const int splits = gdrn_conv3x3_wgrad_splits(pp);
+    if (splits <= 0) return GDRN_ERR_SHAPE;
     constexpr size_t smem = 2 * (size_t)STAGEB;
     static bool attr_set = false;
     if (!attr_set) {
@@ -198,6 +291,30 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     }
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch,
                        splits);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
+    if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
+    constexpr size_t smem = 2 * (size_t)STAGEB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return GDRN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(nblocks), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev,
+                       blk_start_dev, ntasks);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
+    if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tasks_dev,
+                       blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -20,6 +20,9 @@ __device__ __forceinline__ int find_task(const int* __restrict__ start, int n, i
 
 constexpr int PACK_CHUNK = 2048;  // elements per workgroup
 
+// One thread converts one 16-byte destination granule (GE consecutive b): one index decode per GE elements -- the
+// per-element version was bound by its 64-bit divisions, not by HBM.  Needs B % GE == 0 (true for every layout of the
+// path: B is a channel stride padded to the 128-byte K stage); other tables take the scalar tail below.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* __restrict__ tasks, const int* __restrict__ blk_start,
                                                          int ntasks) {
@@ -28,12 +31,48 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
     const gdrn_pack_task k = tasks[t];
     const long long base = (long long)(blockIdx.x - blk_start[t]) * PACK_CHUNK;
     T* dst = reinterpret_cast<T*>(k.dst);
+    if ((k.B % GE) == 0 && (k.n % GE) == 0) {
+        const unsigned B = (unsigned)k.B, Tt = (unsigned)k.T, A2 = (unsigned)k.A2;
+        for (int g = threadIdx.x; g < PACK_CHUNK / GE; g += 256) {
+            const long long i = base + (long long)g * GE;
+            if (i >= k.n) break;
+            unsigned a1, a2, tt, b0;
+            unsigned r = (unsigned)(i / GE);  // granule index (< 2^31: n < 2^31 * GE)
+            if (k.frag) {
+                // fragment-major destination (conv3x3_halo.hip): granule ((((cb*9 + tap)*kch + kc)*2 + ks)*64 + lane)
+                const unsigned lane = r & 63u; r >>= 6;
+                const unsigned ks = r & 1u; r >>= 1;
+                const unsigned kch = B / EPS;
+                const unsigned kc = r % kch; r /= kch;
+                tt = r % 9u;
+                a1 = (r / 9u) * 16u + (lane & 15u);
+                a2 = 0;
+                b0 = kc * EPS + (ks * 4u + (lane >> 4)) * GE;
+            } else {
+                const unsigned bg = B / GE;
+                b0 = (r % bg) * GE; r /= bg;
+                tt = r % Tt; r /= Tt;
+                a2 = r % A2;
+                a1 = r / A2;
+            }
+            float v[GE];
+            const bool ok = (int)a1 < k.A1v && (int)a2 < k.A2v;
+            const unsigned ts = k.flip ? (Tt - 1u - tt) : tt;
+            const float* sp = k.src + (long long)a1 * k.s1 + (long long)a2 * k.s2 + (long long)ts * k.st;
+#pragma unroll
+            for (int el = 0; el < GE; ++el) {
+                const int b = (int)b0 + el;
+                v[el] = (ok && b < k.Bv) ? sp[(long long)b * k.sb] : 0.f;
+            }
+            Vec16<T>::store(dst + i, v);
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < PACK_CHUNK; e += 256) {
         const long long i = base + e;
         if (i >= k.n) break;
         int a1, a2, tt, b;
         if (k.frag) {
-            // fragment-major destination (conv3x3_halo.hip): granule index ((((cb*9 + tap)*kch + kc)*2 + ks)*64 + lane)
             const int el = (int)(i % GE);
             long long r = i / GE;
             const int lane = (int)(r & 63); r >>= 6;
@@ -66,8 +105,27 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const gdrn_pack_task*
     const gdrn_pack_task k = tasks[t];  // src = packed fp32 [A1][A2][T][B], dst = parameter-layout gradient
     const long long base = (long long)(blockIdx.x - blk_start[t]) * PACK_CHUNK;
     float* dst = reinterpret_cast<float*>(k.dst);
+    if ((k.Bv & 3) == 0 && (k.B & 3) == 0) {  // 4 consecutive b per thread: one decode, one 16-byte read
+        const unsigned bq = (unsigned)k.Bv >> 2, Tt = (unsigned)k.T, A2v = (unsigned)k.A2v;
+        for (int g = threadIdx.x; g < PACK_CHUNK / 4; g += 256) {
+            const long long i = base + (long long)g * 4;  // index over the VALID region [A1v][A2v][T][Bv]
+            if (i >= k.n) break;
+            unsigned r = (unsigned)(i >> 2);
+            const unsigned b = (r % bq) * 4u; r /= bq;
+            const unsigned tt = r % Tt; r /= Tt;
+            const unsigned a2 = r % A2v, a1 = r / A2v;
+            const unsigned ts = k.flip ? (Tt - 1u - tt) : tt;
+            const float4 v = *reinterpret_cast<const float4*>(k.src + (((long long)a1 * k.A2 + a2) * k.T + tt) * k.B + b);
+            float* dp = dst + (long long)a1 * k.s1 + (long long)a2 * k.s2 + (long long)ts * k.st + (long long)b * k.sb;
+            dp[0] = v.x;
+            dp[k.sb] = v.y;
+            dp[2 * k.sb] = v.z;
+            dp[3 * k.sb] = v.w;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < PACK_CHUNK; e += 256) {
-        const long long i = base + e;  // index over the VALID region [A1v][A2v][T][Bv]
+        const long long i = base + e;
         if (i >= k.n) break;
         const int b = (int)(i % k.Bv);
         long long r = i / k.Bv;

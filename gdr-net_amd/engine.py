@@ -49,6 +49,8 @@ class Engine:
         import os as _os
 
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
+        self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
+        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "2048"))  # target workgroups of a grouped launch
         self.layers = OrderedDict()
         self._versions = {}
         self._build_layers()
@@ -156,9 +158,14 @@ class Engine:
         for L in self.layers.values():
             L.dwp_off = tot
             tot += _ru(int(math.prod(L.dwp_shape)), 4)
-        self.dwp_flat = torch.zeros(tot, dtype=torch.float32, device=self.dev)
+        # tail: the BN backward per-channel sums of a plan -- accumulated with atomics like the packed weight gradients,
+        # so one fill per backward pass clears both
+        self.bn_sums_cap = 65536
+        self.dwp_flat = torch.zeros(tot + self.bn_sums_cap, dtype=torch.float32, device=self.dev)
+        self.bn_sums_flat = self.dwp_flat[tot:]
         for L in self.layers.values():
             L.dwp = self.dwp_flat[L.dwp_off: L.dwp_off + int(math.prod(L.dwp_shape))]
+        self.bn_ws = torch.zeros(2 * 512 + 32, dtype=torch.float64, device=self.dev)  # gdrn_bn_finalize workspace (self-cleaning)
         self.rt_w = torch.zeros(9, 256, dtype=torch.float32, device=self.dev)
         self.rt_b = torch.zeros(9, dtype=torch.float32, device=self.dev)
 
@@ -188,8 +195,9 @@ class Engine:
             if L.kind == "stem":
                 continue
             src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
+            halo_only = self.use_halo and L.wfF is not None  # both conv passes read the fragment-major copies
             for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, 1), ("d", L.wdF, 1)):
-                if dst is None:
+                if dst is None or (halo_only and not frag):
                     continue
                 A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip = self._pack_args(L, which)
                 t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
@@ -244,6 +252,8 @@ class Plan:
         self.keep = []         # keep ctypes structs alive
         self.bn = {}           # bn key -> NS(mean, invstd, scale, shift, sums)
         self._unpack_pending = []  # (forward group index, layer)
+        self._wreduce = {}         # layer key -> (workspace, nsplit, Cout, Cin) of the halo weight-gradient partials
+        self._wgrad_deferred = []  # (forward group index, layer, WgradParams, flops) of the halo weight gradients
         self._build()
         if self.has_backward:
             self._finish_unpack()
@@ -272,6 +282,8 @@ class Plan:
         th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
         e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
         use_halo = e.use_halo and th.value > 0 and L.kind == "conv" and L.wfF is not None
+        if e.use_halo and L.wfF is not None and not use_halo:
+            raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
         if use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
@@ -315,6 +327,11 @@ class Plan:
         ref = C.byref(wp)
         use_halo = e.use_halo and L.kind == "conv" and bool(e.lib.gdrn_conv3x3_wgrad_ok(ref))
         fn = e.lib.gdrn_conv3x3_wgrad if use_halo else e.lib.gdrn_conv_wgrad
+        if use_halo and e.wgrad_ws:
+            # deferred: one grouped launch per gradient bucket (see _finish_unpack) -- weight gradients are off the
+            # critical path, and a grid over many layers fills the chip with far fewer pixel-range splits per layer
+            self._wgrad_deferred.append((len(self.bwd_groups), L, wp, 2.0 * self.B * Ho * Wo * L.O * L.I * L.KK))
+            return None
 
         def run(st, ctx):
             s = fn(ref, st)
@@ -342,14 +359,20 @@ class Plan:
             g = e.grads[L.src[0]]
             return lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w")
         self._unpack_pending.append((len(self.bwd_groups), L))
-        return None
+        return None  # marker, dropped when the groups are flattened
+
+    def _bn_sums(self, n):
+        off = getattr(self, "_bn_sums_off", 0)
+        assert off + n <= self.e.bn_sums_cap
+        self._bn_sums_off = off + n
+        return self.e.bn_sums_flat[off: off + n]
 
     def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
         """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
         e, lib = self.e, self.e.lib
         s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
                scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32),
-               sums=e._empty(2 * C_, dtype=torch.float32), C=C_, npix=npix)
+               sums=self._bn_sums(2 * C_), C=C_, npix=npix)
         self.bn[bnkey] = s
         g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
         rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
@@ -358,7 +381,7 @@ class Plan:
             rows = self._stats_rows(cp)
             ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
                                                                   ptr(rv), ptr(nbt), 0.1, 1e-5, ptr(s.mean), ptr(s.invstd),
-                                                                  ptr(s.scale), ptr(s.shift), st), "bn_finalize"))
+                                                                  ptr(s.scale), ptr(s.shift), ptr(e.bn_ws), st), "bn_finalize"))
         else:
             ops.append(lambda st, ctx: check(lib.gdrn_bn_eval_params(ptr(g), ptr(b), ptr(rm), ptr(rv), 1e-5, C_, ptr(s.scale),
                                                                      ptr(s.shift), st), "bn_eval_params"))
@@ -402,10 +425,58 @@ class Plan:
         ng = len(self.bwd_groups)
         assert ng == 29, ng
         first_group = (25, 17, 8, 0)  # forward index of the LAST-executed group of buckets 0..3
+        from .cabi import WreduceTask
+
+        bucket_of = lambda gi: 0 if gi >= 25 else (1 if gi >= 17 else (2 if gi >= 8 else 3))
+        # ---- grouped halo weight gradients: a common number of 8x8 pixel patches per workgroup within a bucket, chosen so
+        # that the bucket's grid has ~wgrad_blocks workgroups (2 per CU resident); longest-running tasks first
+        wg_bucket = {0: [], 1: [], 2: [], 3: []}
+        for gi, L, wp, flops in self._wgrad_deferred:
+            wg_bucket[bucket_of(gi)].append((L, wp, flops))
+        self._wgrad_tables = []
+        for bkt, items in wg_bucket.items():
+            if not items:
+                continue
+            geo = []
+            for L, wp, flops in items:
+                npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // 8) * (wp.Wo // 8)
+                geo.append((npatch, (wp.Cout // 64) * (wp.Cin // 64)))
+            per = max(8, sum(n * t for n, t in geo) // e.wgrad_blocks)
+            tasks = []
+            for (L, wp, flops), (npatch, tiles) in zip(items, geo):
+                wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
+                wp.splits = max(1, npatch // per)
+                wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
+                ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
+                self.keep.append(ws)
+                wp.ws, wp.dw = ptr(ws), None
+                self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin)
+                tasks.append((-(npatch // wp.splits), len(tasks), wp, tiles, flops))
+            tasks.sort(key=lambda t: t[:2])
+            starts = [0]
+            for _, _, wp, tiles, _ in tasks:
+                starts.append(starts[-1] + tiles * wp.splits)
+            tab = to_device_table([t[2] for t in tasks], e.dev)
+            stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
+            self._wgrad_tables.append((tab, stt))
+            nt, nb = len(tasks), starts[-1]
+
+            def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb):
+                check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab), ptr(stt), nt, nb, st), "conv3x3_wgrad_multi")
+
+            run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
+            self.bwd_groups[first_group[bkt]].append(run)
+
         per_bucket = {0: [], 1: [], 2: [], 3: []}
+        red_bucket = {0: [], 1: [], 2: [], 3: []}
         for gi, L in self._unpack_pending:
-            bkt = 0 if gi >= 25 else (1 if gi >= 17 else (2 if gi >= 8 else 3))
-            if L.key == "pnp_net.fc_rt":
+            bkt = bucket_of(gi)
+            if L.key in self._wreduce:
+                ws, nsplit, cout, cin = self._wreduce[L.key]
+                assert (cout, cin) == (L.O, L.I)
+                red_bucket[bkt].append(WreduceTask(ws=ws.data_ptr(), dst=e.grads[L.src[0]].data_ptr(), nsplit=nsplit, Cout=cout, Cin=cin,
+                                                   pad_=0, s_co=cin * 9, s_ci=9, s_t=1))
+            elif L.key == "pnp_net.fc_rt":
                 per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr(), e.grads["pnp_net.fc_r.weight"], 6))
                 per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr() + 6 * L.in_ch * 4, e.grads["pnp_net.fc_t.weight"], 3))
             else:
@@ -423,6 +494,18 @@ class Plan:
             nt, nb = len(tasks), starts[-1]
             self.bwd_groups[first_group[bkt]].append(
                 lambda st, ctx, tab=tab, stt=stt, nt=nt, nb=nb: check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi"))
+        for bkt, tasks in red_bucket.items():
+            if not tasks:
+                continue
+            starts = [0]
+            for t in tasks:
+                starts.append(starts[-1] + t.Cout * t.Cin // 256)
+            tab = to_device_table(tasks, e.dev)
+            stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
+            self._unpack_tables.append((tab, stt))
+            nt, nb = len(tasks), starts[-1]
+            self.bwd_groups[first_group[bkt]].append(
+                lambda st, ctx, tab=tab, stt=stt, nt=nt, nb=nb: check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi"))
 
     # ---- graph -------------------------------------------------------------------------------
     def _build(self):

@@ -82,11 +82,13 @@ int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
 /* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
  *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather).  variant: 0 = LDS transpose-read (bf16),
  *   1 = scalar LDS reads (bf16 reference variant).  splits <= 0: automatic pixel-range split.
+ * ws (gdrn_conv3x3_wgrad only, else NULL): per-split partial tiles go here (plain stores) instead of atomics on dw.
  * Replaces the autograd weight-gradients of the same layers (engine.py:279). */
 typedef struct gdrn_wgrad_params {
     const void* x;
     const void* dy;
     float* dw;
+    float* ws;
     int Hi, Wi, Cin, x_cs;
     int Ho, Wo, Cout, dy_cs;
     int KH, KW, stride, pad;
@@ -95,9 +97,25 @@ typedef struct gdrn_wgrad_params {
 int gdrn_conv_wgrad(const gdrn_wgrad_params* p, void* stream);
 /* Halo-tiled variant for KH=KW=3, stride 1, pad 1, bf16, H and W multiples of 8, Cin and Cout multiples of 64: a workgroup
  * accumulates a 64 x 64 (co x ci) tile of all nine taps from one staged 8x8 pixel patch per stage.  Same dw layout and
- * accumulate-with-atomics contract.  gdrn_conv3x3_wgrad_ok returns 1 when the shape is covered. */
+ * accumulate-with-atomics contract.  gdrn_conv3x3_wgrad_ok returns 1 when the shape is covered.
+ * With p->ws != NULL the partial tiles of the gdrn_conv3x3_wgrad_splits(p) pixel-range splits are stored to
+ * ws[split][Cout*Cin*9] (fragment order, no atomics, dw unused) and gdrn_wgrad_reduce_multi sums them for a whole
+ * table of layers in one launch, writing dst[co*s_co + ci*s_ci + tap*s_t] (e.g. the OIHW .grad: s_co = Cin*9, s_ci = 9,
+ * s_t = 1).  blk_start[i] = sum over tasks j < i of Cout_j*Cin_j/256; nblocks = blk_start[ntasks]. */
 int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* p, void* stream);
 int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p);
+int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* p);
+/* Grouped launch: the weight gradients of ntasks layers in one grid.  tasks_dev: device array of gdrn_wgrad_params with
+ * ws != NULL and splits = gdrn_conv3x3_wgrad_splits() of an explicit request (no empty split);
+ * blk_start[i] = sum_{j<i} (Cout_j/64)*(Cin_j/64)*splits_j, nblocks = blk_start[ntasks]. */
+int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+typedef struct gdrn_wreduce_task {
+    const float* ws;
+    float* dst;
+    int nsplit, Cout, Cin, pad_;
+    long long s_co, s_ci, s_t;
+} gdrn_wreduce_task;
+int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight / layout packing.
@@ -125,14 +143,17 @@ int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, float* dst, in
  * BatchNorm2d (train / eval), fused with ReLU, residual add and max-pool where the graph has them.
  * Replaces nn.BatchNorm2d + nn.ReLU + `out += identity` + nn.MaxPool2d at resnet_backbone.py:24-26,
  * BasicBlock, cdpn_rot_head_region.py:92-93,113-114 and their backward. */
+/* ws: optional workspace of 2*C doubles + ceil(C/16) uint32, zeroed ONCE by the caller (the kernel leaves it zeroed);
+ * with it the reduction over the `rows` per-tile partials is spread over many workgroups, NULL = one pass per 16 channels */
 int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
-                     float eps, float* mean, float* invstd, float* scale, float* shift, void* stream);
+                     float eps, float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream);
 int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, int C, float* scale, float* shift, void* stream);
 int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                   long long npix, int C, int relu, int dtype, void* stream);
-/* sums[0][c] = sum g, sums[1][c] = sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy) */
+/* sums[0][c] += sum g, sums[1][c] += sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy).  ACCUMULATES with
+ * atomics: the caller clears sums[2*C] first (the engine clears all layers' sums with one fill per backward pass) */
 int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
                        long long npix, int C, float* sums, int dtype, void* stream);
 /* dx = gamma*invstd*(g - sums0/n - xhat*sums1/n); optional g_out = g; dgamma = sums1, dbeta = sums0 */

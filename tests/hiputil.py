@@ -107,7 +107,8 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     return y, stats
 
 
-def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0, halo=False):
+def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0, halo=False, ws=False):
+    """ws: halo kernel with workspace partials + gdrn_wgrad_reduce_multi; returns the OIHW gradient in that case."""
     lib = cabi.load()
     dw = torch.zeros(Cout, KH * KW, Cin, dtype=torch.float32, device=DEV)
     wp = WgradParams()
@@ -118,6 +119,21 @@ def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride,
     wp.M, wp.dtype, wp.splits, wp.variant = B * Ho * Wo, dt, splits, variant
     if halo:
         assert lib.gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 1
+    if ws:
+        from gdrnet_amd.cabi import WreduceTask, to_device_table
+
+        wp.ws = ptr(dw)  # non-null: query the split count of the workspace mode
+        ns = lib.gdrn_conv3x3_wgrad_splits(C.byref(wp))
+        assert ns >= 1
+        wsb = torch.full((ns * Cout * Cin * 9,), float("nan"), dtype=torch.float32, device=DEV)  # every slab must be written
+        wp.ws, wp.dw = ptr(wsb), None
+        check(lib.gdrn_conv3x3_wgrad(C.byref(wp), stream()), "conv3x3_wgrad(ws)")
+        grad = torch.full((Cout, Cin, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+        tab = to_device_table([WreduceTask(ws=ptr(wsb), dst=ptr(grad), nsplit=ns, Cout=Cout, Cin=Cin, pad_=0, s_co=Cin * 9, s_ci=9, s_t=1)], DEV)
+        stt = torch.tensor([0, Cout * Cin // 256], dtype=torch.int32, device=DEV)
+        check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), 1, Cout * Cin // 256, stream()), "wgrad_reduce_multi")
+        torch.cuda.synchronize()
+        return grad
     check((lib.gdrn_conv3x3_wgrad if halo else lib.gdrn_conv_wgrad)(C.byref(wp), stream()), "conv_wgrad")
     torch.cuda.synchronize()
     return dw

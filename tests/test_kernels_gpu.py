@@ -224,6 +224,63 @@ def test_conv3x3_wgrad_halo(H, case, splits):
     assert H.rel(dw.view(O, 3, 3, I).permute(0, 3, 1, 2), w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("splits", [0, 1, 5])
+@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (5, 512, 512, 8), (8, 64, 64, 64)])
+def test_conv3x3_wgrad_halo_workspace(H, case, splits):
+    """halo weight gradient with per-split workspace partials + multi-layer reduce (writes the OIHW gradient directly)."""
+    B, I, O, Hh = case
+    dt = BF16
+    x = H.rounded(H.randn(46, B, I, Hh, Hh), dt)
+    w = H.randn(47, O, I, 3, 3).requires_grad_(True)
+    dy = H.rounded(H.randn(48, B, O, Hh, Hh), dt)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    grad = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True, ws=True)
+    assert torch.isfinite(grad).all()
+    assert H.rel(grad, w.grad) < 1e-2
+
+
+def test_conv3x3_wgrad_grouped(H):
+    """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer."""
+    from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
+
+    lib = cabi.load()
+    dt, dev = BF16, H.DEV
+    cases = [(2, 64, 64, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1)]  # B, I, O, H, requested splits
+    keep, wps, tasks, refs, grads = [], [], [], [], []
+    for i, (B, I, O, Hh, sp) in enumerate(cases):
+        x = H.rounded(H.randn(60 + i, B, I, Hh, Hh), dt)
+        w = H.randn(70 + i, O, I, 3, 3).requires_grad_(True)
+        dy = H.rounded(H.randn(80 + i, B, O, Hh, Hh), dt)
+        F.conv2d(x, w, None, 1, 1).backward(dy)
+        refs.append(w.grad)
+        xd, dyd = H.nhwc(x, dt), H.nhwc(dy, dt)
+        wp = WgradParams()
+        wp.x, wp.dy, wp.dw = ptr(xd), ptr(dyd), None
+        wp.Hi, wp.Wi, wp.Cin, wp.x_cs, wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Hh, Hh, I, I, Hh, Hh, O, O
+        wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.splits, wp.variant = 3, 3, 1, 1, B * Hh * Hh, dt, sp, 0
+        wp.ws = ptr(xd)  # placeholder for the query
+        wp.splits = lib.gdrn_conv3x3_wgrad_splits(C.byref(wp))
+        assert 1 <= wp.splits <= sp
+        ws = torch.full((wp.splits * O * I * 9,), float("nan"), dtype=torch.float32, device=dev)
+        wp.ws = ptr(ws)
+        g = torch.full((O, I, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+        keep += [xd, dyd, ws]
+        grads.append(g)
+        wps.append(wp)
+        tasks.append(WreduceTask(ws=ptr(ws), dst=ptr(g), nsplit=wp.splits, Cout=O, Cin=I, pad_=0, s_co=I * 9, s_ci=9, s_t=1))
+    st1, st2 = [0], [0]
+    for wp in wps:
+        st1.append(st1[-1] + (wp.Cout // 64) * (wp.Cin // 64) * wp.splits)
+        st2.append(st2[-1] + wp.Cout * wp.Cin // 256)
+    tab1, tab2 = to_device_table(wps, dev), to_device_table(tasks, dev)
+    s1, s2 = torch.tensor(st1, dtype=torch.int32, device=dev), torch.tensor(st2, dtype=torch.int32, device=dev)
+    check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab1), ptr(s1), len(wps), st1[-1], H.stream()), "conv3x3_wgrad_multi")
+    check(lib.gdrn_wgrad_reduce_multi(ptr(tab2), ptr(s2), len(tasks), st2[-1], H.stream()), "wgrad_reduce_multi")
+    torch.cuda.synchronize()
+    for g, r in zip(grads, refs):
+        assert torch.isfinite(g).all() and H.rel(g, r) < 1e-2
+
+
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])
@@ -251,7 +308,7 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     gam_d, bet_d = gam.detach().to(dev), bet.detach().to(dev)  # keep alive: the launches are asynchronous
     st = H.stream()
     check(lib.gdrn_bn_finalize(ptr(part), 2, C_, float(npix), ptr(gam_d), ptr(bet_d), ptr(rmd), ptr(rvd), ptr(nbt),
-                               0.1, 1e-5, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), st), "bn_finalize")
+                               0.1, 1e-5, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), None, st), "bn_finalize")
     y = torch.empty_like(xd)
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), ptr(resd), ptr(y), npix, C_, 1, dt, st), "bn_apply")
     assert H.rel(H.nchw(y), yref) < TOL[dt]
@@ -411,3 +468,31 @@ def test_head_tail_and_map_losses(H, dt):
     gotd = dh.float().cpu().view(B, 64, 64, 128)
     assert H.rel(gotd[..., :69].permute(0, 3, 1, 2), head.grad) < (1e-4 if dt == F32 else 2e-2)
     assert float(gotd[..., 69:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,C_", [(1000, 64), (4096, 64), (513, 256), (130, 512), (64, 128)])
+def test_bn_finalize_workspace(H, rows, C_):
+    """many-workgroup finalize (ticket + fp64 workspace) == fp64 numpy; the workspace is left zeroed (second call agrees)."""
+    lib = cabi.load()
+    dev = H.DEV
+    rng = np.random.default_rng(rows + C_)
+    part = rng.normal(size=(rows, 2, C_)).astype(np.float32)
+    part[:, 1] = np.abs(part[:, 1]) * 3 + 1.0
+    count = float(rows * 7)
+    pd = torch.from_numpy(part).to(dev)
+    gam, bet = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev)
+    ws = torch.zeros(2 * C_ + (C_ + 15) // 16, dtype=torch.float64, device=dev)
+    m = part[:, 0].astype(np.float64).sum(0) / count
+    var = np.maximum(part[:, 1].astype(np.float64).sum(0) / count - m * m, 0)
+    for it in range(2):
+        mk = lambda: torch.zeros(C_, device=dev)
+        mean, invstd, scale, shift = mk(), mk(), mk(), mk()
+        rm, rv, nbt = torch.zeros(C_, device=dev), torch.ones(C_, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+        check(lib.gdrn_bn_finalize(ptr(pd), rows, C_, count, ptr(gam), ptr(bet), ptr(rm), ptr(rv), ptr(nbt), 0.1, 1e-5, ptr(mean),
+                                   ptr(invstd), ptr(scale), ptr(shift), ptr(ws), H.stream()), "bn_finalize")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mean.cpu().numpy(), m, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(invstd.cpu().numpy(), 1 / np.sqrt(var + 1e-5), rtol=1e-6)
+        np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(scale.cpu().numpy(), gam.cpu().numpy() / np.sqrt(var + 1e-5), rtol=2e-6)
+        assert int(nbt) == 1 and float(ws.abs().max()) == 0.0
