@@ -103,8 +103,8 @@ _SIGS = {
     "gdrn_bn_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P, P, P, P],
     "gdrn_bn_eval_params": [P, P, P, P, F, I, P, P, P],
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
-    "gdrn_bn_bwd_reduce": [P, P, P, P, P, LL, I, P, I, P],
-    "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
+    "gdrn_bn_bwd_reduce": [P, P, P, P, P, P, P, LL, I, P, I, P],
+    "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const gdrn_
 }
 
 // Sum the workspace partials of one 16(co) x 16(ci) x 9(tap) unit per workgroup and write it in the parameter's layout
-// (for OIHW gradients 16 runs of 144 contiguous floats).  Wave w takes the splits w, w+4, ...; LDS combines the waves.
+// (for OIHW gradients 16 runs of 144 contiguous floats); LDS turns fragment order into that layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wreduce_task* __restrict__ tasks,
                                                                  const int* __restrict__ blk_start, int ntasks) {
     __shared__ float tile_s[2304];
@@ -219,23 +219,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wred
     const int unit = blockIdx.x - blk_start[lo];       // (tile, wv, a, b)
     const int b = unit & 1, a = (unit >> 1) & 1, wv = (unit >> 2) & 3, tile = unit >> 4;
     const int ncot = k.Cout / 64, ntile = ncot * (k.Cin / 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2304; i += 256) tile_s[i] = 0.f;
-    __syncthreads();
-    f32x4_t acc[9];
+    // 9 taps x 64 fragment lanes = 576 float4 columns; a thread sums one column over all splits (4 loads in flight),
+    // so the memory parallelism does not depend on the split count
+    const float* base = k.ws + (size_t)tile * 36864 + (size_t)((a * 2 + b) * 4 + wv) * 256;
+    const size_t sstride = (size_t)ntile * 36864;
+    for (int idx = threadIdx.x; idx < 576; idx += 256) {
+        const int t = idx >> 6, ln = idx & 63;
+        const float* src = base + t * 4096 + ln * 4;
+        f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int sp = 0;
+        for (; sp + 4 <= k.nsplit; sp += 4) {
+            a0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)sp * sstride);
+            a1 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(sp + 1) * sstride);
+            a2 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(sp + 2) * sstride);
+            a3 += *reinterpret_cast<const f32x4_t*>(src + (size_t)(sp + 3) * sstride);
+        }
+        for (; sp < k.nsplit; ++sp) a0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)sp * sstride);
+        a0 += a1;
+        a2 += a3;
+        a0 += a2;
+        const int g = ln >> 4, q = ln & 15;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const float* base = k.ws + (size_t)tile * 36864 + (size_t)((a * 2 + b) * 4 + wv) * 256 + lane * 4;
-    for (int sp = wave; sp < k.nsplit; sp += 4) {
-        const float* src = base + (size_t)sp * ntile * 36864;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] += *reinterpret_cast<const f32x4_t*>(src + t * 4096);
+        for (int j = 0; j < 4; ++j) tile_s[((g * 4 + j) * 16 + q) * 9 + t] = a0[j];
     }
-    const int g = lane >> 4, q = lane & 15;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&tile_s[((g * 4 + j) * 16 + q) * 9 + t], acc[t][j]);
     __syncthreads();
     const int co0 = (tile % ncot) * 64 + (wv >> 1) * 32 + a * 16, ci0 = (tile / ncot) * 64 + (wv & 1) * 32 + b * 16;
     for (int i = threadIdx.x; i < 2304; i += 256) {

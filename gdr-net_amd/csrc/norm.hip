@@ -94,9 +94,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     constexpr int V = Vec16<T>::VEC;
     const int tpr = C / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    __shared__ float kst[2][512];
+    for (int c = threadIdx.x; c < C; c += 256) { kst[0][c] = scale[c]; kst[1][c] = shift[c]; }
+    __syncthreads();
     float sc[V], sh[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { sc[j] = scale[cv * V + j]; sh[j] = shift[cv * V + j]; }
+    for (int j = 0; j < V; ++j) { sc[j] = kst[0][cv * V + j]; sh[j] = kst[1][cv * V + j]; }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(npix, r0 + rows_per_block);
     if (rl >= rpp) return;
@@ -120,17 +123,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, long long npix, int C,
+                                                            const float* __restrict__ invstd, const float* __restrict__ msc,
+                                                            const float* __restrict__ msh, long long npix, int C,
                                                             float* sums, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
     __shared__ float acc[2 * 512];
     const int tpr = C / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) acc[i] = 0.f;
+    // per-channel constants through LDS: one coalesced load round per workgroup instead of 4*V dependent scalar loads
+    // per thread (those latency chains cost ~10 us per launch)
+    __shared__ float kst[4][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        acc[c] = 0.f;
+        acc[C + c] = 0.f;
+        kst[0][c] = mean[c];
+        kst[1][c] = invstd[c];
+        kst[2][c] = msc ? msc[c] : 0.f;
+        kst[3][c] = msc ? msh[c] : 1.f;
+    }
     __syncthreads();
-    float s1[V], s2[V], mu[V], is[V];
+    float s1[V], s2[V], mu[V], is[V], ksc[V], ksh[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[cv * V + j]; is[j] = invstd[cv * V + j]; }
+    for (int j = 0; j < V; ++j) {
+        s1[j] = 0.f; s2[j] = 0.f;
+        mu[j] = kst[0][cv * V + j]; is[j] = kst[1][cv * V + j]; ksc[j] = kst[2][cv * V + j]; ksh[j] = kst[3][cv * V + j];
+    }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(npix, r0 + rows_per_block);
     if (rl < rpp) {
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int j = 0; j < V; ++j) {
                 float gg = g[j];
                 if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
+                if (!(xv[j] * ksc[j] + ksh[j] > 0.f)) gg = 0.f;  // ReLU mask recomputed from x (no-op without msc)
                 s1[j] += gg;
                 s2[j] += gg * (xv[j] - mu[j]) * is[j];
             }
@@ -154,32 +172,45 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) unsafeAtomicAdd(&sums[i], acc[i]);
+    // same-address global atomics run at only a few G/s: spread the workgroups over GDRN_BN_SUM_COPIES copies of the sums
+    float* dst = sums + (size_t)(blockIdx.x % GDRN_BN_SUM_COPIES) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) unsafeAtomicAdd(&dst[i], acc[i]);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, long long npix, int C, float inv_n,
+                                                           const float* __restrict__ sums, const float* __restrict__ msc,
+                                                           const float* __restrict__ msh, long long npix, int C, float inv_n,
                                                            T* __restrict__ dx, T* __restrict__ gout, float* dgamma,
                                                            float* dbeta, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
-    if (blockIdx.x == 0 && dgamma != nullptr) {
-        for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] = sums[c]; dgamma[c] = sums[C + c]; }
+    // per-channel constants computed once per workgroup (thread = channel) and handed out through LDS:
+    // dx = a*(g - m1) - a*xhat*m2  with xhat = (x - mu)*is  ->  dx = a*g + (b*x + c), b = -a*is*m2, c = -a*m1 - b*mu
+    __shared__ float kst[5][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < GDRN_BN_SUM_COPIES; ++r) { m1 += sums[(size_t)r * 2 * C + c]; m2 += sums[(size_t)r * 2 * C + C + c]; }
+        if (blockIdx.x == 0 && dgamma != nullptr) { dbeta[c] = m1; dgamma[c] = m2; }
+        m1 *= inv_n;
+        m2 *= inv_n;
+        const float is = invstd[c], a = gamma[c] * is, b = -a * is * m2;
+        kst[0][c] = a;
+        kst[1][c] = b;
+        kst[2][c] = -a * m1 - b * mean[c];
+        kst[3][c] = msc ? msc[c] : 0.f;
+        kst[4][c] = msc ? msh[c] : 1.f;
     }
+    __syncthreads();
     const int tpr = C / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    // dx = a*(g - m1) - a*xhat*m2  with xhat = (x - mu)*is  ->  dx = a*g + (b*x + c), b = -a*is*m2, c = -a*m1 - b*mu
-    float ka[V], kb[V], kc[V];
+    float ka[V], kb[V], kc[V], ksc[V], ksh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j;
-        const float is = invstd[c], a = gamma[c] * is;
-        const float m1 = sums[c] * inv_n, m2 = sums[C + c] * inv_n;
-        ka[j] = a;
-        kb[j] = -a * is * m2;
-        kc[j] = -a * m1 - kb[j] * mean[c];
+        ka[j] = kst[0][c]; kb[j] = kst[1][c]; kc[j] = kst[2][c]; ksc[j] = kst[3][c]; ksh[j] = kst[4][c];
     }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(npix, r0 + rows_per_block);
@@ -194,6 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int j = 0; j < V; ++j) {
             float gg = g[j];
             if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
+            if (!(xv[j] * ksc[j] + ksh[j] > 0.f)) gg = 0.f;
             g[j] = gg;
             o[j] = ka[j] * gg + (kb[j] * xv[j] + kc[j]);
         }
@@ -596,27 +628,30 @@ extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shi
 }
 
 extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                                  long long npix, int C, float* sums, int dtype, void* stream) {
+                                  const float* mask_scale, const float* mask_shift, long long npix, int C, float* sums, int dtype,
+                                  void* stream) {
     if (!dy || !x || !mean || !invstd || !sums || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
+    if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
     if (256 % (C / V)) return GDRN_ERR_SHAPE;
     const int rpp = 256 / (C / V);
-    int rpb = rpp * 16;
+    int rpb = rpp * 4;  // >= 4 rows per thread, as many workgroups as that allows (small layers were latency-bound at 64)
     long long blocks = (npix + rpb - 1) / rpb;
-    if (blocks > 2048) { rpb = (int)(((npix + 2047) / 2048 + rpp - 1) / rpp * rpp); blocks = (npix + rpb - 1) / rpb; }
+    if (blocks > 1024) { rpb = (int)(((npix + 1023) / 1024 + rpp - 1) / rpp * rpp); blocks = (npix + rpb - 1) / rpb; }
     DISPATCH(dtype,
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, ST, (const float*)dy,
-                                (const float*)ymask, (const float*)x, mean, invstd, npix, C, sums, rpb),
+                                (const float*)ymask, (const float*)x, mean, invstd, mask_scale, mask_shift, npix, C, sums, rpb),
              hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, ST, (const bf16_t*)dy,
-                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, npix, C, sums, rpb));
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, mask_scale, mask_shift, npix, C, sums, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
 extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                                 const float* gamma, const float* sums, long long npix, int C, void* dx, void* g_out,
-                                 float* dgamma, float* dbeta, int dtype, void* stream) {
+                                 const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
+                                 long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
+    if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
     const float inv_n = (float)(1.0 / (double)npix);
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
     if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
@@ -624,10 +659,10 @@ extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* 
     ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
              hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
-                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, npix, C, inv_n,
+                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, mask_scale, mask_shift, npix, C, inv_n,
                                 (float*)dx, (float*)g_out, dgamma, dbeta, rpb),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
-                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, npix, C, inv_n,
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, mask_scale, mask_shift, npix, C, inv_n,
                                 (bf16_t*)dx, (bf16_t*)g_out, dgamma, dbeta, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

@@ -20,6 +20,7 @@ import torch
 from . import cabi
 from .cabi import BF16, F32, ConvParams, PoseParams, WgradParams, check, ptr
 
+BN_SUM_COPIES = 16  # GDRN_BN_SUM_COPIES of include/gdrn_hip.h
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
 HEAD_CONVS = ((3, 4, False), (6, 7, False), (10, 11, True), (13, 14, False), (17, 18, True), (20, 21, False))
@@ -160,7 +161,7 @@ class Engine:
             tot += _ru(int(math.prod(L.dwp_shape)), 4)
         # tail: the BN backward per-channel sums of a plan -- accumulated with atomics like the packed weight gradients,
         # so one fill per backward pass clears both
-        self.bn_sums_cap = 65536
+        self.bn_sums_cap = 1 << 20
         self.dwp_flat = torch.zeros(tot + self.bn_sums_cap, dtype=torch.float32, device=self.dev)
         self.bn_sums_flat = self.dwp_flat[tot:]
         for L in self.layers.values():
@@ -372,7 +373,7 @@ class Plan:
         e, lib = self.e, self.e.lib
         s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
                scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32),
-               sums=self._bn_sums(2 * C_), C=C_, npix=npix)
+               sums=self._bn_sums(2 * C_ * BN_SUM_COPIES), C=C_, npix=npix)
         self.bn[bnkey] = s
         g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
         rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
@@ -390,16 +391,20 @@ class Plan:
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
 
-    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None):
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False):
+        """affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
+        evaluated) instead of reading the stored activation `ymask` -- one tensor pass less in both kernels."""
         e, lib = self.e, self.e.lib
         s = self.bn[bnkey]
         g = e.P[bnkey + ".weight"]
         dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
+        msc, msh = (ptr(s.scale), ptr(s.shift)) if affine_mask else (None, None)
+        ym = None if affine_mask else ptr(ymask)
         return [
-            lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ptr(ymask), ptr(raw), ptr(s.mean), ptr(s.invstd), s.npix, s.C,
+            lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ym, ptr(raw), ptr(s.mean), ptr(s.invstd), msc, msh, s.npix, s.C,
                                                          ptr(s.sums), e.dt, st), "bn_bwd_reduce"),
-            lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ptr(ymask), ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g),
-                                                        ptr(s.sums), s.npix, s.C, ptr(dx), ptr(g_out), ptr(dg), ptr(db), e.dt, st),
+            lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ym, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g),
+                                                        ptr(s.sums), msc, msh, s.npix, s.C, ptr(dx), ptr(g_out), ptr(dg), ptr(db), e.dt, st),
                                   "bn_bwd_apply"),
         ]
 
@@ -586,7 +591,7 @@ class Plan:
                     grp.append(self._unpack(L2))
                     op, _ = self._conv(L2, d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl)
                     grp.append(op)
-                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1)
+                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True)
                     grp.append(self._wgrad(L1, x, d_raw1, Hc, Hc, Ho, Ho, stride, 1, inpl, pl, inpl, pl))
                     grp.append(self._unpack(L1))
                     need_dx = d_x is not None
@@ -618,7 +623,7 @@ class Plan:
         self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
         if T:
             d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
-            grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt)
+            grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt, affine_mask=True)
             # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
             grp.append(self._wgrad(LT, d_rawt, feat, 16, 16, 8, 8, 2, 1, 256, 512, 256, 512))
             grp.append(self._unpack(LT))
@@ -647,7 +652,7 @@ class Plan:
             self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
             if T:
                 d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
-                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw)
+                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True)
                 grp.append(self._wgrad(Lc, xin, d_raw, Hh, Hh, Hh, Hh, 1, 1, 256, 256, 256, 256))
                 grp.append(self._unpack(Lc))
                 op, _ = self._conv(Lc, d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256)

@@ -152,14 +152,19 @@ int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* runn
                         float eps, int C, float* scale, float* shift, void* stream);
 int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                   long long npix, int C, int relu, int dtype, void* stream);
-/* sums[0][c] += sum g, sums[1][c] += sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy).  ACCUMULATES with
- * atomics: the caller clears sums[2*C] first (the engine clears all layers' sums with one fill per backward pass) */
+/* sums[r][0][c] += sum g, sums[r][1][c] += sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy), spread over
+ * r < GDRN_BN_SUM_COPIES copies (same-address atomics are slow; gdrn_bn_bwd_apply adds the copies up).  ACCUMULATES with
+ * atomics: the caller clears sums[GDRN_BN_SUM_COPIES*2*C] first (the engine: one fill per backward pass for all layers) */
+#define GDRN_BN_SUM_COPIES 16
+/* mask_scale/mask_shift (both or neither): the ReLU mask is recomputed as (x*mask_scale + mask_shift > 0), i.e. from
+ * the forward affine of a BN->ReLU without residual, instead of reading the stored activation (one tensor pass less) */
 int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                       long long npix, int C, float* sums, int dtype, void* stream);
+                       const float* mask_scale, const float* mask_shift, long long npix, int C, float* sums, int dtype,
+                       void* stream);
 /* dx = gamma*invstd*(g - sums0/n - xhat*sums1/n); optional g_out = g; dgamma = sums1, dbeta = sums0 */
 int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                      const float* gamma, const float* sums, long long npix, int C, void* dx, void* g_out,
-                      float* dgamma, float* dbeta, int dtype, void* stream);
+                      const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
+                      long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream);
 int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
                              int N, int H, int W, int C, int dtype, void* stream);
 int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale, const float* shift,

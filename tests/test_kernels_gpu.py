@@ -313,12 +313,12 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), ptr(resd), ptr(y), npix, C_, 1, dt, st), "bn_apply")
     assert H.rel(H.nchw(y), yref) < TOL[dt]
     assert H.rel(rmd, rm) < 1e-5 and H.rel(rvd, rv) < 1e-5 and int(nbt) == 1
-    sums = torch.zeros(2 * C_, device=dev)
+    sums = torch.zeros(16 * 2 * C_, device=dev)  # GDRN_BN_SUM_COPIES
     dx, gout = torch.empty_like(xd), torch.empty_like(xd)
     dg, db = mk(), mk()
     yd = H.nhwc(yref.detach(), dt)  # mask source: the stored activation
-    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), npix, C_, ptr(sums), dt, st), "bn_bwd_reduce")
-    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), npix, C_, ptr(dx),
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), None, None, npix, C_, ptr(sums), dt, st), "bn_bwd_reduce")
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), None, None, npix, C_, ptr(dx),
                                 ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
     tol = 2e-4 if dt == F32 else 1e-2
     assert H.rel(H.nchw(dx), x.grad) < tol
@@ -328,6 +328,41 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     check(lib.gdrn_bn_eval_params(ptr(gam_d), ptr(bet_d), ptr(rmd), ptr(rvd), 1e-5, C_, ptr(scale), ptr(shift), st), "bn_eval")
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), None, ptr(y), npix, C_, 0, dt, st), "bn_apply")
     assert H.rel(H.nchw(y), F.batch_norm(x.detach(), rm, rv, gam.detach(), bet.detach(), False, 0.1, 1e-5)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C_,B,Hh", [(64, 3, 12), (512, 2, 8), (256, 5, 16)])
+def test_batchnorm_bwd_affine_mask(H, dt, C_, B, Hh):
+    """BN -> ReLU (no residual) backward with the ReLU mask recomputed from x*scale+shift == autograd."""
+    lib = cabi.load()
+    dev = H.DEV
+    x = H.rounded(H.randn(150, B, C_, Hh, Hh) * 2 + 0.5, dt).requires_grad_(True)
+    gam = (0.5 + torch.rand(C_, generator=torch.Generator().manual_seed(1))).requires_grad_(True)
+    bet = (torch.rand(C_, generator=torch.Generator().manual_seed(2)) - 0.5).requires_grad_(True)
+    yref = F.relu(F.batch_norm(x, None, None, gam, bet, True, 0.1, 1e-5))
+    dy = H.rounded(H.randn(152, B, C_, Hh, Hh), dt)
+    yref.backward(dy)
+    npix = B * Hh * Hh
+    xd, dyd = H.nhwc(x.detach(), dt), H.nhwc(dy, dt)
+    xf = xd.float().view(npix, C_)
+    part = torch.stack([xf.sum(0), (xf ** 2).sum(0)]).unsqueeze(0).contiguous()
+    mk = lambda: torch.zeros(C_, device=dev)
+    mean, invstd, scale, shift, dg, db = mk(), mk(), mk(), mk(), mk(), mk()
+    gam_d, bet_d = gam.detach().to(dev), bet.detach().to(dev)
+    st = H.stream()
+    check(lib.gdrn_bn_finalize(ptr(part), 1, C_, float(npix), ptr(gam_d), ptr(bet_d), None, None, None, 0.1, 1e-5, ptr(mean),
+                               ptr(invstd), ptr(scale), ptr(shift), None, st), "bn_finalize")
+    sums = torch.zeros(16 * 2 * C_, device=dev)  # GDRN_BN_SUM_COPIES
+    dx, gout = torch.empty_like(xd), torch.empty_like(xd)
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), None, ptr(xd), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), npix, C_, ptr(sums), dt, st),
+          "bn_bwd_reduce")
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), None, ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), ptr(scale), ptr(shift), npix, C_,
+                                ptr(dx), ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
+    torch.cuda.synchronize()
+    tol = 2e-4 if dt == F32 else 1e-2
+    assert H.rel(H.nchw(dx), x.grad) < tol
+    assert H.rel(dg, gam.grad) < tol and H.rel(db, bet.grad) < tol
+    assert H.rel(H.nchw(gout), dy * (yref > 0)) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)
