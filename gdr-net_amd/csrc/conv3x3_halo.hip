@@ -18,6 +18,7 @@
 // MFMA: v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32, weights = A operand, pixels = B operand, so a
 // lane ends with 4 consecutive output channels of one pixel (8/16-byte stores).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "../../include/gdrn_hip.h"
@@ -316,6 +317,13 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     *th = 8;
     *tw = (p->Wo % 16 == 0) ? 16 : 8;
     *bn = p->Cout <= 64 ? 64 : 128;
+    // small feature maps: a 128-channel tiling leaves one workgroup (one wave per SIMD) per CU; halve the channel tile
+    // when that grid is below `min_wg` workgroups (measured: no gain at bs=64, so off unless GDRN_HALO_MIN_WG is set)
+    static const int min_wg = [] { const char* e = getenv("GDRN_HALO_MIN_WG"); return e ? atoi(e) : 0; }();
+    if (*bn == 128 && p->M > 0) {
+        const long long wg = (long long)(p->M / (*th * *tw)) * cdiv(p->Cout, 128);
+        if (wg < min_wg) *bn = 64;
+    }
     return GDRN_OK;
 }
 

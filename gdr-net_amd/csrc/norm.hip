@@ -165,6 +165,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 s2[j] += gg * (xv[j] - mu[j]) * is[j];
             }
         }
+    }
+    // lanes of a wave that share a channel vector (lane % tpr) are combined with shuffles; one LDS atomic per wave/channel
+    const int lane = threadIdx.x & 63;
+    for (int o = tpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (rl < rpp && (tpr >= 64 || lane < tpr)) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             atomicAdd(&acc[cv * V + j], s1[j]);
@@ -596,7 +604,7 @@ extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double co
                                 float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream) {
     if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0) return GDRN_ERR_ARG;
     int S = 1;  // row slices: ~4 rows per thread, only with a workspace
-    if (ws != nullptr) S = std::max(1, std::min(64, rows / 64));
+    if (ws != nullptr) S = std::max(1, std::min(64, rows / 128));  // <= 8 rows per thread; few rows: no ticket round at all
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16), S), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
                        running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, ws);
     GDRN_CHECK_LAUNCH();
