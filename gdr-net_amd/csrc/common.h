@@ -26,14 +26,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction per PAIR; the
+// integer-arithmetic version cost ~7 VALU instructions per element in every bf16-writing epilogue)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    typedef float f32x2_cvt_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_cvt_t __attribute__((ext_vector_type(2)));
+    const f32x2_cvt_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_cvt_t));
 }
 
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 // 16-byte vector access of VEC elements of T as floats.
 template <typename T>
