@@ -64,15 +64,6 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ s
     }
 }
 
-// sum over the 16 lanes of a DPP row (every lane gets the total): quad xor 1, quad xor 2, half-row mirror, row mirror
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-    return v;
-}
-
 template <typename T, int TH, int TW, int BN>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);

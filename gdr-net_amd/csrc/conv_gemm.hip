@@ -250,11 +250,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const gdrn_conv_param
         for (int a = 0; a < FN; ++a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s1 = 0.f, s2 = 0.f;
+                float s1, s2;
+                if constexpr (sizeof(T) == 4) {
+                    // parity (fp32) mode: the per-tile sums in fp64 -- the pose error against the reference sits at the
+                    // fp32 summation-order noise floor (~1e-4 after the ~1600x amplification through BN at B=4), so the
+                    // statistics should not add their own rounding to it
+                    double d1 = 0.0, d2 = 0.0;
 #pragma unroll
-                for (int b = 0; b < FM; ++b) { const float v = acc[a][b][j]; s1 += v; s2 += v * v; }
+                    for (int b = 0; b < FM; ++b) { const double v = (double)acc[a][b][j]; d1 += v; d2 += v * v; }
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                    for (int o = 8; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+                    s1 = (float)d1;
+                    s2 = (float)d2;
+                } else {
+                    s1 = 0.f;
+                    s2 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) { const float v = acc[a][b][j]; s1 += v; s2 += v * v; }
+                    s1 = row16_sum(s1);
+                    s2 = row16_sum(s2);
+                }
                 if (r16 == 0) {
                     const int c = wn * WN + a * 16 + g * 4 + j;
                     red[(wm * BN + c) * 2 + 0] = s1;
@@ -271,6 +286,46 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const gdrn_conv_param
         }
     }
 
+    // Fast path (full channel tile, storage-dtype output, no bias / activation; optional addend): straight-line stores
+    // with 32-bit offsets.  The generic code below is ~2000-3500 instructions with 200-400 branches per wave, which
+    // exceeds the MFMA loop of the short-K layers (1x1 convs, stride-2 convs of the small feature maps).
+    if (p.bias == nullptr && p.act == 0 && (!p.out_f32 || sizeof(T) == 4) && co0 + BN <= p.Cout) {
+        const char* ab = reinterpret_cast<const char*>(p.addend);
+        char* yb = reinterpret_cast<char*>(p.y);
+        const unsigned cl = (unsigned)(co0 + wn * WN + g * 4);
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int r = row0 + wm * WM + b * 16 + r16;
+            if (r >= Mrows) continue;
+            unsigned orow;
+            if (p.mode == 1) {
+                const int n = r / (Hc * Wc);
+                const int rem = r - n * (Hc * Wc);
+                const int yc = rem / Wc, xc = rem - yc * Wc;
+                orow = (unsigned)((n * p.Ho + 2 * yc + py) * p.Wo + 2 * xc + px);
+            } else {
+                orow = (unsigned)r;
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
+                const unsigned c = cl + a * 16;
+                if (ab != nullptr) {
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(ab + ((size_t)orow * p.add_cs + c) * 2);
+                        v0 += __uint_as_float(q.x << 16); v1 += __uint_as_float(q.x & 0xffff0000u);
+                        v2 += __uint_as_float(q.y << 16); v3 += __uint_as_float(q.y & 0xffff0000u);
+                    } else {
+                        const float4 q = *reinterpret_cast<const float4*>(ab + ((size_t)orow * p.add_cs + c) * 4);
+                        v0 += q.x; v1 += q.y; v2 += q.z; v3 += q.w;
+                    }
+                }
+                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(yb + ((size_t)orow * p.y_cs + c) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                else *reinterpret_cast<float4*>(yb + ((size_t)orow * p.y_cs + c) * 4) = make_float4(v0, v1, v2, v3);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
         const int r = row0 + wm * WM + b * 16 + r16;
