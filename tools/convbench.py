@@ -5,7 +5,7 @@ import time
 
 import torch
 
-R = os.path.dirname(os.path.abspath(__file__))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 sys.path.insert(0, os.path.join(R, "tests"))
 import hiputil as H  # noqa: E402
