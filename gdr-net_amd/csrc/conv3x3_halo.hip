@@ -26,7 +26,14 @@
 namespace {
 
 constexpr int ROWB = 128;   // bytes of K per stage row
-constexpr int PITCH = 144;  // LDS pixel pitch
+// LDS patch layout: the eight 16-byte channel granules of a pixel's 128-byte chunk are split into an EVEN-granule
+// and an ODD-granule array ([pixel][4 granules + 16 B pad], pitch 80 B), the odd array a multiple of 256 B after the
+// even one.  ds_read_b128 services lanes {0-3,12-15} of one k-group together with lanes {4-11} of the NEXT k-group
+// (hardware lane groups); with one [pixel][8 granules] array those two sets collide on 7 of 8 banks whatever the pitch
+// (measured: SQ_LDS_BANK_CONFLICT = 45 % of the LDS cycles).  Even/odd k-groups in bank-aligned arrays make the two
+// sets land on the slots of DIFFERENT pixels -> conflict-free for every tap shift (16-pixel-wide tiles).
+constexpr int PITCH = 80;   // LDS pixel pitch inside one half array
+__host__ __device__ constexpr int half_bytes(int ppix) { return (ppix * PITCH + 255) / 256 * 256; }
 
 template <typename T>
 __device__ __forceinline__ f32x4_t mma_step(uint4 a, uint4 b, f32x4_t c);
@@ -69,7 +76,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     constexpr int EPS = ROWB / (int)sizeof(T);
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
-    constexpr int PBYTES = PPIX * PITCH;
+    constexpr int HB = half_bytes(PPIX);      // odd-granule array offset
+    constexpr int PBYTES = 2 * HB;
     constexpr int PSEG = PPIX * 8;            // 16-byte segments of one patch chunk
     constexpr int PSLICE = (PSEG + 8) / 9;    // segments fetched per tap stage
     static_assert(PSLICE <= 256, "one patch segment per thread per stage");
@@ -117,14 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         const bool ok = inpatch && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
         poff[st] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * (unsigned)sizeof(T) + sg * 16;
-        pdst[st] = inpatch ? (pp * PITCH + sg * 16) : -1;
+        pdst[st] = inpatch ? (pp * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
         pokm |= ok ? (1u << st) : 0u;
     }
 
     // ---- pixel-fragment lane base inside a patch: fragment b, lane column r16 -> pixel (oy, ox)
     int lbase;
-    if constexpr (TW == 16) lbase = r16 * PITCH + g * 16;                             // oy = b, ox = r16
-    else lbase = ((r16 >> 3) * PW + (r16 & 7)) * PITCH + g * 16;                      // oy = 2b + (r16>>3)
+    if constexpr (TW == 16) lbase = r16 * PITCH + (g & 1) * HB + (g >> 1) * 16;                        // oy = b, ox = r16
+    else lbase = ((r16 >> 3) * PW + (r16 & 7)) * PITCH + (g & 1) * HB + (g >> 1) * 16;             // oy = 2b + (r16>>3)
     constexpr int FROW = (TW == 16) ? PW * PITCH : 2 * PW * PITCH;                    // byte step per fragment b
 
     f32x4_t acc[FN][FM];
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                   \
             uint4 fb_[FM];                                                                                      \
             _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                                   \
-                fb_[b_] = *reinterpret_cast<const uint4*>(pcur + (b_ * FROW + tsh_ + ks_ * 64));               \
+                fb_[b_] = *reinterpret_cast<const uint4*>(pcur + (b_ * FROW + tsh_ + ks_ * 32));               \
             _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
                 _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) {                                             \
                     if constexpr (sizeof(T) == 4) part[a_][b_] = mma_step<T>(WQ_[a_ * 2 + ks_], fb_[b_], part[a_][b_]); \
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 
 template <typename T, int TH, int TW, int BN>
 int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
-    constexpr size_t smem = 2 * (size_t)(TH + 2) * (TW + 2) * PITCH;
+    constexpr size_t smem = 2 * 2 * (size_t)half_bytes((TH + 2) * (TW + 2));
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN>),

@@ -263,3 +263,45 @@ def test_full_size_properties_bs64():
     _, L2 = model(pb["roi_img"], **synth.model_kwargs(pb, do_loss=True))
     for k in L:
         assert abs(L[k].item() - L2[k].item()) <= 2e-2 * max(abs(L[k].item()), 1e-3), k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_train_step_graph_replay_equals_eager(dtype, monkeypatch):
+    """train_step through the captured hipGraph (third call onwards) == train_step issued launch by launch:
+    same losses step by step and the same parameters after 6 Ranger steps (up to the fp32-atomics ordering noise)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 4
+    batches = [to_dev(synth.make_batch(B, seed=11 + i)) for i in range(3)]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GDRN_GRAPH", mode)
+        model, opt = build(dtype)
+        model.train()
+        losses = []
+        for it in range(6):
+            b = batches[it % 3]  # new tensors every call: the graph path must restage them
+            kw = synth.model_kwargs(b, do_loss=True)
+            kw.pop("do_loss")
+            losses.append(model.train_step(b["roi_img"], optimizer=opt, **kw).clone())
+        torch.cuda.synchronize()
+        st = getattr(model, "_graph_state", {}).get(B)
+        assert (st is not None and st["graph"] is not None and st["ok"]) == (mode == "1")
+        if mode == "1":
+            # the replay must see the CURRENT weights (operand repack inside the graph) and the CURRENT inputs: its
+            # forward is deterministic, so the losses equal an eager forward on the same batch bit for bit (almost)
+            from gdrnet_amd.engine import LOSS_NAMES
+
+            kw = synth.model_kwargs(batches[1], do_loss=True)
+            kw.pop("do_loss")
+            lg = model.train_step(batches[1]["roi_img"], optimizer=None, **kw).clone()
+            _, ld = model(batches[1]["roi_img"], **synth.model_kwargs(batches[1], do_loss=True))
+            le = torch.stack([ld[k].detach() for k in LOSS_NAMES])
+            torch.testing.assert_close(lg, le, rtol=1e-5, atol=1e-7)
+        runs[mode] = (torch.stack(losses).cpu(), {n: p.detach().cpu().clone() for n, p in model.named_parameters()})
+    l0, l1 = runs["0"][0], runs["1"][0]
+    assert torch.isfinite(l1).all()
+    # the two trajectories drift apart through the fp32-atomics ordering noise (x1600 through BN at B=4, compounded over
+    # the updates): 1e-2 after six steps in fp32; bf16 pose losses decorrelate after an update (test_bf16_train_step_*)
+    tol = 1e-2 if dtype == "fp32" else 0.3
+    assert ((l0 - l1).abs() / (l0.abs() + 1e-3)).max() < tol, (l0, l1)
