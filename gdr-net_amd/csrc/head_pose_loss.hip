@@ -11,28 +11,50 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ head tail fwd
-// one wave per pixel: lane j <-> region class j+1
+// 16 lanes per pixel (one DPP row), 4 pixels per wave: lane q holds classes q, q+16, ... -- contiguous 64-byte loads,
+// row reductions in 4 DPP adds.  (The first version used one wave per pixel with 6-step cross-lane reductions and ran
+// at ~0.5 TB/s.)
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restrict__ head, int hs,
                                                             const float* __restrict__ coord2d,
                                                             const float* __restrict__ extents, T* __restrict__ pnp, int pcs,
                                                             int N, int HW, int nreg) {
-    const int lane = threadIdx.x & 63;
+    const int q = threadIdx.x & 15;
     const long long M = (long long)N * HW;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long m = wave0; m < M; m += nwaves) {
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    for (long long m = g0; m < M; m += ng) {
         const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
         const float* h = head + m * hs;
-        const float r = (lane < nreg) ? h[5 + lane] : -INFINITY;
-        const float mx = wave_max(r);
-        const float e = (lane < nreg) ? expf(r - mx) : 0.f;
-        const float s = wave_sum(e);
+        float r[4], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = (q + 16 * j < nreg) ? h[5 + q + 16 * j] : -INFINITY;
+            mx = fmaxf(mx, r[j]);
+        }
+        mx = row16_max(mx);
+        float e[4], se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            e[j] = (q + 16 * j < nreg) ? expf(r[j] - mx) : 0.f;
+            se += e[j];
+        }
+        se = row16_sum(se);
         T* o = pnp + m * pcs;
-        if (lane < nreg) st1<T>(o + 5 + lane, e / s);
-        if (lane < 3) st1<T>(o + lane, (h[1 + lane] - 0.5f) * extents[n * 3 + lane]);
-        else if (lane < 5) st1<T>(o + lane, coord2d[((size_t)n * 2 + (lane - 3)) * HW + pix]);
-        for (int c = 5 + nreg + lane; c < pcs; c += 64) st1<T>(o + c, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q + 16 * j < nreg) st1<T>(o + 5 + q + 16 * j, e[j] / se);
+        if (q < 3) st1<T>(o + q, (h[1 + q] - 0.5f) * extents[n * 3 + q]);
+        else if (q < 5) st1<T>(o + q, coord2d[((size_t)n * 2 + (q - 3)) * HW + pix]);
+        for (int c = 5 + nreg + q; c < pcs; c += 16) st1<T>(o + c, 0.f);
     }
 }
 
@@ -42,31 +64,35 @@ __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restri
                                                            const float* __restrict__ mvis, const float* __restrict__ mtr,
                                                            const long long* __restrict__ gt_region, int N, int HW, int nreg,
                                                            double* acc) {
-    __shared__ float red[6][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float red[6][16];
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long long M = (long long)N * HW;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // lane-0 accumulators
-    for (long long m = wave0; m < M; m += nwaves) {
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    const int ncls = nreg + 1;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // accumulators of lane q == 0 of each pixel group
+    for (long long m = g0; m < M; m += ng) {
         const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
         const float* h = head + m * hs;
         const float mv = mvis[m];
-        // CE over nreg+1 classes of logits region*mv; lane j <-> class j, lane 0 also class 64 (if nreg == 64)
-        const int ncls = nreg + 1;
-        const float z0 = (lane < ncls) ? h[4 + lane] * mv : -INFINITY;
-        const float z1 = (lane + 64 < ncls) ? h[4 + 64 + lane] * mv : -INFINITY;
-        const float mx = wave_max(fmaxf(z0, z1));
-        float e = 0.f;
-        if (lane < ncls) e += expf(z0 - mx);
-        if (lane + 64 < ncls) e += expf(z1 - mx);
-        const float se = wave_sum(e);
+        // CE over nreg+1 classes of logits region*mv; lane q <-> classes q + 16 j
         const int tgt = (int)(gt_region[m] * (long long)mv);
-        float zt = 0.f;
-        if (tgt == lane) zt = z0;
-        if (tgt == lane + 64) zt = z1;
-        zt = wave_sum(zt);
-        if (lane == 0) {
+        float z[5], mx = -INFINITY, zt = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = q + 16 * j;
+            z[j] = (k < ncls) ? h[4 + k] * mv : -INFINITY;
+            mx = fmaxf(mx, z[j]);
+            if (k == tgt) zt = z[j];
+        }
+        mx = row16_max(mx);
+        float e = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (q + 16 * j < ncls) e += expf(z[j] - mx);
+        const float se = row16_sum(e);
+        zt = row16_sum(zt);
+        if (q == 0) {
             a[4] += (logf(se) + mx) - zt;
             a[5] += mv;
             a[3] += fabsf(h[0] - mtr[m]);
@@ -74,12 +100,14 @@ __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restri
             for (int c = 0; c < 3; ++c) a[c] += fabsf(h[1 + c] * mv - gt_xyz[((size_t)n * 3 + c) * HW + pix] * mv);
         }
     }
-    if (lane == 0)
+    if (q == 0)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) red[k][wave] = a[k];
+        for (int k = 0; k < 6; ++k) red[k][grp] = a[k];
     __syncthreads();
     if (threadIdx.x < 6) {
-        const double v = (double)red[threadIdx.x][0] + (double)red[threadIdx.x][1] + (double)red[threadIdx.x][2] + (double)red[threadIdx.x][3];
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += (double)red[threadIdx.x][i];
         unsafeAtomicAdd(&acc[threadIdx.x], v);
     }
 }
@@ -107,54 +135,64 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restr
                                                             const long long* __restrict__ gt_region,
                                                             const double* __restrict__ acc, const float* __restrict__ gw,
                                                             T* __restrict__ dhead, int dcs, int N, int HW, int nreg) {
-    const int lane = threadIdx.x & 63;
+    const int q = threadIdx.x & 15;  // 16 lanes per pixel, lane q <-> classes q + 16 j
     const long long M = (long long)N * HW;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
     const float inv_den = (float)(1.0 / (acc[5] < 1.0 ? 1.0 : acc[5]));
     const float inv_np = (float)(1.0 / (double)M);
     const float gx[3] = {gw[0], gw[1], gw[2]};
     const float gmask = gw[3], gce = gw[4];
     const int ncls = nreg + 1;
-    for (long long m = wave0; m < M; m += nwaves) {
+    for (long long m = g0; m < M; m += ng) {
         const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
         const float* h = head + m * hs;
         const float mv = mvis[m];
-        // CE gradient: mv * (softmax(region*mv)_k - onehot_k) / den
-        const float z0 = (lane < ncls) ? h[4 + lane] * mv : -INFINITY;
-        const float z1 = (lane + 64 < ncls) ? h[4 + 64 + lane] * mv : -INFINITY;
-        const float mx = wave_max(fmaxf(z0, z1));
-        const float e0 = (lane < ncls) ? expf(z0 - mx) : 0.f;
-        const float e1 = (lane + 64 < ncls) ? expf(z1 - mx) : 0.f;
-        const float se = wave_sum(e0 + e1);
         const int tgt = (int)(gt_region[m] * (long long)mv);
-        float d0 = gce * mv * inv_den * (e0 / se - (tgt == lane ? 1.f : 0.f));        // class lane
-        float d1 = gce * mv * inv_den * (e1 / se - (tgt == lane + 64 ? 1.f : 0.f));   // class lane+64
-        // attention softmax chain: region class j+1 <- pnp channel 5+j
-        float dsm = 0.f;
-        if (dpnp != nullptr) {
-            const float s = (lane < nreg) ? ld1<T>(pnp + m * pcs + 5 + lane) : 0.f;
-            const float ds = (lane < nreg) ? ld1<T>(dpnp + m * pcs + 5 + lane) : 0.f;
-            const float dot = wave_sum(s * ds);
-            dsm = s * (ds - dot);  // gradient for class lane+1
+        // CE gradient: mv * (softmax(region*mv)_k - onehot_k) / den
+        float z[5], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = q + 16 * j;
+            z[j] = (k < ncls) ? h[4 + k] * mv : -INFINITY;
+            mx = fmaxf(mx, z[j]);
         }
-        // shift dsm from "lane j <-> class j+1" to "lane j <-> class j": class k takes dsm of lane k-1
-        float dsm_k = __shfl_up(dsm, 1, 64);
-        if (lane == 0) dsm_k = 0.f;
-        const float dsm_64 = __shfl(dsm, 63, 64);  // class 64 <- lane 63
+        mx = row16_max(mx);
+        float e[5], se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            e[j] = (q + 16 * j < ncls) ? expf(z[j] - mx) : 0.f;
+            se += e[j];
+        }
+        se = row16_sum(se);
+        // attention softmax chain: region class k (>= 1) <- pnp channel 4 + k
+        float sk[5], dk[5], dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = q + 16 * j;
+            const bool on = dpnp != nullptr && k >= 1 && k <= nreg;
+            sk[j] = on ? ld1<T>(pnp + m * pcs + 4 + k) : 0.f;
+            dk[j] = on ? ld1<T>(dpnp + m * pcs + 4 + k) : 0.f;
+            dot += sk[j] * dk[j];
+        }
+        dot = row16_sum(dot);
         T* o = dhead + m * dcs;
-        if (lane < ncls) st1<T>(o + 4 + lane, d0 + dsm_k);
-        if (lane + 64 < ncls) st1<T>(o + 4 + 64 + lane, d1 + dsm_64);
-        if (lane == 0) {
+        const float cs = gce * mv * inv_den;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = q + 16 * j;
+            if (k < ncls) st1<T>(o + 4 + k, cs * (e[j] / se - (tgt == k ? 1.f : 0.f)) + sk[j] * (dk[j] - dot));
+        }
+        if (q == 0) {
             st1<T>(o + 0, gmask * inv_np * sgn(h[0] - mtr[m]));
-        } else if (lane < 4) {
-            const int c = lane - 1;
+        } else if (q < 4) {
+            const int c = q - 1;
             const float gt = gt_xyz[((size_t)n * 3 + c) * HW + pix];
             float d = gx[c] * mv * inv_den * sgn(h[1 + c] * mv - gt * mv);
             if (dpnp != nullptr) d += ld1<T>(dpnp + m * pcs + c) * extents[n * 3 + c];
-            st1<T>(o + lane, d);
+            st1<T>(o + q, d);
         }
-        for (int c = 4 + ncls + lane; c < dcs; c += 64) st1<T>(o + c, 0.f);
+        for (int c = 4 + ncls + q; c < dcs; c += 16) st1<T>(o + c, 0.f);
     }
 }
 
@@ -400,7 +438,7 @@ extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2
         pcs < nreg + 5)
         return GDRN_ERR_ARG;
     const long long M = (long long)N * HW;
-    const int blocks = (int)std::min<long long>((M + 3) / 4, 4096);
+    const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
     if (dtype == GDRN_DT_F32)
         hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
     else if (dtype == GDRN_DT_BF16)
@@ -417,7 +455,7 @@ extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz,
         return GDRN_ERR_ARG;
     if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     const long long M = (long long)N * HW;
-    const int blocks = (int)std::min<long long>((M + 3) / 4, 2048);
+    const int blocks = (int)std::min<long long>((M + 15) / 16, 2048);
     hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -439,7 +477,7 @@ extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in,
         return GDRN_ERR_ARG;
     if (d_pnp_in != nullptr && pnp_in == nullptr) return GDRN_ERR_ARG;
     const long long M = (long long)N * HW;
-    const int blocks = (int)std::min<long long>((M + 3) / 4, 4096);
+    const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
     if (dtype == GDRN_DT_F32)
         hipLaunchKernelGGL(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
                            (const float*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
