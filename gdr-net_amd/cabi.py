@@ -24,6 +24,8 @@ class GdrnHipError(RuntimeError):
 class ConvParams(C.Structure):
     _fields_ = [
         ("x", P), ("w", P), ("y", P), ("bias", P), ("addend", P), ("stats", P),
+        ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_scale", P), ("bnb_shift", P), ("bnb_sums", P),
+        ("bnb_cs", I), ("pad0_", I),
         ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("add_cs", I),
         ("KH", I), ("KW", I), ("stride", I), ("pad", I),

@@ -17,6 +17,8 @@
 //   * hence NO barrier inside a channel chunk: one __syncthreads per 9 taps (patch double buffer swap).
 // MFMA: v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32, weights = A operand, pixels = B operand, so a
 // lane ends with 4 consecutive output channels of one pixel (8/16-byte stores).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -263,6 +265,72 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
             const int pstep = (TW == 16 ? 1 : 2) * p.Wo;  // pixel-row step per fragment b
             char* yb = reinterpret_cast<char*>(p.y);
             const char* ab = reinterpret_cast<const char*>(p.addend);
+            if (p.bnb_x != nullptr) {
+                // data gradient feeding a BatchNorm(+ReLU) backward: ReLU mask + the two per-channel sums of that
+                // backward here, on the accumulators, instead of a separate pass over (dy, x, mask)
+                const char* xb = reinterpret_cast<const char*>(p.bnb_x);
+                const char* mb = reinterpret_cast<const char*>(p.bnb_mask);
+                const bool affine = mb == nullptr && p.bnb_scale != nullptr;
+                float kmu[FN][4], kis[FN][4], ksc[FN][4], ksh[FN][4], t1[FN][4], t2[FN][4];
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 16);
+                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 16);
+                    kmu[a][0] = mu.x; kmu[a][1] = mu.y; kmu[a][2] = mu.z; kmu[a][3] = mu.w;
+                    kis[a][0] = is.x; kis[a][1] = is.y; kis[a][2] = is.z; kis[a][3] = is.w;
+                    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(1.f, 1.f, 1.f, 1.f);  // mask always true
+                    if (affine) {
+                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 16);
+                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 16);
+                    }
+                    ksc[a][0] = sc.x; ksc[a][1] = sc.y; ksc[a][2] = sc.z; ksc[a][3] = sc.w;
+                    ksh[a][0] = sh.x; ksh[a][1] = sh.y; ksh[a][2] = sh.z; ksh[a][3] = sh.w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t1[a][j] = 0.f; t2[a][j] = 0.f; }
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const unsigned pr = (unsigned)(prow0 + b * pstep);
+                    uint2 av[FN], xq[FN], mq[FN];
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        xq[a] = *reinterpret_cast<const uint2*>(xb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
+                        av[a] = ab ? *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u) : make_uint2(0u, 0u);
+                        mq[a] = mb ? *reinterpret_cast<const uint2*>(mb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u) : make_uint2(0x3f803f80u, 0x3f803f80u);
+                    }
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        const float xv[4] = {__uint_as_float(xq[a].x << 16), __uint_as_float(xq[a].x & 0xffff0000u),
+                                             __uint_as_float(xq[a].y << 16), __uint_as_float(xq[a].y & 0xffff0000u)};
+                        const float mv[4] = {__uint_as_float(mq[a].x << 16), __uint_as_float(mq[a].x & 0xffff0000u),
+                                             __uint_as_float(mq[a].y << 16), __uint_as_float(mq[a].y & 0xffff0000u)};
+                        const float ad[4] = {__uint_as_float(av[a].x << 16), __uint_as_float(av[a].x & 0xffff0000u),
+                                             __uint_as_float(av[a].y << 16), __uint_as_float(av[a].y & 0xffff0000u)};
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float gv = acc[a][b][j] + ad[j];
+                            if (!(mv[j] > 0.f) || !(xv[j] * ksc[a][j] + ksh[a][j] > 0.f)) gv = 0.f;
+                            v[j] = gv;
+                            t1[a][j] += gv;
+                            t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
+                        }
+                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                }
+                float* sdst = p.bnb_sums + (size_t)(blockIdx.x % GDRN_BN_SUM_COPIES) * 2 * p.Cout + cl;
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u1 = row16_sum(t1[a][j]), u2 = row16_sum(t2[a][j]);
+                        if (r16 == 0) {
+                            unsafeAtomicAdd(sdst + a * 16 + j, u1);
+                            unsafeAtomicAdd(sdst + p.Cout + a * 16 + j, u2);
+                        }
+                    }
+                return;
+            }
             if (ab != nullptr) {
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
@@ -428,6 +496,11 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
+    if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
+        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_sums || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (p.bias || p.act || p.out_f32 || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
+        if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
+    }
     if ((unsigned long long)p.M * (unsigned long long)std::max(p.y_cs, p.add_cs) * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     const int N = p.M / hw;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -50,6 +50,7 @@ class Engine:
         import os as _os
 
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
+        self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "2048"))  # target workgroups of a grouped launch
         self.layers = OrderedDict()
@@ -263,7 +264,10 @@ class Plan:
 
     # ---- op builders -------------------------------------------------------------------------
     def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
-              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None):
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None):
+        """bnb = (bn key, raw input of that BN, stored activation or None, affine mask?): data-gradient launch whose
+        output is the gradient w.r.t. that BatchNorm(+ReLU)'s output -- the halo kernel's epilogue masks it and
+        accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass."""
         e = self.e
         cp = ConvParams()
         cp.x, cp.w, cp.y = ptr(x), ptr(w if w is not None else L.wf), ptr(y)
@@ -287,6 +291,14 @@ class Plan:
             raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
         if use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
+        if bnb is not None:
+            assert use_halo, L.key
+            bkey, braw, bmask, baffine = bnb
+            sb = self.bn[bkey]
+            cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(braw), ptr(bmask), braw.shape[-1]
+            cp.bnb_mean, cp.bnb_invstd, cp.bnb_sums = ptr(sb.mean), ptr(sb.invstd), ptr(sb.sums)
+            if baffine:
+                cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
@@ -391,7 +403,12 @@ class Plan:
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
 
-    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False):
+    def _fusable(self, L):
+        """can the data gradient of layer L run on the halo kernel (and so carry a fused BN-backward reduction)?"""
+        e = self.e
+        return e.fuse_bnb and e.use_halo and e.dt == BF16 and L.kind == "conv" and L.wfF is not None
+
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False):
         """affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
         evaluated) instead of reading the stored activation `ymask` -- one tensor pass less in both kernels."""
         e, lib = self.e, self.e.lib
@@ -400,6 +417,10 @@ class Plan:
         dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
         msc, msh = (ptr(s.scale), ptr(s.shift)) if affine_mask else (None, None)
         ym = None if affine_mask else ptr(ymask)
+        if prereduced:  # dy arrives masked and the sums are complete (fused into the producing data-gradient conv)
+            return [lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), None, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g), ptr(s.sums),
+                                                                None, None, s.npix, s.C, ptr(dx), None, ptr(dg), ptr(db), e.dt, st),
+                                          "bn_bwd_apply")]
         return [
             lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ym, ptr(raw), ptr(s.mean), ptr(s.invstd), msc, msh, s.npix, s.C,
                                                          ptr(s.sums), e.dt, st), "bn_bwd_reduce"),
@@ -585,13 +606,24 @@ class Plan:
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, out, residual=x)
                 if T:
                     d_out = E(B, Ho, Ho, pl)
-                    d_raw2, g2, d_a1, d_raw1 = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
-                    grp = self._bn_bwd(pfx + ".bn2", d_out, out, raw2, d_raw2, g_out=g2)
+                    d_raw2, d_a1, d_raw1 = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                    # d_out comes from the next block's conv1 data gradient when that is a plain (stride-1) block of the
+                    # same layer: its halo epilogue has then already applied this block's output ReLU mask and reduced
+                    # the bn2-backward sums (and d_out itself is the residual-path gradient g2)
+                    pre2 = (b + 1 < nb) and self._fusable(e.layers[f"backbone.layer{li}.{b + 1}.conv1"])
+                    if pre2:
+                        g2 = d_out
+                        grp = self._bn_bwd(pfx + ".bn2", d_out, None, raw2, d_raw2, prereduced=True)
+                    else:
+                        g2 = E(B, Ho, Ho, pl)
+                        grp = self._bn_bwd(pfx + ".bn2", d_out, out, raw2, d_raw2, g_out=g2)
                     grp.append(self._wgrad(L2, a1, d_raw2, Ho, Ho, Ho, Ho, 1, 1, pl, pl, pl, pl))
                     grp.append(self._unpack(L2))
-                    op, _ = self._conv(L2, d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl)
+                    pre1 = self._fusable(L2)
+                    op, _ = self._conv(L2, d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl,
+                                       bnb=(pfx + ".bn1", raw1, None, True) if pre1 else None)
                     grp.append(op)
-                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True)
+                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True, prereduced=pre1)
                     grp.append(self._wgrad(L1, x, d_raw1, Hc, Hc, Ho, Ho, stride, 1, inpl, pl, inpl, pl))
                     grp.append(self._unpack(L1))
                     need_dx = d_x is not None
@@ -606,12 +638,16 @@ class Plan:
                                            cout=inpl, addend=d_xd, add_cs=inpl)
                         grp.append(op)
                     elif need_dx:
+                        # previous block of the same layer: d_x is the gradient w.r.t. its output (mask = x, stored) and
+                        # feeds its bn2 backward (raw input prev_raw2)
+                        fuse_prev = b >= 1 and self._fusable(L1)
                         op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 1, 1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d, cout=inpl,
-                                           addend=g2, add_cs=pl)
+                                           addend=g2, add_cs=pl,
+                                           bnb=(f"backbone.layer{li}.{b - 1}.bn2", prev_raw2, x, False) if fuse_prev else None)
                         grp.append(op)
                     self.bwd_groups.append(grp)
                     d_x = d_out
-                x, Hc, inpl = out, Ho, pl
+                x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
         feat, d_feat = x, d_x
 
         # ---------------- geometric head
@@ -623,7 +659,8 @@ class Plan:
         self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
         if T:
             d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
-            grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt, affine_mask=True)
+            pre_t = (not HEAD_CONVS[0][2]) and self._fusable(e.layers[h + str(HEAD_CONVS[0][0])])
+            grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt, affine_mask=True, prereduced=pre_t)
             # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
             grp.append(self._wgrad(LT, d_rawt, feat, 16, 16, 8, 8, 2, 1, 256, 512, 256, 512))
             grp.append(self._unpack(LT))
@@ -631,7 +668,8 @@ class Plan:
             grp.append(op)
             self.bwd_groups.append(grp)
         hx, d_hx, Hh = h0, (d_h0 if T else None), 16
-        for ci, bi, up in HEAD_CONVS:
+        prev_bn, prev_raw = h + "1", rawt
+        for hi, (ci, bi, up) in enumerate(HEAD_CONVS):
             Lc = e.layers[h + str(ci)]
             grp = []
             if up:
@@ -652,16 +690,22 @@ class Plan:
             self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
             if T:
                 d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
-                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True)
+                # d_act is produced by the NEXT head conv's data gradient; when no upsampling sits in between, that
+                # launch masks it and reduces this BN's backward sums
+                nxt = HEAD_CONVS[hi + 1] if hi + 1 < len(HEAD_CONVS) else None
+                pre = nxt is not None and not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])
+                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre)
                 grp.append(self._wgrad(Lc, xin, d_raw, Hh, Hh, Hh, Hh, 1, 1, 256, 256, 256, 256))
                 grp.append(self._unpack(Lc))
-                op, _ = self._conv(Lc, d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256)
+                fuse_in = (not up) and self._fusable(Lc)  # d_in is the gradient w.r.t. the previous BN+ReLU's output
+                op, _ = self._conv(Lc, d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256,
+                                   bnb=(prev_bn, prev_raw, None, True) if fuse_in else None)
                 grp.append(op)
                 if up_bwd is not None:
                     grp.append(up_bwd)
                 self.bwd_groups.append(grp)
                 d_hx = d_act
-            hx = act
+            hx, prev_bn, prev_raw = act, h + str(bi), raw
         LO = e.layers[h + "23"]
         M = B * 64 * 64
         self.hs = 72

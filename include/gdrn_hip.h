@@ -50,6 +50,12 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *   epilogue: + bias[co] (fp32), + addend[m][co] (dtype), act (0 none, 1 ReLU, 2 LeakyReLU 0.1);
  *   stats != NULL: per-M-tile partial sum / sum of squares of the raw accumulators,
  *      stats[tile][0][co], stats[tile][1][co] (gdrn_conv_stats_rows tiles) for the following BatchNorm.
+ *   bnb_x != NULL (gdrn_conv3x3_halo only, data-gradient launches): y is the gradient w.r.t. the OUTPUT of a
+ *      BatchNorm(+ReLU) whose raw input was bnb_x[m][co] (channel stride bnb_cs).  The epilogue then also applies the
+ *      ReLU mask -- (bnb_mask[m][co] > 0) when bnb_mask is given, else (bnb_x*bnb_scale + bnb_shift > 0) when
+ *      bnb_scale/bnb_shift are given, else none -- stores the MASKED gradient and accumulates the BatchNorm backward
+ *      sums into bnb_sums exactly as gdrn_bn_bwd_reduce would (same [GDRN_BN_SUM_COPIES][2][Cout] layout, atomics,
+ *      caller clears): the separate reduction pass over (dy, x, mask) disappears.
  */
 typedef struct gdrn_conv_params {
     const void* x;
@@ -58,6 +64,15 @@ typedef struct gdrn_conv_params {
     const float* bias;
     const void* addend;
     float* stats;
+    const void* bnb_x;
+    const void* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    float* bnb_sums;
+    int bnb_cs;
+    int pad0_;
     int Hi, Wi, Cin, x_cs;
     int Ho, Wo, Cout, y_cs, add_cs;
     int KH, KW, stride, pad;

@@ -78,7 +78,9 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
-              out_f32=0, y_cs=None, want_stats=False, halo=False):
+              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None):
+    """bnb (halo only): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
+    the second return value is then the [16][2][Cout] sums buffer."""
     lib = cabi.load()
     if halo:  # the halo kernel takes the fragment-major permutation of the same operand
         wf = torch.empty_like(w)
@@ -102,6 +104,12 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         rows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
         stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
         cp.stats = ptr(stats)
+    if bnb is not None:
+        sums = torch.zeros(16, 2, Cout, dtype=torch.float32, device=DEV)
+        cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(bnb["x"]), ptr(bnb.get("mask")), bnb["x"].shape[-1]
+        cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
+        cp.bnb_sums = ptr(sums)
+        stats = sums
     check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
     torch.cuda.synchronize()
     return y, stats

@@ -239,6 +239,42 @@ def test_conv3x3_wgrad_halo_workspace(H, case, splits):
     assert H.rel(grad, w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("mask_kind", ["stored", "affine", "none"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8)])
+def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
+    """data-gradient launch with the fused BatchNorm(+ReLU) backward prologue: masked gradient + the two per-channel
+    sums == conv -> mask -> gdrn_bn_bwd_reduce semantics, computed with torch."""
+    B, I, O, Hh = case
+    dt, dev = BF16, H.DEV
+    x = H.rounded(H.randn(90, B, I, Hh, Hh), dt)
+    w = H.rounded(H.randn(91, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    add = H.rounded(H.randn(92, B, O, Hh, Hh), dt)
+    bx = H.rounded(H.randn(93, B, O, Hh, Hh) * 1.5 + 0.3, dt)       # raw input of the BatchNorm
+    mean, invstd = H.randn(94, O) * 0.2, torch.rand(O, generator=torch.Generator().manual_seed(95)) + 0.5
+    scale, shift = torch.rand(O, generator=torch.Generator().manual_seed(96)) + 0.5, H.randn(97, O) * 0.3
+    ystored = H.rounded(F.relu(bx * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + H.randn(98, B, O, Hh, Hh)), dt)  # with a residual
+    g = F.conv2d(x, w, None, 1, 1) + add
+    if mask_kind == "stored":
+        m = ystored > 0
+    elif mask_kind == "affine":
+        m = (bx * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
+    else:
+        m = torch.ones_like(g, dtype=torch.bool)
+    gm = g * m
+    xhat = (bx - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    ref1, ref2 = gm.sum((0, 2, 3)), (gm * xhat).sum((0, 2, 3))
+    d = lambda t: t.to(dev)
+    bnb = dict(x=H.nhwc(bx, dt), mean=d(mean), invstd=d(invstd))
+    if mask_kind == "stored":
+        bnb["mask"] = H.nhwc(ystored, dt)
+    elif mask_kind == "affine":
+        bnb["scale"], bnb["shift"] = d(scale), d(shift)
+    y, sums = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True, bnb=bnb)
+    assert H.rel(H.nchw(y, O), gm) < 1e-2
+    got = sums.sum(0).cpu()
+    assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
+
+
 def test_conv3x3_wgrad_grouped(H):
     """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
