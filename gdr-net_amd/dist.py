@@ -13,8 +13,9 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat, bounds, world_size=None, group=None, average=True):
-        self.flat, self.bounds, self.group, self.average = flat, bounds, group, average
+    def __init__(self, flat, bounds, world_size=None, group=None, average=True, force=False):
+        """force: issue the collectives even in a one-rank group (exercises the stream / event protocol on one GPU)."""
+        self.flat, self.bounds, self.group, self.average, self.force = flat, bounds, group, average, force
         self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
@@ -22,7 +23,7 @@ class GradReducer:
 
     def on_bucket(self, i):
         """Called right after the kernels that complete bucket i were enqueued on the compute stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         lo, hi = self.bounds[i]
         view = self.flat[lo:hi]
@@ -41,14 +42,14 @@ class GradReducer:
 
     def wait(self):
         """Make the compute stream wait for every outstanding bucket exchange."""
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.force):
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 
 
-def attach(model, group=None, average=True):
+def attach(model, group=None, average=True, force=False):
     """Overlap the gradient all-reduce with the model's backward; returns the GradReducer."""
     eng = model.engine()
-    red = GradReducer(eng.grad_flat, eng.bucket_bounds, group=group, average=average)
+    red = GradReducer(eng.grad_flat, eng.bucket_bounds, group=group, average=average, force=force)
     model._on_bucket = red.on_bucket
     model._reducer = red
     return red
