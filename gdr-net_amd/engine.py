@@ -50,6 +50,7 @@ class Engine:
         import os as _os
 
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
+        self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "2048"))  # target workgroups of a grouped launch
@@ -766,8 +767,21 @@ class Plan:
         f1, f2 = E(B, 1024), E(B, 256)
         self.fc_out = E(B, 64, dtype=F32t)
         b1, b2 = e.P["pnp_net.fc1.bias"], e.P["pnp_net.fc2.bias"]
-        op, _ = self._conv(L1, g2act, 128, f1, 8, 8, 1, 1, 1, 0, bias=b1, act=2, cin=128, cout=1024)
-        self.fwd.append(op)
+        if e.dt == BF16 and B <= 64 and e.fc_splitk:
+            # fc1 is bound by reading its 16.8 MB of weights once: split-K skinny GEMM instead of 8 gather workgroups.
+            # L1.wf = [1024 rows][64 taps][128 ch] = row-major [N][K] in the (pixel, channel) order of the NHWC input
+            ws1 = e._zeros(B * 1024 + 64, dtype=F32t)
+            self.keep.append(ws1)
+
+            def fc1_fwd(st, ctx):
+                check(lib.gdrn_linear_splitk(ptr(g2act), ptr(L1.wf), ptr(b1), ptr(f1), B, 8192, 1024, 8192, 8192, 1024, 2, ptr(ws1), e.dt, st),
+                      "linear_splitk fc1")
+
+            fc1_fwd.meta = dict(kernel="linear_splitk_kernel", flops=2.0 * B * 8192 * 1024, layer="pnp_net.fc1")
+            self.fwd.append(fc1_fwd)
+        else:
+            op, _ = self._conv(L1, g2act, 128, f1, 8, 8, 1, 1, 1, 0, bias=b1, act=2, cin=128, cout=1024)
+            self.fwd.append(op)
         op, _ = self._conv(L2, f1, 1024, f2, 1, 1, 1, 1, 1, 0, bias=b2, act=2, cin=1024, cout=256)
         self.fwd.append(op)
         op, _ = self._conv(L3, f2, 256, self.fc_out, 1, 1, 1, 1, 1, 0, bias=e.rt_b, out_f32=1, cin=256, cout=9, y_cs=64)

@@ -81,6 +81,12 @@ typedef struct gdrn_conv_params {
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
+/* Skinny-M linear layer (M <= 64 rows, bf16): y[m][n] = act(sum_k x[m][k]*w[n][k] + bias[n]) with the K range split
+ * over workgroups (the layer is bound by reading w once).  Replaces F.linear + LeakyReLU of Patch-PnP's fc1
+ * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in
+ * elements; ws: M*N floats + N/16 uint32 tickets, zeroed ONCE by the caller (the kernel leaves it zeroed). */
+int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
+                       int y_rs, int act, float* ws, int dtype, void* stream);
 int gdrn_conv_stats_rows(const gdrn_conv_params* p);
 /* Halo-tiled variant for KH=KW=3, stride 1, pad 1, mode 0, H and W multiples of 8 (same params / epilogue contract):
  * the input patch of a TH x TW pixel tile is staged in LDS once per 128-byte channel chunk and the nine taps read

@@ -567,3 +567,23 @@ def test_bn_finalize_workspace(H, rows, C_):
         np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(scale.cpu().numpy(), gam.cpu().numpy() / np.sqrt(var + 1e-5), rtol=2e-6)
         assert int(nbt) == 1 and float(ws.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N,act", [(64, 8192, 1024, 2), (4, 8192, 1024, 2), (37, 1024, 256, 0), (16, 128, 16, 1)])
+def test_linear_splitk(H, M, K, N, act):
+    """split-K skinny linear (Patch-PnP fc1) == F.linear + bias + activation; workspace left zeroed (called twice)."""
+    lib = cabi.load()
+    dev = H.DEV
+    x = H.rounded(H.randn(200, M, K), BF16)
+    w = H.rounded(H.randn(201, N, K) / math.sqrt(K), BF16)
+    b = H.randn(202, N) * 0.1
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.1) if act == 2 else ref)
+    xd, wd, bd = x.to(dev).to(torch.bfloat16), w.to(dev).to(torch.bfloat16), b.to(dev)
+    ws = torch.zeros(M * N + N // 16, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        check(lib.gdrn_linear_splitk(ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, K, K, N, act, ptr(ws), BF16, H.stream()), "linear_splitk")
+        torch.cuda.synchronize()
+        assert H.rel(y.float().cpu(), ref) < TOL[BF16]
+        assert float(ws.abs().max()) == 0.0
