@@ -35,7 +35,26 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int MF = (M + 15) >> 4;
-    for (int k = 0; k < kq; k += 32) {
+    int k = 0;
+    // four k-steps per trip: all 20 fragment loads are issued before the first MFMA (the loads come straight from
+    // L2/HBM; one dependent round trip per k-step made the first version latency-bound)
+    for (; k + 128 <= kq; k += 128) {
+        uint4 bq[4], aq[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bq[u] = *reinterpret_cast<const uint4*>(wp + k + u * 32);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) aq[f][u] = (f < MF) ? *reinterpret_cast<const uint4*>(xp[f] + k + u * 32) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (f < MF)
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f][u]), __builtin_bit_cast(bf16x8_t, bq[u]),
+                                                                     acc[f], 0, 0, 0);
+    }
+    for (; k < kq; k += 32) {
         const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + k));
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -99,9 +118,9 @@ extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bia
     if (!x || !w || !y || !ws || M <= 0 || M > 64 || K <= 0 || N <= 0) return GDRN_ERR_ARG;
     if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
     if ((N % 16) || (K % 128) || (x_rs % 8) || (w_rs % 8) || x_rs < K || w_rs < K || y_rs < N) return GDRN_ERR_SHAPE;
-    // K range per workgroup: a multiple of 128 (32 per wave-step x 4 waves); ~512 workgroups
+    // K range per workgroup: a multiple of 128 (32 per wave-step x 4 waves); ~1024 workgroups
     const int ntile = N / 16;
-    int S = std::max(1, std::min(K / 128, cdiv(512, ntile)));
+    int S = std::max(1, std::min(K / 128, cdiv(1024, ntile)));
     while (S > 1 && (K % (128 * S))) --S;
     const int kper = K / S;
     unsigned int* tickets = reinterpret_cast<unsigned int*>(ws + (size_t)M * N);

@@ -260,3 +260,21 @@ def model_kwargs(batch, do_loss=True):
             sym_infos=batch.get("sym_info", None),
         )
     return kw
+
+
+def make_postproc_inputs(B=3, H=64):
+    """Inputs of the inference post-processing golden G7 (dense maps as the network emits them at test time):
+    values in [0,1] with exact-0.5 coordinates (de-normalise to 0 -> rejected by the evaluator's |xyz| > 1e-4*extent
+    test) and one flat-mask RoI (max == min -> NaN mask after the epsilon-free min-max normalisation -> no points)."""
+    u = lambda tag, *shape: hash_uniform(71, tag, shape).astype(np.float32)
+    mask = u("mask", B, 1, H, H) * np.float32(1.4) - np.float32(0.2)
+    if B > 2:
+        mask[2] = 0.25
+    cx, cy, cz = u("cx", B, 1, H, H), u("cy", B, 1, H, H), u("cz", B, 1, H, H)
+    cx[0, 0, :8] = 0.5
+    if B > 1:
+        cz[1, 0, :, :5] = 0.5
+    coord2d = u("c2d", B, 2, H, H)
+    extents = (np.float32(0.05) + np.float32(0.25) * u("ext", B, 3)).astype(np.float32)
+    im_hw = np.array([[480, 640], [480, 640], [540, 720], [480, 640]], dtype=np.float32)[np.arange(B) % 4]
+    return dict(mask=mask, coor_x=cx, coor_y=cy, coor_z=cz, coord2d=coord2d, extents=extents, im_hw=im_hw)

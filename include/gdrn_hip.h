@@ -311,6 +311,20 @@ int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_de
                       float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Inference post-processing on the device: get_out_coor + get_out_mask
+ * (core/gdrn_modeling/engine_utils.py:92-126, L1 branches) and GDRN_Evaluator.get_img_model_points_with_coords2d
+ * (gdrn_evaluator.py:89-126, max_num_points < 4) for the whole batch, one workgroup per RoI.
+ *   mask / coor_{x,y,z}: fp32 maps, element (n, pixel) at base[n*roi_stride + pixel*pix_stride]
+ *     (NCHW [N,1,H,W] tensors: roi_stride = HW, pix_stride = 1; the engine's NHWC head output: hs*HW, hs)
+ *   coord2d [N][2][HW], extents [N][3], im_hw [N][2] = (im_H, im_W), mask_thr = cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST
+ *   out_mask [N][HW] = (mask - min)/(max - min) per RoI;  out_xyz [N][3][HW] (either may be NULL)
+ *   img_pts [N][HW][2], model_pts [N][HW][3]: the selected pixels of RoI n in row-major order, counts[n] of them
+ *     (both NULL: only the maps / counts).  fp32, the reference's operation order: bit-identical results. */
+int gdrn_correspondences(const float* mask, const float* coor_x, const float* coor_y, const float* coor_z, long long roi_stride,
+                         int pix_stride, const float* coord2d, const float* extents, const float* im_hw, float mask_thr, int N,
+                         int HW, float* out_mask, float* out_xyz, float* img_pts, float* model_pts, int* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -305,3 +305,52 @@ def to_dtype(obj, dtype):
     if isinstance(obj, (list, tuple)):
         return type(obj)(to_dtype(v, dtype) for v in obj)
     return obj
+
+
+# ------------------------------------------------------------------------------------------------
+# Inference post-processing -- CPU restatement, numpy like the reference
+def get_out_coor(coor_x, coor_y, coor_z):
+    """core/gdrn_modeling/engine_utils.py:92-105, XYZ_LOSS_TYPE == "L1" branch (one channel per coordinate)."""
+    assert coor_x.shape[1] == coor_y.shape[1] == coor_z.shape[1] == 1
+    return torch.cat([coor_x, coor_y, coor_z], dim=1)
+
+
+def get_out_mask(pred_mask):
+    """engine_utils.py:108-120, MASK_LOSS_TYPE == "L1": per-RoI min-max normalisation, no epsilon."""
+    bs, c, h, w = pred_mask.shape
+    assert c == 1
+    mask_max = torch.max(pred_mask.view(bs, -1), dim=-1)[0].view(bs, 1, 1, 1)
+    mask_min = torch.min(pred_mask.view(bs, -1), dim=-1)[0].view(bs, 1, 1, 1)
+    return (pred_mask - mask_min) / (mask_max - mask_min)
+
+
+def get_img_model_points_with_coords2d(mask_pred_crop, xyz_pred_crop, coord2d_crop, im_H, im_W, extent, mask_thr=0.5):
+    """core/gdrn_modeling/gdrn_evaluator.py:89-126 with max_num_points < 4 (no random sub-sampling).
+    mask HW, xyz HWC in [0,1], coord2d HW2 in [0,1] (numpy fp32) -> (image_points [n,2], model_points [n,3])."""
+    xyz = np.array(xyz_pred_crop, dtype=np.float32, copy=True)
+    c2d = np.array(coord2d_crop, dtype=np.float32, copy=True)
+    extent = np.asarray(extent, dtype=np.float32)
+    for c in range(3):
+        xyz[:, :, c] = (xyz[:, :, c] - np.float32(0.5)) * extent[c]
+    c2d[:, :, 0] = c2d[:, :, 0] * np.float32(im_W)
+    c2d[:, :, 1] = c2d[:, :, 1] * np.float32(im_H)
+    sel = (
+        (mask_pred_crop > np.float32(mask_thr))
+        & (np.abs(xyz[:, :, 0]) > np.float32(0.0001) * extent[0])
+        & (np.abs(xyz[:, :, 1]) > np.float32(0.0001) * extent[1])
+        & (np.abs(xyz[:, :, 2]) > np.float32(0.0001) * extent[2])
+    )
+    return c2d[sel].reshape(-1, 2), xyz[sel].reshape(-1, 3)
+
+
+def correspondences_batch(mask, coor_x, coor_y, coor_z, roi_coord_2d, roi_extents, im_hw, mask_thr=0.5):
+    """the evaluator's per-instance loop (gdrn_evaluator.py:325-377) over a batch: returns out_mask [N,1,H,W],
+    out_xyz [N,3,H,W], and per-RoI (image_points, model_points) lists."""
+    out_xyz = get_out_coor(coor_x, coor_y, coor_z).numpy()
+    out_mask = get_out_mask(mask).numpy()
+    pts = []
+    for i in range(out_xyz.shape[0]):
+        pts.append(get_img_model_points_with_coords2d(
+            np.squeeze(out_mask[i]), out_xyz[i].transpose(1, 2, 0), roi_coord_2d[i].numpy().transpose(1, 2, 0),
+            im_H=float(im_hw[i][0]), im_W=float(im_hw[i][1]), extent=roi_extents[i].numpy(), mask_thr=mask_thr))
+    return out_mask, out_xyz, pts

@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 STUBS = (
     "mmcv detectron2 torchvision transforms3d numba fvcore cv2 termcolor imageio png six plyfile chardet loguru "
     "setproctitle pytorch_lightning imgaug tensorboardX matplotlib pycocotools OpenGL glfw pyassimp vispy meshplex "
-    "fastfunc open3d albumentations pyquaternion ipdb"
+    "fastfunc open3d albumentations pyquaternion ipdb skimage"
 ).split()
 
 
@@ -88,6 +88,10 @@ def install_shims():
             nn.init.constant_(m.bias, bias)
 
     mc.normal_init, mc.constant_init, mc.kaiming_init = normal_init, constant_init, normal_init
+
+    import detectron2.evaluation as dev_
+
+    dev_.DatasetEvaluator = object  # GDRN_Evaluator must be a real class to reach its (self-free) helper method
 
     import torchvision.models.resnet as tvr
 
@@ -351,6 +355,26 @@ def main():
         for i, p in enumerate(ps):
             g[f"step{step}/p{i}"] = p.detach().numpy().copy()
     np.savez_compressed(os.path.join(out_dir, "g6_ranger.npz"), **g)
+
+    # ------------------------------------------------------------------ G7: inference post-processing (N2), B=3
+    # get_out_coor / get_out_mask (engine_utils.py:92-126) and GDRN_Evaluator.get_img_model_points_with_coords2d
+    # (gdrn_evaluator.py:89-126) run exactly as process_pnp_ransac (gdrn_evaluator.py:325-377) chains them.
+    from core.gdrn_modeling.engine_utils import get_out_coor, get_out_mask
+    from core.gdrn_modeling.gdrn_evaluator import GDRN_Evaluator
+
+    B7, H7 = 3, 64
+    inp = synth.make_postproc_inputs(B7, H7)
+    out_xyz = get_out_coor(cfg, *(torch.from_numpy(inp[k]) for k in ("coor_x", "coor_y", "coor_z"))).numpy()
+    out_mask = get_out_mask(cfg, torch.from_numpy(inp["mask"])).numpy()
+    g = dict(out_xyz=out_xyz, out_mask=out_mask)
+    for i in range(B7):
+        ip, mp = GDRN_Evaluator.get_img_model_points_with_coords2d(
+            None, np.squeeze(out_mask[i]), out_xyz[i].transpose(1, 2, 0).copy(), inp["coord2d"][i].transpose(1, 2, 0).copy(),
+            im_H=int(inp["im_hw"][i][0]), im_W=int(inp["im_hw"][i][1]), extent=inp["extents"][i],
+            mask_thr=cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST)
+        g[f"img_pts{i}"], g[f"model_pts{i}"] = np.asarray(ip, np.float32), np.asarray(mp, np.float32)
+        print("G7 roi", i, "correspondences:", len(ip))
+    np.savez_compressed(os.path.join(out_dir, "g7_postproc.npz"), **g)
     print("wrote goldens to", out_dir)
 
 

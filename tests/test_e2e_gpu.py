@@ -303,8 +303,11 @@ def test_train_step_graph_replay_equals_eager(dtype, monkeypatch):
     assert torch.isfinite(l1).all()
     # the two trajectories drift apart through the fp32-atomics ordering noise (x1600 through BN at B=4, compounded over
     # the updates): 1e-2 after six steps in fp32; bf16 pose losses decorrelate after an update (test_bf16_train_step_*)
-    tol = 1e-2 if dtype == "fp32" else 0.3
-    assert ((l0 - l1).abs() / (l0.abs() + 1e-3)).max() < tol, (l0, l1)
+    # (the strong check is the bit-level forward equality above; this one only guards against gross divergence, the pose
+    # losses -- last three -- being the chaotic ones)
+    rel = (l0 - l1).abs() / (l0.abs() + 1e-3)
+    tol_map, tol_pose = (5e-3, 0.1) if dtype == "fp32" else (0.1, 0.5)
+    assert rel[:, :5].max() < tol_map and rel[:, 5:].max() < tol_pose, (l0, l1)
 
 
 def test_bucketed_allreduce_protocol_one_rank_rccl():
@@ -353,3 +356,38 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_postproc_correspondences_vs_reference_golden(golden_dir):
+    """N2 on the device: gdrn_correspondences (one launch for the batch) == the reference's get_out_coor / get_out_mask /
+    get_img_model_points_with_coords2d chain (golden G7), bit for bit, and == the oracle on a bs=64 batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd import postproc
+    from oracle import gdrn_oracle as O
+
+    cfg = lm13_cfg(device=DEV)
+    g = np.load(os.path.join(golden_dir, "g7_postproc.npz"))
+    for B, golden in ((3, g), (64, None)):
+        inp = synth.make_postproc_inputs(B, 64)
+        d = {k: torch.from_numpy(v).to(DEV) for k, v in inp.items()}
+        od = dict(mask=d["mask"], coor_x=d["coor_x"], coor_y=d["coor_y"], coor_z=d["coor_z"])
+        om, ox, ip, mp, cnt = postproc.get_img_model_points_with_coords2d(cfg, od, d["coord2d"], d["extents"], inp["im_hw"][:, 0],
+                                                                          inp["im_hw"][:, 1])
+        torch.cuda.synchronize()
+        t = lambda k: torch.from_numpy(inp[k])
+        rm, rx, rpts = O.correspondences_batch(t("mask"), t("coor_x"), t("coor_y"), t("coor_z"), t("coord2d"), t("extents"), inp["im_hw"], 0.5)
+        if golden is not None:
+            np.testing.assert_array_equal(rx, golden["out_xyz"])
+        np.testing.assert_array_equal(ox.cpu().numpy(), rx)
+        np.testing.assert_array_equal(om.cpu().numpy(), rm)
+        cnt = cnt.cpu().numpy()
+        for i, (rip, rmp) in enumerate(rpts):
+            assert cnt[i] == len(rip)
+            np.testing.assert_array_equal(ip[i, : cnt[i]].cpu().numpy(), rip)
+            np.testing.assert_array_equal(mp[i, : cnt[i]].cpu().numpy(), rmp)
+            if golden is not None:
+                np.testing.assert_array_equal(rip, golden[f"img_pts{i}"])
+    # the two map helpers on their own
+    np.testing.assert_array_equal(postproc.get_out_mask(cfg, d["mask"]).cpu().numpy(), rm)
+    np.testing.assert_array_equal(postproc.get_out_coor(cfg, d["coor_x"], d["coor_y"], d["coor_z"]).cpu().numpy(), rx)

@@ -133,3 +133,21 @@ def test_pose_decode(golden_dir):
     rte, tte = O.pose_decode_test(R, t_, pb["roi_cam"], center, pb["resize_ratio"], pb["roi_wh"])
     np.testing.assert_allclose(rte.numpy(), g["rot_test"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(tte.numpy(), g["trans_test"], rtol=1e-6, atol=1e-7)
+
+
+def test_postproc_oracle_vs_reference_golden(golden_dir):
+    """G7: get_out_coor / get_out_mask / get_img_model_points_with_coords2d restatement == the reference's own functions,
+    bit for bit (fp32 numpy in the reference's operation order), incl. the flat-mask RoI that yields no points."""
+    from gdrnet_amd import synth
+
+    g = np.load(os.path.join(golden_dir, "g7_postproc.npz"))
+    inp = synth.make_postproc_inputs(3, 64)
+    t = lambda k: torch.from_numpy(inp[k])
+    out_mask, out_xyz, pts = O.correspondences_batch(t("mask"), t("coor_x"), t("coor_y"), t("coor_z"), t("coord2d"), t("extents"),
+                                                     inp["im_hw"], mask_thr=0.5)
+    np.testing.assert_array_equal(out_xyz, g["out_xyz"])
+    np.testing.assert_array_equal(out_mask, g["out_mask"])  # NaN == NaN for the flat mask under assert_array_equal
+    for i, (ip, mp) in enumerate(pts):
+        np.testing.assert_array_equal(ip, g[f"img_pts{i}"])
+        np.testing.assert_array_equal(mp, g[f"model_pts{i}"])
+    assert len(pts[2][0]) == 0 and len(pts[0][0]) > 1000
