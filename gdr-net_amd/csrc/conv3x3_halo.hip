@@ -451,6 +451,8 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     *th = 8;
     *tw = (p->Wo % 16 == 0) ? 16 : 8;
     *bn = p->Cout <= 64 ? 64 : 128;
+    // (measured and rejected: 4x16-pixel tiles -- 164 VGPRs, three workgroups per CU -- are 4 % slower over the step;
+    //  the kernel wants reuse per staged patch, not occupancy)
     // small feature maps: a 128-channel tiling leaves one workgroup (one wave per SIMD) per CU; halve the channel tile
     // when that grid is below `min_wg` workgroups (measured: no gain at bs=64, so off unless GDRN_HALO_MIN_WG is set)
     static const int min_wg = [] { const char* e = getenv("GDRN_HALO_MIN_WG"); return e ? atoi(e) : 0; }();

@@ -50,6 +50,7 @@ class Engine:
         import os as _os
 
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
+        self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "0") == "1"  # bucket-end work on a 2nd stream (measured: no gain on one GPU)
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
@@ -74,6 +75,11 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.dev)
@@ -492,6 +498,7 @@ class Plan:
                 check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab), ptr(stt), nt, nb, st), "conv3x3_wgrad_multi")
 
             run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
+            run.side = True
             self.bwd_groups[first_group[bkt]].append(run)
 
         per_bucket = {0: [], 1: [], 2: [], 3: []}
@@ -519,8 +526,11 @@ class Plan:
             stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
             self._unpack_tables.append((tab, stt))
             nt, nb = len(tasks), starts[-1]
-            self.bwd_groups[first_group[bkt]].append(
-                lambda st, ctx, tab=tab, stt=stt, nt=nt, nb=nb: check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi"))
+            def unpack(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb):
+                check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi")
+
+            unpack.side = True
+            self.bwd_groups[first_group[bkt]].append(unpack)
         for bkt, tasks in red_bucket.items():
             if not tasks:
                 continue
@@ -531,8 +541,11 @@ class Plan:
             stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
             self._unpack_tables.append((tab, stt))
             nt, nb = len(tasks), starts[-1]
-            self.bwd_groups[first_group[bkt]].append(
-                lambda st, ctx, tab=tab, stt=stt, nt=nt, nb=nb: check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi"))
+            def wreduce(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb):
+                check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi")
+
+            wreduce.side = True
+            self.bwd_groups[first_group[bkt]].append(wreduce)
 
     # ---- graph -------------------------------------------------------------------------------
     def _build(self):
@@ -854,13 +867,31 @@ class Plan:
         """ctx as in forward; self.gw must hold dL/dloss_k.  on_bucket(i) is called after the ops that
         complete gradient bucket i have been enqueued (used to overlap the RCCL all-reduce)."""
         e = self.e
-        st = e._stream()
+        main = torch.cuda.current_stream(e.dev)
+        st = main.cuda_stream
         e.dwp_flat.zero_()
         marks = self._bucket_marks() if on_bucket is not None else {}
+        # The bucket-end work (grouped weight gradients, their reduction, gradient unpack) only feeds the optimizer /
+        # the RCCL exchange: it goes to a second stream behind an event, so the next bucket's dependent chain of short
+        # data-gradient / BatchNorm kernels (one workgroup per CU on the small feature maps) shares the CUs with it.
+        side = e.side_stream() if e.wgrad_stream else None
+        used_side = in_side = False
         for i, op in enumerate(self.bwd):
-            op(st, ctx)
-            if i in marks:
-                on_bucket(marks[i])
+            if side is not None and getattr(op, "side", False):
+                if not in_side:
+                    side.wait_stream(main)  # everything enqueued so far on the main stream
+                    in_side = used_side = True
+                op(side.cuda_stream, ctx)
+                if i in marks:
+                    with torch.cuda.stream(side):
+                        on_bucket(marks[i])
+            else:
+                in_side = False
+                op(st, ctx)
+                if i in marks:
+                    on_bucket(marks[i])
+        if used_side:
+            main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
 
     def _bucket_marks(self):
         """index of the last backward op of each gradient bucket (pnp | head | layer4+3 | rest)."""
