@@ -34,10 +34,11 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
     f32x4_t acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int MF = (M + 15) >> 4;
     int k = 0;
     // four k-steps per trip: all 20 fragment loads are issued before the first MFMA (the loads come straight from
-    // L2/HBM; one dependent round trip per k-step made the first version latency-bound)
+    // L2/HBM; one dependent round trip per k-step made the first version latency-bound).  Rows >= M re-read row M-1
+    // (clamped pointers) and are dropped at the store: no per-load condition -- hipcc would branch around each load and
+    // wait for it separately.
     for (; k + 128 <= kq; k += 128) {
         uint4 bq[4], aq[4][4];
 #pragma unroll
@@ -45,24 +46,21 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) aq[f][u] = (f < MF) ? *reinterpret_cast<const uint4*>(xp[f] + k + u * 32) : make_uint4(0, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) aq[f][u] = *reinterpret_cast<const uint4*>(xp[f] + k + u * 32);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                if (f < MF)
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f][u]), __builtin_bit_cast(bf16x8_t, bq[u]),
-                                                                     acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f][u]), __builtin_bit_cast(bf16x8_t, bq[u]),
+                                                                 acc[f], 0, 0, 0);
     }
     for (; k < kq; k += 32) {
         const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + k));
+        uint4 aq[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            if (f < MF) {
-                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp[f] + k));
-                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[f], 0, 0, 0);
-            }
-        }
+        for (int f = 0; f < 4; ++f) aq[f] = *reinterpret_cast<const uint4*>(xp[f] + k);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f]), b, acc[f], 0, 0, 0);
     }
     // D[i = g*4 + j (row m of the fragment)][col = r16 (column n0 + r16)]
 #pragma unroll

@@ -391,3 +391,33 @@ def test_postproc_correspondences_vs_reference_golden(golden_dir):
     # the two map helpers on their own
     np.testing.assert_array_equal(postproc.get_out_mask(cfg, d["mask"]).cpu().numpy(), rm)
     np.testing.assert_array_equal(postproc.get_out_coor(cfg, d["coor_x"], d["coor_y"], d["coor_z"]).cpu().numpy(), rx)
+
+
+def test_eval_bn_constants_follow_training_updates():
+    """eval-mode BN scale/shift are cached across inference calls; a training step in between (new running statistics,
+    new weights, all written by kernels behind autograd's back) must invalidate them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 4
+    batch = to_dev(synth.make_batch(B, seed=5))
+    kwi = synth.model_kwargs(batch, do_loss=False)
+    kwt = synth.model_kwargs(batch, do_loss=True)
+    kwt.pop("do_loss")
+    model, opt = build("fp32")
+    model.eval()
+    with torch.no_grad():
+        r0 = model(batch["roi_img"], **kwi)["rot"].clone()
+        r0b = model(batch["roi_img"], **kwi)["rot"].clone()
+    assert torch.equal(r0, r0b)  # cached constants, deterministic forward
+    model.train()
+    model.train_step(batch["roi_img"], optimizer=opt, **kwt)
+    model.eval()
+    with torch.no_grad():
+        r1 = model(batch["roi_img"], **kwi)["rot"].clone()
+    fresh, _ = build("fp32")
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        r2 = fresh(batch["roi_img"], **kwi)["rot"].clone()
+    assert float((r1 - r0).abs().max()) > 1e-6      # the step changed the network
+    torch.testing.assert_close(r1, r2, rtol=1e-5, atol=1e-6)
