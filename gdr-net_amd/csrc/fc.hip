@@ -5,8 +5,8 @@
 // each stream 2 MB of weights serially (129 us, 8 TFLOP/s).  The layer is bound by reading w once (16.8 MB): split K.
 // A workgroup owns 16 output columns and a K range; its four waves take a quarter of that range each and feed both MFMA
 // operands straight from global memory (x rows and w rows are K-contiguous, so a lane's 8-element fragment is one
-// 16-byte load; no LDS staging, no transposes).  Partial sums meet in an fp32 workspace through atomics; the workgroup
-// that draws the last ticket of its column tile applies bias + activation, writes y and leaves the workspace zeroed.
+// 16-byte load; no LDS staging, no transposes).  Partial sums go to per-split slabs of an fp32 workspace; a second tiny
+// kernel adds them, applies bias + activation and writes y.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>
@@ -16,15 +16,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                            const float* __restrict__ bias, bf16_t* __restrict__ y, int M, int K,
-                                                            int N, int x_rs, int w_rs, int y_rs, int act, int kper, float* ws,
-                                                            unsigned int* tickets) {
+__global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int M, int K,
+                                                            int N, int x_rs, int w_rs, int kper, float* ws) {
     __shared__ float red[4][4][64][4];  // [wave][m fragment][lane][4]
-    __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
-    const int n0 = blockIdx.x * 16, S = gridDim.y;
+    const int n0 = blockIdx.x * 16;
     const int kq = kper >> 2;  // K elements per wave
     const int k_begin = blockIdx.y * kper + wave * kq;
     const bf16_t* wp = w + (size_t)(n0 + r16) * w_rs + k_begin + g * 8;
@@ -68,49 +65,37 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[wave][f][lane][j] = acc[f][j];
     __syncthreads();
-    // 1024 partial outputs (64 rows x 16 columns): 4 per thread, summed over the four waves
-    float* wsb = ws + (size_t)n0;
+    // 1024 partial outputs (64 rows x 16 columns): 4 per thread, summed over the four waves, stored to this split's slab
+    // of the workspace with plain stores.  A second tiny kernel adds the S slabs in a fixed order and applies bias +
+    // activation.  (Tried and rejected: fp32 atomics into one slab, and a last-arriver ticket in this kernel -- the
+    // agent-scope release/acquire that hand-off needs writes back the XCD's whole L2 per workgroup: 75-150 us.)
+    float* dst = ws + (size_t)blockIdx.y * M * N + n0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + 256 * i;             // (f, lane, j) flattened
         const int f = e >> 8, ln = (e >> 2) & 63, j = e & 3;
         const int m = f * 16 + (ln >> 4) * 4 + j, c = ln & 15;
-        if (m < M) {
-            const float v = red[0][f][ln][j] + red[1][f][ln][j] + red[2][f][ln][j] + red[3][f][ln][j];
-            if (S > 1) unsafeAtomicAdd(wsb + (size_t)m * N + c, v);
-            else red[0][f][ln][j] = v;
-        }
+        if (m < M) dst[(size_t)m * N + c] = red[0][f][ln][j] + red[1][f][ln][j] + red[2][f][ln][j] + red[3][f][ln][j];
     }
-    if (S > 1) {
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) is_last = (atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(S - 1));
-        __syncthreads();
-        if (!is_last) return;
-        __threadfence();
-    } else {
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + 256 * i;
-        const int m = e >> 4, c = e & 15;         // row-major over the 64 x 16 tile: 32-byte rows of y
-        if (m < M) {
-            float v;
-            if (S > 1) v = __hip_atomic_exchange(wsb + (size_t)m * N + c, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else v = red[0][m >> 4][((m & 15) >> 2) * 16 + c][m & 3];
-            if (bias != nullptr) v += bias[n0 + c];
-            if (act == 1) v = fmaxf(v, 0.f);
-            else if (act == 2) v = v > 0.f ? v : 0.1f * v;
-            y[(size_t)m * y_rs + n0 + c] = f2bf(v);
-        }
-    }
-    if (S > 1 && tid == 0) tickets[blockIdx.x] = 0u;
+}
+
+__global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ y, int M, int N, int y_rs, int act) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int m = i / N, n = i - m * N;
+    float v = 0.f;
+#pragma unroll 4
+    for (int sp = 0; sp < S; ++sp) v += ws[(size_t)sp * M * N + i];
+    if (bias != nullptr) v += bias[n];
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = v > 0.f ? v : 0.1f * v;
+    y[(size_t)m * y_rs + n] = f2bf(v);
 }
 
 }  // namespace
 
-// ws: M*N floats followed by N/16 uint32 tickets, zeroed ONCE by the caller (left zeroed).  bf16 only.
+// ws: GDRN_LINEAR_MAX_SPLITS * M*N floats (per-split partial slabs; no initialisation needed).  bf16 only.
 extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
                                   int y_rs, int act, float* ws, int dtype, void* stream) {
     if (!x || !w || !y || !ws || M <= 0 || M > 64 || K <= 0 || N <= 0) return GDRN_ERR_ARG;
@@ -118,12 +103,13 @@ extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bia
     if ((N % 16) || (K % 128) || (x_rs % 8) || (w_rs % 8) || x_rs < K || w_rs < K || y_rs < N) return GDRN_ERR_SHAPE;
     // K range per workgroup: a multiple of 128 (32 per wave-step x 4 waves); ~1024 workgroups
     const int ntile = N / 16;
-    int S = std::max(1, std::min(K / 128, cdiv(1024, ntile)));
+    int S = std::max(1, std::min(std::min(K / 128, GDRN_LINEAR_MAX_SPLITS), cdiv(1024, ntile)));
     while (S > 1 && (K % (128 * S))) --S;
     const int kper = K / S;
-    unsigned int* tickets = reinterpret_cast<unsigned int*>(ws + (size_t)M * N);
-    hipLaunchKernelGGL(linear_splitk_kernel, dim3(ntile, S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)x,
-                       (const bf16_t*)w, bias, (bf16_t*)y, M, K, N, x_rs, w_rs, y_rs, act, kper, ws, tickets);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(linear_splitk_kernel, dim3(ntile, S), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, M, K, N, x_rs, w_rs,
+                       kper, ws);
+    hipLaunchKernelGGL(linear_finish_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, ws, S, bias, (bf16_t*)y, M, N, y_rs, act);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

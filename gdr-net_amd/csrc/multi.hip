@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
                 const unsigned lane = r & 63u; r >>= 6;
                 const unsigned ks = r & 1u; r >>= 1;
                 const unsigned kch = B / EPS;
-                const unsigned kc = r % kch; r /= kch;
+                unsigned kc;
+                if (k.pad_ > 0) { kc = r & (kch - 1u); r >>= (unsigned)(k.pad_ - 1); }  // kch = 2^(pad_-1): no 32-bit division
+                else { kc = r % kch; r /= kch; }
                 tt = r % 9u;
                 a1 = (r / 9u) * 16u + (lane & 15u);
                 a2 = 0;

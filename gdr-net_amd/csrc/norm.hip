@@ -12,15 +12,13 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ BN
-// grid (C/16, S): block (cg, sl) sums rows sl, sl+S, ... of 16 channels, adds its fp64 totals to `ws` and takes a ticket;
-// the block that draws the last ticket of its channel group finalises the statistics and leaves `ws` zeroed again.
-// (The one-block-per-16-channels version spent 17 us per layer walking up to 4096 partial rows serially.)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
-                                                          const float* gamma, const float* beta, float* running_mean,
-                                                          float* running_var, long long* nbt, float momentum, float eps,
-                                                          float* mean, float* invstd, float* scale, float* shift, double* ws) {
+// Two launches for many partial rows: bn_reduce_rows_kernel, grid (C/16, S), sums rows sl, sl+S, ... of 16 channels in
+// fp64 and stores one fp64 row per slice; bn_finalize_kernel then reduces the (few) rows and finalises the statistics.
+// (A single launch with a last-arriver ticket was tried: the agent-scope release/acquire it needs writes back the XCD's
+// L2 -- full of the conv's fresh output -- per workgroup, 13-23 us per layer; the one-block-per-16-channels version
+// walked up to 4096 rows serially, 17 us.)
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __restrict__ partial, int rows, int C, double* __restrict__ out) {
     __shared__ double red[2][16][16];
-    __shared__ int is_last;
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
     const int S = gridDim.y;
@@ -34,28 +32,33 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     red[0][rl][cl] = s1;
     red[1][rl][cl] = s2;
     __syncthreads();
-    unsigned int* tickets = reinterpret_cast<unsigned int*>(ws + 2 * C);
     if (rl == 0 && ch < C) {
         for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
-        if (S > 1) {
-            atomicAdd(&ws[ch], s1);
-            atomicAdd(&ws[C + ch], s2);
+        out[((size_t)blockIdx.y * 2 + 0) * C + ch] = s1;  // fp64 rows: the parity mode sits at the fp32 noise floor
+        out[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2;
+    }
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ partial, int rows, int C, double count,
+                                                          const float* gamma, const float* beta, float* running_mean,
+                                                          float* running_var, long long* nbt, float momentum, float eps,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (ch < C) {
+        for (int r = rl; r < rows; r += 16) {
+            s1 += (double)partial[((size_t)r * 2 + 0) * C + ch];
+            s2 += (double)partial[((size_t)r * 2 + 1) * C + ch];
         }
     }
-    if (S > 1) {
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) is_last = (atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(S - 1));
-        __syncthreads();
-        if (!is_last) return;
-        __threadfence();
-        if (rl == 0 && ch < C) {
-            s1 = __hip_atomic_exchange(&ws[ch], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s2 = __hip_atomic_exchange(&ws[C + ch], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
-    }
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
     if (rl == 0 && ch < C) {
+        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
         const double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -603,10 +606,16 @@ extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double co
                                 float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream) {
     if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0) return GDRN_ERR_ARG;
-    int S = 1;  // row slices: ~4 rows per thread, only with a workspace
-    if (ws != nullptr) S = std::max(1, std::min(64, rows / 128));  // <= 8 rows per thread; few rows: no ticket round at all
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16), S), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
-                       running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift, ws);
+    // many rows (large feature maps): first fold them into S <= 64 fp64 rows with S x C/16 workgroups (needs the workspace)
+    if (ws != nullptr && rows >= 256) {
+        const int S = std::min(64, rows / 64);
+        hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(C, 16), S), dim3(256), 0, ST, partial, rows, C, ws);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, ST, (const double*)ws, S, C, count, gamma, beta,
+                           running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
+                           running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+    }
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -175,7 +175,7 @@ class Engine:
         self.bn_sums_flat = self.dwp_flat[tot:]
         for L in self.layers.values():
             L.dwp = self.dwp_flat[L.dwp_off: L.dwp_off + int(math.prod(L.dwp_shape))]
-        self.bn_ws = torch.zeros(2 * 512 + 32, dtype=torch.float64, device=self.dev)  # gdrn_bn_finalize workspace (self-cleaning)
+        self.bn_ws = torch.zeros(64 * 2 * 512, dtype=torch.float64, device=self.dev)  # gdrn_bn_finalize workspace (64*2*C doubles)
         self.rt_w = torch.zeros(9, 256, dtype=torch.float32, device=self.dev)
         self.rt_b = torch.zeros(9, dtype=torch.float32, device=self.dev)
 
@@ -210,8 +210,10 @@ class Engine:
                 if dst is None or (halo_only and not frag):
                     continue
                 A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip = self._pack_args(L, which)
+                kch = B * (2 if self.dt == BF16 else 4) // 128  # 128-byte chunks per pixel row
+                sh = (kch.bit_length() if (frag and kch > 0 and kch & (kch - 1) == 0) else 0)  # 1 + log2(kch)
                 t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
-                             s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=0)
+                             s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
                 tasks.append(t)
                 starts.append(starts[-1] + (t.n + chunk - 1) // chunk)
         self._pack_tasks = to_device_table(tasks, self.dev)
@@ -788,7 +790,7 @@ class Plan:
         if e.dt == BF16 and B <= 64 and e.fc_splitk:
             # fc1 is bound by reading its 16.8 MB of weights once: split-K skinny GEMM instead of 8 gather workgroups.
             # L1.wf = [1024 rows][64 taps][128 ch] = row-major [N][K] in the (pixel, channel) order of the NHWC input
-            ws1 = e._zeros(B * 1024 + 64, dtype=F32t)
+            ws1 = e._zeros(16 * B * 1024 + 64, dtype=F32t)  # GDRN_LINEAR_MAX_SPLITS slabs + tickets
             self.keep.append(ws1)
 
             def fc1_fwd(st, ctx):

@@ -84,7 +84,8 @@ int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
 /* Skinny-M linear layer (M <= 64 rows, bf16): y[m][n] = act(sum_k x[m][k]*w[n][k] + bias[n]) with the K range split
  * over workgroups (the layer is bound by reading w once).  Replaces F.linear + LeakyReLU of Patch-PnP's fc1
  * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in
- * elements; ws: M*N floats + N/16 uint32 tickets, zeroed ONCE by the caller (the kernel leaves it zeroed). */
+ * elements; ws: GDRN_LINEAR_MAX_SPLITS*M*N floats (per-split partial slabs, no initialisation needed). */
+#define GDRN_LINEAR_MAX_SPLITS 16
 int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
                        int y_rs, int act, float* ws, int dtype, void* stream);
 int gdrn_conv_stats_rows(const gdrn_conv_params* p);
@@ -164,8 +165,8 @@ int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, float* dst, in
  * BatchNorm2d (train / eval), fused with ReLU, residual add and max-pool where the graph has them.
  * Replaces nn.BatchNorm2d + nn.ReLU + `out += identity` + nn.MaxPool2d at resnet_backbone.py:24-26,
  * BasicBlock, cdpn_rot_head_region.py:92-93,113-114 and their backward. */
-/* ws: optional workspace of 2*C doubles + ceil(C/16) uint32, zeroed ONCE by the caller (the kernel leaves it zeroed);
- * with it the reduction over the `rows` per-tile partials is spread over many workgroups, NULL = one pass per 16 channels */
+/* ws: optional workspace of 64*2*C doubles (no initialisation needed): with it, and 256 or
+ * more per-tile partial rows, the rows are first folded into <= 64 rows by a wide launch; NULL = one pass per 16 channels */
 int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                      float eps, float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream);
@@ -285,6 +286,8 @@ int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  * gdrn_pack_task: gdrn_pack4 semantics (dst[a1][a2][t][b] = src[a1*s1 + a2*s2 + t'*st + b*sb], zero padded); frag != 0:
  *   dst is the fragment-major permutation (gdrn_pack_wfrag) of that [A1][1][9][B] operand.  For gdrn_unpack_multi the
  *   same struct describes gdrn_unpack4 (src = packed fp32, dst = parameter-layout gradient, n = A1v*A2v*T*Bv). */
+/* gdrn_pack_task.pad_ (frag tasks): 1 + log2(B*sizeof(dtype)/128) when that chunk count is a power of two (the kernel
+ * then shifts instead of dividing), else 0. */
 typedef struct gdrn_pack_task {
     const float* src;
     void* dst;

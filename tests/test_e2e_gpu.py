@@ -64,6 +64,7 @@ def test_fp32_train_step_vs_reference(g5, B, tag):
     errs_pose = {k: rel(a, g5[f"{tag}/{n}"]) for k, a, n in (("rot6d", fc[:, :6], "rot6d"), ("t_", fc[:, 6:9], "t_"),
                                                             ("rot", plan.rot, "rot_train"), ("trans", plan.trans, "trans"))}
     print(f"fp32 bs={B} pose rel-err vs reference:", {k: "%.2e" % v for k, v in errs_pose.items()})
+    print("fp32 pose errors vs reference:", {k: float("%.3e" % v) for k, v in errs_pose.items()})
     assert max(errs_pose.values()) < ptol, errs_pose
     vd = model.vis_dict()
     assert abs(vd["vis/error_R"] - float(g5[f"{tag}/vis_error_R"])) < 2e-2

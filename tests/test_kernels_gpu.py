@@ -543,7 +543,7 @@ def test_head_tail_and_map_losses(H, dt):
 
 @pytest.mark.parametrize("rows,C_", [(1000, 64), (4096, 64), (513, 256), (130, 512), (64, 128)])
 def test_bn_finalize_workspace(H, rows, C_):
-    """many-workgroup finalize (ticket + fp64 workspace) == fp64 numpy; the workspace is left zeroed (second call agrees)."""
+    """two-launch finalize for many partial rows (fold to <= 64 rows, then finalise) == fp64 numpy, also on the second call."""
     lib = cabi.load()
     dev = H.DEV
     rng = np.random.default_rng(rows + C_)
@@ -552,7 +552,7 @@ def test_bn_finalize_workspace(H, rows, C_):
     count = float(rows * 7)
     pd = torch.from_numpy(part).to(dev)
     gam, bet = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev)
-    ws = torch.zeros(2 * C_ + (C_ + 15) // 16, dtype=torch.float64, device=dev)
+    ws = torch.full((64 * 2 * C_,), float("nan"), dtype=torch.float64, device=dev)  # 64*2*C doubles, uninitialised
     m = part[:, 0].astype(np.float64).sum(0) / count
     var = np.maximum(part[:, 1].astype(np.float64).sum(0) / count - m * m, 0)
     for it in range(2):
@@ -566,12 +566,12 @@ def test_bn_finalize_workspace(H, rows, C_):
         np.testing.assert_allclose(invstd.cpu().numpy(), 1 / np.sqrt(var + 1e-5), rtol=1e-6)
         np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(scale.cpu().numpy(), gam.cpu().numpy() / np.sqrt(var + 1e-5), rtol=2e-6)
-        assert int(nbt) == 1 and float(ws.abs().max()) == 0.0
+        assert int(nbt) == 1
 
 
 @pytest.mark.parametrize("M,K,N,act", [(64, 8192, 1024, 2), (4, 8192, 1024, 2), (37, 1024, 256, 0), (16, 128, 16, 1)])
 def test_linear_splitk(H, M, K, N, act):
-    """split-K skinny linear (Patch-PnP fc1) == F.linear + bias + activation; workspace left zeroed (called twice)."""
+    """split-K skinny linear (Patch-PnP fc1) == F.linear + bias + activation; workspace needs no initialisation (called twice)."""
     lib = cabi.load()
     dev = H.DEV
     x = H.rounded(H.randn(200, M, K), BF16)
@@ -580,10 +580,9 @@ def test_linear_splitk(H, M, K, N, act):
     ref = F.linear(x, w, b)
     ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.1) if act == 2 else ref)
     xd, wd, bd = x.to(dev).to(torch.bfloat16), w.to(dev).to(torch.bfloat16), b.to(dev)
-    ws = torch.zeros(M * N + N // 16, dtype=torch.float32, device=dev)
+    ws = torch.full((16 * M * N,), float("nan"), dtype=torch.float32, device=dev)  # GDRN_LINEAR_MAX_SPLITS slabs, uninitialised
     for _ in range(2):
         y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
         check(lib.gdrn_linear_splitk(ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, K, K, N, act, ptr(ws), BF16, H.stream()), "linear_splitk")
         torch.cuda.synchronize()
         assert H.rel(y.float().cpu(), ref) < TOL[BF16]
-        assert float(ws.abs().max()) == 0.0
