@@ -29,8 +29,51 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
     constexpr int EPS = 128 / (int)sizeof(T), GE = 16 / (int)sizeof(T);
     const int t = find_task(blk_start, ntasks, blockIdx.x);
     const gdrn_pack_task k = tasks[t];
-    const long long base = (long long)(blockIdx.x - blk_start[t]) * PACK_CHUNK;
     T* dst = reinterpret_cast<T*>(k.dst);
+    if constexpr (sizeof(T) == 2) {
+        if (k.frag) {
+            // Fragment-major 3x3 operand, one workgroup per brick of 16 rows x 64 b x 9 taps (= nine 2 KiB blocks of the
+            // destination): the source is read along its contiguous axis (runs of 576 or 144 floats), transposed through
+            // LDS and written as whole 16-byte granules.  (The granule-gather version read 4-byte words 36 B apart and
+            // spent 210 us per step in the texture addresser.)
+            __shared__ bf16_t tile[16][9][72];
+            const int brick = blockIdx.x - blk_start[t];
+            const int kch = k.B >> 6;
+            const int cb = brick / kch, kc = brick - cb * kch;
+            const int a0 = cb * 16, b0 = kc * 64;
+            if (k.st == 1 && k.sb == 9) {          // src[a1*s1 + b*9 + t]
+                for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
+                    const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
+                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * 9 + tp] : 0.f;
+                    tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
+                }
+            } else if (k.st == 1 && k.s1 == 9) {   // src[a1*9 + b*sb + t]
+                for (int idx = threadIdx.x; idx < 64 * 144; idx += 256) {
+                    const int b = idx / 144, r = idx - b * 144, a = r / 9, tp = r - a * 9;
+                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)(a0 + a) * 9 + (long long)(b0 + b) * k.sb + tp] : 0.f;
+                    tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
+                }
+            } else {
+                for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
+                    const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
+                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * k.sb + (long long)tp * k.st] : 0.f;
+                    tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
+                }
+            }
+            __syncthreads();
+            // destination granule ((((cb*9 + tap)*kch + kc)*2 + ks)*64 + lane): row lane&15, b = (ks*4 + (lane>>4))*8 ..+7
+            for (int gi = threadIdx.x; gi < 9 * 2 * 64; gi += 256) {
+                const int lane = gi & 63, ks = (gi >> 6) & 1, tap = gi >> 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(&tile[lane & 15][tap][(ks * 4 + (lane >> 4)) * 8]);
+                *reinterpret_cast<uint4*>(dst + ((size_t)((((cb * 9 + tap) * kch + kc) * 2 + ks) * 64 + lane) << 3)) = v;
+            }
+            return;
+        }
+    }
+    const long long base = (long long)(blockIdx.x - blk_start[t]) * PACK_CHUNK;
     if ((k.B % GE) == 0 && (k.n % GE) == 0) {
         const unsigned B = (unsigned)k.B, Tt = (unsigned)k.T, A2 = (unsigned)k.A2;
         for (int g = threadIdx.x; g < PACK_CHUNK / GE; g += 256) {

@@ -215,7 +215,9 @@ class Engine:
                 t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
                              s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
                 tasks.append(t)
-                starts.append(starts[-1] + (t.n + chunk - 1) // chunk)
+                # workgroups of the task: bf16 fragment-major operands go brick by brick (16 rows x 64 b x 9 taps)
+                nblk = (A1 // 16) * (B // 64) if (frag and self.dt == BF16) else (t.n + chunk - 1) // chunk
+                starts.append(starts[-1] + nblk)
         self._pack_tasks = to_device_table(tasks, self.dev)
         self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.dev)
         self._pack_n = (len(tasks), starts[-1])

@@ -286,6 +286,8 @@ int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  * gdrn_pack_task: gdrn_pack4 semantics (dst[a1][a2][t][b] = src[a1*s1 + a2*s2 + t'*st + b*sb], zero padded); frag != 0:
  *   dst is the fragment-major permutation (gdrn_pack_wfrag) of that [A1][1][9][B] operand.  For gdrn_unpack_multi the
  *   same struct describes gdrn_unpack4 (src = packed fp32, dst = parameter-layout gradient, n = A1v*A2v*T*Bv). */
+/* Workgroups per task (blk_start prefix sums): ceil(n / gdrn_pack_chunk()) for row-major destinations; bf16 fragment-major
+ * (frag = 1, T = 9) tasks take (A1/16) * (B/64) workgroups -- one per brick of 16 rows x 64 b x 9 taps. */
 /* gdrn_pack_task.pad_ (frag tasks): 1 + log2(B*sizeof(dtype)/128) when that chunk count is a power of two (the kernel
  * then shifts instead of dividing), else 0. */
 typedef struct gdrn_pack_task {

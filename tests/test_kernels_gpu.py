@@ -586,3 +586,35 @@ def test_linear_splitk(H, M, K, N, act):
         check(lib.gdrn_linear_splitk(ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, K, K, N, act, ptr(ws), BF16, H.stream()), "linear_splitk")
         torch.cuda.synchronize()
         assert H.rel(y.float().cpu(), ref) < TOL[BF16]
+
+
+@pytest.mark.parametrize("O,I", [(128, 64), (64, 256), (256, 128)])
+def test_pack_multi_fragment_major(H, O, I):
+    """gdrn_pack_multi (brick transpose through LDS) == gdrn_pack4 + gdrn_pack_wfrag for the forward and the flipped
+    data-gradient operand of a 3x3 conv, both in ONE launch."""
+    from gdrnet_amd.cabi import PackTask, to_device_table
+
+    lib = cabi.load()
+    dev, dt = H.DEV, BF16
+    w = H.randn(300, O, I, 3, 3).to(dev).contiguous()
+    ru64 = lambda v: (v + 63) // 64 * 64
+    rows_f, cin_p, rows_d, cout_p = H.bn_rows(O), ru64(I), H.bn_rows(ru64(I)), ru64(O)
+    specs = [(rows_f, cin_p, O, I, I * 9, 9, 0), (rows_d, cout_p, I, O, 9, I * 9, 1)]  # A1, B, A1v, Bv, s1, sb, flip
+    refs, dsts, tasks, starts = [], [], [], [0]
+    for A1, B, A1v, Bv, s1, sb, flip in specs:
+        rowmajor = H.pack(w, A1, 1, 9, B, A1v, 1, Bv, s1, 0, 1, sb, flip, dt)
+        ref = torch.empty_like(rowmajor)
+        check(lib.gdrn_pack_wfrag(ptr(rowmajor), ptr(ref), A1, B, dt, H.stream()), "pack_wfrag")
+        dst = torch.full((A1 * 9 * B,), float("nan"), dtype=torch.bfloat16, device=dev)
+        kch = B // 64
+        tasks.append(PackTask(src=ptr(w), dst=ptr(dst), A1=A1, A2=1, T=9, B=B, A1v=A1v, A2v=1, Bv=Bv, flip=flip, s1=s1, s2=0, st=1, sb=sb,
+                              n=A1 * 9 * B, frag=1, pad_=kch.bit_length() if kch & (kch - 1) == 0 else 0))
+        starts.append(starts[-1] + (A1 // 16) * (B // 64))
+        refs.append(ref)
+        dsts.append(dst)
+    tab = to_device_table(tasks, dev)
+    stt = torch.tensor(starts, dtype=torch.int32, device=dev)
+    check(lib.gdrn_pack_multi(ptr(tab), ptr(stt), len(tasks), starts[-1], dt, H.stream()), "pack_multi")
+    torch.cuda.synchronize()
+    for ref, dst in zip(refs, dsts):
+        assert torch.equal(dst.view(torch.int16), ref.reshape(-1).view(torch.int16))
