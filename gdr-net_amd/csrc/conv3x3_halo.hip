@@ -178,29 +178,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     }
     __syncthreads();
 
-    // one tap stage: 2 k-steps x (FN weight frags in registers) x (FM pixel frags from LDS at immediate offsets)
-#define STAGE(WQ_, TAP_)                                                                                        \
+    // One tap stage = 2 k-steps x (FN weight frags in registers) x (FM pixel frags from LDS at immediate offsets), software
+    // pipelined over the k-steps: the LDS reads of k-step 1 are issued before the MFMAs of k-step 0, and the reads of the
+    // NEXT tap's k-step 0 before the MFMAs of k-step 1, so a wave's LDS latency hides under its own MFMAs (hipcc
+    // otherwise issues all 16 reads of a stage up front and the first MFMA waits ~150 cycles per stage).
+    uint4 fbA[FM], fbB[FM];
+#define RD(dst_, TAP_, KS_)                                                                                     \
     {                                                                                                           \
         constexpr int tsh_ = ((TAP_) / 3) * PW * PITCH + ((TAP_) % 3) * PITCH;                                  \
-        f32x4_t part[FN][FM];                                                                                   \
-        if constexpr (sizeof(T) == 4) {                                                                         \
-            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
-                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) part[a_][b_] = f32x4_t{0.f, 0.f, 0.f, 0.f};   \
-        }                                                                                                       \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                                   \
-            uint4 fb_[FM];                                                                                      \
+        _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                                       \
+            dst_[b_] = *reinterpret_cast<const uint4*>(pcur + (b_ * FROW + tsh_ + (KS_) * 32));                 \
+    }
+#define MM(WQ_, KS_, src_)                                                                                      \
+    {                                                                                                           \
+        _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                       \
             _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                                   \
-                fb_[b_] = *reinterpret_cast<const uint4*>(pcur + (b_ * FROW + tsh_ + ks_ * 32));               \
-            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
-                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) {                                             \
-                    if constexpr (sizeof(T) == 4) part[a_][b_] = mma_step<T>(WQ_[a_ * 2 + ks_], fb_[b_], part[a_][b_]); \
-                    else acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + ks_], fb_[b_], acc[a_][b_]);                    \
-                }                                                                                               \
-        }                                                                                                       \
-        if constexpr (sizeof(T) == 4) {                                                                         \
-            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
-                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) acc[a_][b_] += part[a_][b_];                  \
-        }                                                                                                       \
+                acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + (KS_)], src_[b_], acc[a_][b_]);                          \
     }
     // stage TAP_ of chunk kc: compute, refill the ring slot for stage +3, move one slice of the next patch
 #define STEP(WQ_, TAP_)                                                                                         \
@@ -209,7 +202,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
             if constexpr ((TAP_) > 0) WRITEP(rp, pb ^ 1, (TAP_) - 1)                                            \
             LOADP(rp, kc + 1, TAP_)                                                                             \
         }                                                                                                       \
-        STAGE(WQ_, TAP_)                                                                                        \
+        RD(fbB, TAP_, 1)                                                                                        \
+        \
+        MM(WQ_, 0, fbA)                                                                                         \
+        \
+        if constexpr ((TAP_) < 8) RD(fbA, (TAP_) + 1, 0)                                                        \
+        \
+        MM(WQ_, 1, fbB)                                                                                         \
         {                                                                                                       \
             constexpr int nt_ = ((TAP_) + 3) % 9;                                                               \
             const int nk_ = kc + (((TAP_) + 3) >= 9 ? 1 : 0);                                                   \
@@ -221,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         const int pb = kc & 1;
         const bool more_p = kc + 1 < kch;
         const unsigned char* pcur = smem + pb * PBYTES + lbase;
+        RD(fbA, 0, 0)
         STEP(wq0, 0) STEP(wq1, 1) STEP(wq2, 2)
         STEP(wq0, 3) STEP(wq1, 4) STEP(wq2, 5)
         STEP(wq0, 6) STEP(wq1, 7) STEP(wq2, 8)
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #undef LOADW
 #undef LOADP
 #undef WRITEP
-#undef STAGE
+#undef RD
+#undef MM
 #undef STEP
 
     // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
