@@ -24,7 +24,7 @@ class GdrnHipError(RuntimeError):
 class ConvParams(C.Structure):
     _fields_ = [
         ("x", P), ("w", P), ("y", P), ("bias", P), ("addend", P), ("stats", P),
-        ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_scale", P), ("bnb_shift", P), ("bnb_sums", P),
+        ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_scale", P), ("bnb_shift", P), ("bnb_rows", P),
         ("bnb_cs", I), ("pad0_", I),
         ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("add_cs", I),
@@ -108,6 +108,7 @@ _SIGS = {
     "gdrn_bn_eval_params": [P, P, P, P, F, I, P, P, P],
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
     "gdrn_bn_bwd_reduce": [P, P, P, P, P, P, P, LL, I, P, I, P],
+    "gdrn_bn_fold_rows": [P, I, I, P, P],
     "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],

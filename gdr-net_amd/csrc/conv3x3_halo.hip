@@ -319,17 +319,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
                         *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     }
                 }
-                float* sdst = p.bnb_sums + (size_t)(blockIdx.x % GDRN_BN_SUM_COPIES) * 2 * p.Cout + cl;
+                // per-tile partial rows with plain stores (as the forward statistics); gdrn_bn_fold_rows folds them into the
+                // GDRN_BN_SUM_COPIES layout bn_bwd_apply reads.  (Atomics from every workgroup onto 16 x 2C addresses
+                // cost 25-55 us per launch on the large maps -- same-address atomics run at a few G/s.)
+                float* srow = p.bnb_rows + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll
-                for (int a = 0; a < FN; ++a)
+                for (int a = 0; a < FN; ++a) {
+                    float u1[4], u2[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float u1 = row16_sum(t1[a][j]), u2 = row16_sum(t2[a][j]);
-                        if (r16 == 0) {
-                            unsafeAtomicAdd(sdst + a * 16 + j, u1);
-                            unsafeAtomicAdd(sdst + p.Cout + a * 16 + j, u2);
-                        }
+                    for (int j = 0; j < 4; ++j) { u1[j] = row16_sum(t1[a][j]); u2[j] = row16_sum(t2[a][j]); }
+                    if (r16 == 0) {
+                        *reinterpret_cast<float4*>(srow + a * 16) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                        *reinterpret_cast<float4*>(srow + p.Cout + a * 16) = make_float4(u2[0], u2[1], u2[2], u2[3]);
                     }
+                }
                 return;
             }
             if (ab != nullptr) {
@@ -500,7 +503,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
-        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_sums || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }

@@ -77,6 +77,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
 }
 
+// fold per-tile partial rows into GDRN_BN_SUM_COPIES rows (the layout of the BatchNorm-backward sums)
+__global__ __launch_bounds__(256) void bn_fold_rows_kernel(const float* __restrict__ rows, int nrows, int C, float* __restrict__ sums) {
+    __shared__ float red[2][16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (ch < C) {
+        for (int r = blockIdx.y + GDRN_BN_SUM_COPIES * rl; r < nrows; r += GDRN_BN_SUM_COPIES * 16) {
+            s1 += rows[((size_t)r * 2 + 0) * C + ch];
+            s2 += rows[((size_t)r * 2 + 1) * C + ch];
+        }
+    }
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && ch < C) {
+        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+        sums[((size_t)blockIdx.y * 2 + 0) * C + ch] = s1;
+        sums[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2;
+    }
+}
+
 __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -616,6 +638,13 @@ extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double co
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
                            running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
     }
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_fold_rows(const float* rows, int nrows, int C, float* sums, void* stream) {
+    if (!rows || !sums || nrows <= 0 || C <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(bn_fold_rows_kernel, dim3(cdiv(C, 16), GDRN_BN_SUM_COPIES), dim3(256), 0, ST, rows, nrows, C, sums);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

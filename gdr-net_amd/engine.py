@@ -310,16 +310,25 @@ class Plan:
             bkey, braw, bmask, baffine = bnb
             sb = self.bn[bkey]
             cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(braw), ptr(bmask), braw.shape[-1]
-            cp.bnb_mean, cp.bnb_invstd, cp.bnb_sums = ptr(sb.mean), ptr(sb.invstd), ptr(sb.sums)
+            cp.bnb_mean, cp.bnb_invstd, cp.bnb_rows = ptr(sb.mean), ptr(sb.invstd), ptr(self.stats)  # stats scratch is idle in backward
             if baffine:
                 cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
-        def run(st, ctx):
-            s = fn(ref, st)
-            if s:
-                check(s, f"conv {L.key}")
+        if bnb is not None:
+            nrows_b, sums_b, lib_ = int(cp._stats_rows), self.bn[bnb[0]].sums, e.lib
+
+            def run(st, ctx):
+                s = fn(ref, st)
+                if s:
+                    check(s, f"conv {L.key}")
+                check(lib_.gdrn_bn_fold_rows(ptr(self.stats), nrows_b, cp.Cout, ptr(sums_b), st), "bn_fold_rows")
+        else:
+            def run(st, ctx):
+                s = fn(ref, st)
+                if s:
+                    check(s, f"conv {L.key}")
 
         # metadata for the roofline measurement in bench.py: kernel instantiation + algorithmic FLOPs
         bm, bn = C.c_int(0), C.c_int(0)

@@ -53,9 +53,10 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *   bnb_x != NULL (gdrn_conv3x3_halo only, data-gradient launches): y is the gradient w.r.t. the OUTPUT of a
  *      BatchNorm(+ReLU) whose raw input was bnb_x[m][co] (channel stride bnb_cs).  The epilogue then also applies the
  *      ReLU mask -- (bnb_mask[m][co] > 0) when bnb_mask is given, else (bnb_x*bnb_scale + bnb_shift > 0) when
- *      bnb_scale/bnb_shift are given, else none -- stores the MASKED gradient and accumulates the BatchNorm backward
- *      sums into bnb_sums exactly as gdrn_bn_bwd_reduce would (same [GDRN_BN_SUM_COPIES][2][Cout] layout, atomics,
- *      caller clears): the separate reduction pass over (dy, x, mask) disappears.
+ *      bnb_scale/bnb_shift are given, else none -- stores the MASKED gradient and writes the two BatchNorm-backward sums
+ *      of its pixel tile to bnb_rows[tile][2][Cout] (gdrn_conv3x3_stats_rows tiles, plain stores); gdrn_bn_fold_rows
+ *      turns the rows into the [GDRN_BN_SUM_COPIES][2][Cout] sums gdrn_bn_bwd_apply reads: the separate reduction pass
+ *      over (dy, x, mask) disappears.
  */
 typedef struct gdrn_conv_params {
     const void* x;
@@ -70,7 +71,7 @@ typedef struct gdrn_conv_params {
     const float* bnb_invstd;
     const float* bnb_scale;
     const float* bnb_shift;
-    float* bnb_sums;
+    float* bnb_rows;
     int bnb_cs;
     int pad0_;
     int Hi, Wi, Cin, x_cs;
@@ -184,6 +185,8 @@ int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const f
                        const float* mask_scale, const float* mask_shift, long long npix, int C, float* sums, int dtype,
                        void* stream);
 /* dx = gamma*invstd*(g - sums0/n - xhat*sums1/n); optional g_out = g; dgamma = sums1, dbeta = sums0 */
+/* sums[r][*][c] = sum of rows r, r+COPIES, ... of rows[nrows][2][C] (r < GDRN_BN_SUM_COPIES): overwrites sums */
+int gdrn_bn_fold_rows(const float* rows, int nrows, int C, float* sums, void* stream);
 int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
                       const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
                       long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream);

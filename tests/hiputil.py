@@ -105,12 +105,16 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
         cp.stats = ptr(stats)
     if bnb is not None:
-        sums = torch.zeros(16, 2, Cout, dtype=torch.float32, device=DEV)
+        nrows = lib.gdrn_conv3x3_stats_rows(C.byref(cp))
+        rows_t = torch.full((nrows, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
+        sums = torch.full((16, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
         cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(bnb["x"]), ptr(bnb.get("mask")), bnb["x"].shape[-1]
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
-        cp.bnb_sums = ptr(sums)
+        cp.bnb_rows = ptr(rows_t)
         stats = sums
     check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
+    if bnb is not None:
+        check(lib.gdrn_bn_fold_rows(ptr(rows_t), nrows, Cout, ptr(sums), stream()), "bn_fold_rows")
     torch.cuda.synchronize()
     return y, stats
 
