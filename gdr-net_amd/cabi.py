@@ -55,7 +55,7 @@ class PoseParams(C.Structure):
 
 class PackTask(C.Structure):
     _fields_ = [
-        ("src", P), ("dst", P),
+        ("src", P), ("dst", P), ("scale", P),
         ("A1", I), ("A2", I), ("T", I), ("B", I), ("A1v", I), ("A2v", I), ("Bv", I), ("flip", I),
         ("s1", LL), ("s2", LL), ("st", LL), ("sb", LL), ("n", LL), ("frag", I), ("pad_", I),
     ]

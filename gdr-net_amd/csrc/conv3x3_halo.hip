@@ -235,12 +235,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #undef STEP
 
     // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
-    // Fast path for what the engine actually launches (full channel tiles, bf16 out, no bias / activation; optional
-    // statistics and addend): straight-line code, 32-bit offsets from uniform bases, DPP row sums.  The generic
+    // Fast path for what the engine actually launches (full channel tiles, bf16 out, bias / ReLU / addend / statistics
+    // optional): straight-line code, 32-bit offsets from uniform bases, DPP row sums.  The generic
     // epilogue below costs ~4600 instructions per wave (264 branches) -- more than the MFMA loop of a 256-channel
     // layer (3700) and 5x the loop of a 64-channel layer.
     if constexpr (sizeof(T) == 2) {
-        if (p.bias == nullptr && p.act == 0 && !p.out_f32 && (p.Cout % BN) == 0) {
+        if (p.act <= 1 && !p.out_f32 && (p.Cout % BN) == 0) {
             const int cl = co0 + wave * (BN / 4) + g * 4;  // + a*16
             if (p.stats != nullptr) {
                 float* srow = p.stats + (size_t)mt * 2 * p.Cout + cl;
@@ -335,6 +335,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
                 }
                 return;
             }
+            // optional bias (eval mode: the folded BatchNorm shift) and ReLU
+            float bq[FN][4];
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + cl + a * 16);
+                bq[a][0] = bv.x; bq[a][1] = bv.y; bq[a][2] = bv.z; bq[a][3] = bv.w;
+            }
+            const bool relu = p.act == 1;
             if (ab != nullptr) {
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
@@ -344,8 +353,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
                     for (int a = 0; a < FN; ++a) av[a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
-                        const float v0 = acc[a][b][0] + __uint_as_float(av[a].x << 16), v1 = acc[a][b][1] + __uint_as_float(av[a].x & 0xffff0000u);
-                        const float v2 = acc[a][b][2] + __uint_as_float(av[a].y << 16), v3 = acc[a][b][3] + __uint_as_float(av[a].y & 0xffff0000u);
+                        float v0 = acc[a][b][0] + bq[a][0] + __uint_as_float(av[a].x << 16), v1 = acc[a][b][1] + bq[a][1] + __uint_as_float(av[a].x & 0xffff0000u);
+                        float v2 = acc[a][b][2] + bq[a][2] + __uint_as_float(av[a].y << 16), v3 = acc[a][b][3] + bq[a][3] + __uint_as_float(av[a].y & 0xffff0000u);
+                        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     }
                 }
@@ -354,9 +364,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
                 for (int b = 0; b < FM; ++b) {
                     const unsigned pr = (unsigned)(prow0 + b * pstep);
 #pragma unroll
-                    for (int a = 0; a < FN; ++a)
-                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) =
-                            make_uint2(pack_bf2(acc[a][b][0], acc[a][b][1]), pack_bf2(acc[a][b][2], acc[a][b][3]));
+                    for (int a = 0; a < FN; ++a) {
+                        float v0 = acc[a][b][0] + bq[a][0], v1 = acc[a][b][1] + bq[a][1], v2 = acc[a][b][2] + bq[a][2], v3 = acc[a][b][3] + bq[a][3];
+                        if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                    }
                 }
             }
             return;

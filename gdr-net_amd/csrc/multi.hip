@@ -41,25 +41,28 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             const int kch = k.B >> 6;
             const int cb = brick / kch, kc = brick - cb * kch;
             const int a0 = cb * 16, b0 = kc * 64;
+            __shared__ float rsc[16];              // optional per-row factor (eval mode: BatchNorm scale folded into the weights)
+            if (threadIdx.x < 16) rsc[threadIdx.x] = (k.scale != nullptr && a0 + (int)threadIdx.x < k.A1v) ? k.scale[a0 + threadIdx.x] : 1.f;
+            __syncthreads();
             if (k.st == 1 && k.sb == 9) {          // src[a1*s1 + b*9 + t]
                 for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
                     const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
                     const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * 9 + tp] : 0.f;
+                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * 9 + tp] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             } else if (k.st == 1 && k.s1 == 9) {   // src[a1*9 + b*sb + t]
                 for (int idx = threadIdx.x; idx < 64 * 144; idx += 256) {
                     const int b = idx / 144, r = idx - b * 144, a = r / 9, tp = r - a * 9;
                     const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * 9 + (long long)(b0 + b) * k.sb + tp] : 0.f;
+                    const float v = ok ? k.src[(long long)(a0 + a) * 9 + (long long)(b0 + b) * k.sb + tp] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             } else {
                 for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
                     const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
                     const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * k.sb + (long long)tp * k.st] : 0.f;
+                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * k.sb + (long long)tp * k.st] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             }
@@ -104,10 +107,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             const bool ok = (int)a1 < k.A1v && (int)a2 < k.A2v;
             const unsigned ts = k.flip ? (Tt - 1u - tt) : tt;
             const float* sp = k.src + (long long)a1 * k.s1 + (long long)a2 * k.s2 + (long long)ts * k.st;
+            const float rs = (k.scale != nullptr && ok) ? k.scale[a1] : 1.f;
 #pragma unroll
             for (int el = 0; el < GE; ++el) {
                 const int b = (int)b0 + el;
-                v[el] = (ok && b < k.Bv) ? sp[(long long)b * k.sb] : 0.f;
+                v[el] = (ok && b < k.Bv) ? sp[(long long)b * k.sb] * rs : 0.f;
             }
             Vec16<T>::store(dst + i, v);
         }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
         float v = 0.f;
         if (a1 < k.A1v && a2 < k.A2v && b < k.Bv) {
             const int ts = k.flip ? (k.T - 1 - tt) : tt;
-            v = k.src[a1 * k.s1 + a2 * k.s2 + ts * k.st + b * k.sb];
+            v = k.src[a1 * k.s1 + a2 * k.s2 + ts * k.st + b * k.sb] * (k.scale != nullptr ? k.scale[a1] : 1.f);
         }
         st1<T>(dst + i, v);
     }

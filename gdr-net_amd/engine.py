@@ -57,6 +57,8 @@ class Engine:
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "2048"))  # target workgroups of a grouped launch
         self.layers = OrderedDict()
         self._versions = {}
+        self.bn_fold = {}  # bn key -> NS(scale, shift, layer): eval-mode BatchNorm folded into the preceding conv
+        self.fold_bn = _os.environ.get("GDRN_FOLD_BN", "1") != "0"  # A/B switch: conv + bn_apply launches in eval mode
         self.bn_epoch = 0  # bumped by every training forward (running statistics changed)
         self._build_layers()
         self.plans = {}
@@ -195,6 +197,54 @@ class Engine:
         return ((L.rows_f, 1, KK, L.cin_f, O, 1, I, I * KK, 0, 1, KK, 0) if which == "f"
                 else (L.rows_d, 1, KK, L.cin_d, I, 1, O, KK, 0, 1, I * KK, flip))
 
+    # ------------------------------------------------------------------------------------------ eval-mode BN folding
+    def fold(self, bnkey, L):
+        """Register conv layer L + the BatchNorm `bnkey` that follows it for eval-mode folding:
+        y = act(conv_{w * scale}(x) + shift [+ residual]) with scale = gamma / sqrt(running_var + eps),
+        shift = beta - running_mean * scale.  Returns NS(scale, shift) (filled by eval_refresh)."""
+        f = self.bn_fold.get(bnkey)
+        if f is None:
+            C_ = self.P[bnkey + ".weight"].numel()
+            f = NS(scale=self._empty(C_, dtype=torch.float32), shift=self._empty(C_, dtype=torch.float32), layer=L, C=C_)
+            self.bn_fold[bnkey] = f
+            L.wf_e = torch.zeros_like(L.wf)
+            L.wfF_e = torch.zeros_like(L.wfF) if L.wfF is not None else None
+            self._eval_tab = None  # rebuilt on the next refresh
+        assert f.layer is L, (bnkey, L.key)
+        return f
+
+    def eval_refresh(self):
+        """(Re)compute the folded scale / shift vectors and the scaled operand copies; the caller decides when."""
+        from .cabi import PackTask, to_device_table
+
+        lib, st = self.lib, self._stream()
+        if not self.bn_fold:
+            return
+        if getattr(self, "_eval_tab", None) is None:
+            chunk = lib.gdrn_pack_chunk()
+            tasks, starts = [], [0]
+            for bnkey, f in self.bn_fold.items():
+                L = f.layer
+                src = self.P[L.src[0]]
+                halo_only = self.use_halo and L.wfF is not None
+                for dst, frag in ((L.wf_e, 0), (L.wfF_e, 1)):
+                    if dst is None or (halo_only and not frag):
+                        continue
+                    A1, A2, T, B, A1v, A2v, Bv, s1, s2, stt, sb, flip = self._pack_args(L, "f")
+                    kch = B * (2 if self.dt == BF16 else 4) // 128
+                    sh = (kch.bit_length() if (frag and kch > 0 and kch & (kch - 1) == 0) else 0)
+                    t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), scale=f.scale.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v,
+                                 A2v=A2v, Bv=Bv, flip=flip, s1=s1, s2=s2, st=stt, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
+                    tasks.append(t)
+                    starts.append(starts[-1] + ((A1 // 16) * (B // 64) if (frag and self.dt == BF16) else (t.n + chunk - 1) // chunk))
+            self._eval_tab = (to_device_table(tasks, self.dev), torch.tensor(starts, dtype=torch.int32, device=self.dev), len(tasks), starts[-1])
+        for bnkey, f in self.bn_fold.items():
+            g, b = self.P[bnkey + ".weight"], self.P[bnkey + ".bias"]
+            rm, rv = self.Bf[bnkey + ".running_mean"], self.Bf[bnkey + ".running_var"]
+            check(lib.gdrn_bn_eval_params(ptr(g), ptr(b), ptr(rm), ptr(rv), 1e-5, f.C, ptr(f.scale), ptr(f.shift), st), "bn_eval_params")
+        tab, stt, nt, nb = self._eval_tab
+        check(lib.gdrn_pack_multi(ptr(tab), ptr(stt), nt, nb, self.dt, st), "pack_multi(eval)")
+
     def _build_pack_table(self):
         """Device task table for gdrn_pack_multi: every operand copy of every layer (stem excluded) in ONE launch."""
         from .cabi import PackTask, to_device_table
@@ -266,6 +316,7 @@ class Plan:
         self.keep = []         # keep ctypes structs alive
         self.bn = {}           # bn key -> NS(mean, invstd, scale, shift, sums)
         self.eval_prep = []        # eval-mode BN scale/shift launches (run when parameters / running stats changed)
+        self._fold_hooked = False
         self._eval_sig = None
         self._unpack_pending = []  # (forward group index, layer)
         self._wreduce = {}         # layer key -> (workspace, nsplit, Cout, Cin) of the halo weight-gradient partials
@@ -278,7 +329,7 @@ class Plan:
 
     # ---- op builders -------------------------------------------------------------------------
     def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
-              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None):
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False):
         """bnb = (bn key, raw input of that BN, stored activation or None, affine mask?): data-gradient launch whose
         output is the gradient w.r.t. that BatchNorm(+ReLU)'s output -- the halo kernel's epilogue masks it and
         accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass."""
@@ -303,7 +354,10 @@ class Plan:
         use_halo = e.use_halo and th.value > 0 and L.kind == "conv" and L.wfF is not None
         if e.use_halo and L.wfF is not None and not use_halo:
             raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
-        if use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
+        if evalw:      # eval-mode operand with the BatchNorm scale folded in (Engine.fold)
+            assert w is None
+            cp.w = ptr(L.wfF_e if use_halo else L.wf_e)
+        elif use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
         if bnb is not None:
             assert use_halo, L.key
@@ -427,6 +481,16 @@ class Plan:
             ops.append(lambda st, ctx: check(lib.gdrn_bn_apply(ptr(raw), ptr(s.scale), ptr(s.shift), ptr(residual), ptr(y), npix,
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
+
+    def _conv_bn_eval(self, L, bnkey, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, relu, residual=None, add_cs=0, **kw):
+        """eval mode: conv -> BatchNorm (-> +residual) (-> ReLU) as ONE launch, y = act(conv_{w*scale}(x) + shift + residual)."""
+        f = self.e.fold(bnkey, L)
+        if not self._fold_hooked:
+            self.eval_prep.append(lambda st, ctx: self.e.eval_refresh())
+            self._fold_hooked = True
+        op, _ = self._conv(L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, bias=f.shift, addend=residual, add_cs=add_cs, act=1 if relu else 0,
+                           evalw=True, **kw)
+        return op
 
     def _fusable(self, L):
         """can the data gradient of layer L run on the halo kernel (and so carry a fused BN-backward reduction)?"""
@@ -569,6 +633,7 @@ class Plan:
     def _build(self):
         e, lib, B = self.e, self.e.lib, self.B
         S, T, WL = self.bn_train, self.has_backward, self.with_loss  # batch stats | backward graph | losses
+        FOLD = (not S) and e.fold_bn  # eval mode: BatchNorm folded into the preceding conv (weights pre-scaled, shift as bias)
 
         def E(*shape, dtype=None):
             # every plan buffer is pinned in self.keep: the pre-bound C structs hold RAW device pointers, so a
@@ -620,6 +685,15 @@ class Plan:
                 Ld = e.layers.get(pfx + ".downsample.0")
                 npo = B * Ho * Ho
                 raw1, a1, raw2, out = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                if FOLD:  # eval: three (four) launches per block, no BatchNorm passes
+                    self.fwd.append(self._conv_bn_eval(L1, pfx + ".bn1", x, inpl, a1, Hc, Hc, Ho, Ho, stride, 1, relu=True))
+                    res = x
+                    if Ld is not None:
+                        res = E(B, Ho, Ho, pl)
+                        self.fwd.append(self._conv_bn_eval(Ld, pfx + ".downsample.1", x, inpl, res, Hc, Hc, Ho, Ho, stride, 0, relu=False))
+                    self.fwd.append(self._conv_bn_eval(L2, pfx + ".bn2", a1, pl, out, Ho, Ho, Ho, Ho, 1, 1, relu=True, residual=res, add_cs=pl))
+                    x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
+                    continue
                 op, cp = self._conv(L1, x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None)
                 self.fwd.append(op)
                 self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, a1)
@@ -686,9 +760,12 @@ class Plan:
         h = "rot_head_net.features."
         LT = e.layers[h + "0"]
         rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
-        op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
-        self.fwd.append(op)
-        self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
+        if FOLD:
+            self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
+        else:
+            op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
+            self.fwd.append(op)
+            self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
         if T:
             d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
             pre_t = (not HEAD_CONVS[0][2]) and self._fusable(e.layers[h + str(HEAD_CONVS[0][0])])
@@ -717,9 +794,12 @@ class Plan:
                 d_in = d_hx
                 up_bwd = None
             raw, act = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
-            op, cp = self._conv(Lc, xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None)
-            self.fwd.append(op)
-            self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
+            if FOLD:
+                self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
+            else:
+                op, cp = self._conv(Lc, xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None)
+                self.fwd.append(op)
+                self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
             if T:
                 d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
                 # d_act is produced by the NEXT head conv's data gradient; when no upsampling sits in between, that

@@ -291,11 +291,14 @@ int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  *   same struct describes gdrn_unpack4 (src = packed fp32, dst = parameter-layout gradient, n = A1v*A2v*T*Bv). */
 /* Workgroups per task (blk_start prefix sums): ceil(n / gdrn_pack_chunk()) for row-major destinations; bf16 fragment-major
  * (frag = 1, T = 9) tasks take (A1/16) * (B/64) workgroups -- one per brick of 16 rows x 64 b x 9 taps. */
+/* gdrn_pack_task.scale (pack only, nullable): per-row factor, dst[a1][..] = src[..] * scale[a1] -- eval mode folds the
+ * BatchNorm scale gamma/sqrt(var+eps) of the following BN into the conv operand this way. */
 /* gdrn_pack_task.pad_ (frag tasks): 1 + log2(B*sizeof(dtype)/128) when that chunk count is a power of two (the kernel
  * then shifts instead of dividing), else 0. */
 typedef struct gdrn_pack_task {
     const float* src;
     void* dst;
+    const float* scale;
     int A1, A2, T, B, A1v, A2v, Bv;
     int flip;
     long long s1, s2, st, sb;
