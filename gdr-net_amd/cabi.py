@@ -83,6 +83,9 @@ _SIGS = {
     "gdrn_device_info": [I, C.c_char_p, C.POINTER(I), C.c_char_p],
     "gdrn_conv_gemm": [C.POINTER(ConvParams), P],
     "gdrn_correspondences": [P, P, P, P, LL, I, P, P, P, F, I, I, P, P, P, P, P, P],
+    "gdrn_pack_stem_w32": [P, P, I, P],
+    "gdrn_stem_stats_rows": [I],
+    "gdrn_stem_conv": [P, P, P, P, I, I, P],
     "gdrn_linear_splitk": [P, P, P, P, I, I, I, I, I, I, I, P, I, P],
     "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],

@@ -51,6 +51,8 @@ class Engine:
 
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
         self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "0") == "1"  # bucket-end work on a 2nd stream (measured: no gain on one GPU)
+        self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
+        self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
@@ -288,6 +290,8 @@ class Engine:
             self.rt_b[6:].copy_(self.P["pnp_net.fc_t.bias"])
         Ls = self.layers["backbone.conv1"]
         check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
+        if self.stem_direct:
+            check(lib.gdrn_pack_stem_w32(ptr(self.P[Ls.src[0]]), ptr(self.stem_w32), self.dt, st), "pack_stem_w32")
         if not hasattr(self, "_pack_tasks"):
             self._build_pack_table()
         check(lib.gdrn_pack_multi(ptr(self._pack_tasks), ptr(self._pack_starts), self._pack_n[0], self._pack_n[1], self.dt, st), "pack_multi")
@@ -372,6 +376,7 @@ class Plan:
 
         if bnb is not None:
             nrows_b, sums_b, lib_ = int(cp._stats_rows), self.bn[bnb[0]].sums, e.lib
+            assert nrows_b * 2 * cp.Cout <= self.stats.numel(), (L.key, nrows_b)
 
             def run(st, ctx):
                 s = fn(ref, st)
@@ -469,6 +474,7 @@ class Plan:
         ops = []
         if self.bn_train:
             rows = self._stats_rows(cp)
+            assert rows * 2 * C_ <= self.stats.numel(), (bnkey, rows, C_)  # the producer's partial rows fit the scratch
             ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
                                                                   ptr(rv), ptr(nbt), 0.1, 1e-5, ptr(s.mean), ptr(s.invstd),
                                                                   ptr(s.scale), ptr(s.shift), ptr(e.bn_ws), st), "bn_finalize"))
@@ -644,7 +650,12 @@ class Plan:
             return t
 
         F32t = torch.float32
-        self.stats = E(B * 32768 + 65536, dtype=F32t)  # per-M-tile BN partial sums (max over layers)
+        # per-tile BN partial sums, max over layers: conv tiles need <= B*32768 floats (64-pixel tiles of the 64x64 maps at 256
+        # channels); the direct stem kernel writes one [2][64] row per wave
+        n_stats = B * 32768 + 65536
+        if e.stem_direct:
+            n_stats = max(n_stats, int(lib.gdrn_stem_stats_rows(B)) * 128)
+        self.stats = E(n_stats, dtype=F32t)
         nreg = e.nreg
 
         # ---------------- stem
@@ -654,9 +665,18 @@ class Plan:
         p0 = E(B, 64, 64, 64)
         idx0 = E(B, 64, 64, 64, dtype=torch.uint8)
         self.fwd.append(lambda st, ctx: check(lib.gdrn_pack_image(ctx["img"], ptr(self.img_p), B, 256, 256, 262, 272, e.dt, st), "pack_image"))
-        op, cp = self._conv(Ls, self.img_p, 4, raw0, 262, 272, 128, 128, 2, 0, cin=64, cout=64, x_cs=4, KH=7, KW=1,
-                            stats=self.stats if S else None)
-        self.fwd.append(op)
+        if e.stem_direct:
+            cp = NS(_stats_rows=int(lib.gdrn_stem_stats_rows(B)))
+
+            def stem(st, ctx):
+                check(lib.gdrn_stem_conv(ptr(self.img_p), ptr(e.stem_w32), ptr(raw0), ptr(self.stats) if S else None, B, e.dt, st), "stem_conv")
+
+            stem.meta = dict(kernel="stem_conv_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1")
+            self.fwd.append(stem)
+        else:
+            op, cp = self._conv(Ls, self.img_p, 4, raw0, 262, 272, 128, 128, 2, 0, cin=64, cout=64, x_cs=4, KH=7, KW=1,
+                                stats=self.stats if S else None)
+            self.fwd.append(op)
         self.fwd += self._bn_fwd("backbone.bn1", raw0, cp, 64, B * 128 * 128, None)
         s0 = self.bn["backbone.bn1"]
         self.fwd.append(lambda st, ctx: check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw0), ptr(s0.scale), ptr(s0.shift), ptr(p0), ptr(idx0),

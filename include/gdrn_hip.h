@@ -82,6 +82,13 @@ typedef struct gdrn_conv_params {
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
+/* ResNet stem, bf16: 7x7 stride-2 pad-3 conv 3 -> 64 on the NHWC4 canvas of gdrn_pack_image (256x256 images ->
+ * [N][262][272][4]), one kernel row = one 32-deep MFMA k-step, pixel fragments straight from global memory, weights in
+ * registers (resnet_backbone.py:23,69).  w32 = gdrn_pack_stem_w32(OIHW fp32 weight) = bf16 [64][7][32];
+ * y = [N][128][128][64]; stats (nullable) = [gdrn_stem_stats_rows(N)][2][64] partial sums for gdrn_bn_finalize. */
+int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream);
+int gdrn_stem_stats_rows(int N);
+int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, int N, int dtype, void* stream);
 /* Skinny-M linear layer (M <= 64 rows, bf16): y[m][n] = act(sum_k x[m][k]*w[n][k] + bias[n]) with the K range split
  * over workgroups (the layer is bound by reading w once).  Replaces F.linear + LeakyReLU of Patch-PnP's fc1
  * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in

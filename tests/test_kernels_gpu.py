@@ -618,3 +618,28 @@ def test_pack_multi_fragment_major(H, O, I):
     torch.cuda.synchronize()
     for ref, dst in zip(refs, dsts):
         assert torch.equal(dst.view(torch.int16), ref.reshape(-1).view(torch.int16))
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_stem_conv_direct(H, B):
+    """dedicated stem kernel (one kernel row per MFMA k-step, fragments straight from the NHWC4 canvas) == F.conv2d
+    7x7 s2 p3, and its per-wave partial statistics sum to the tensor's sum / sum of squares."""
+    lib = cabi.load()
+    dev, dt = H.DEV, BF16
+    img = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(7))
+    w = H.rounded(H.randn(400, 64, 3, 7, 7) / math.sqrt(147), dt)
+    ref = F.conv2d(H.rounded(img, dt), w, None, 2, 3)
+    canvas = torch.zeros(B, 262, 272, 4, dtype=torch.bfloat16, device=dev)
+    imgd = img.to(dev).contiguous()
+    check(lib.gdrn_pack_image(ptr(imgd), ptr(canvas), B, 256, 256, 262, 272, dt, H.stream()), "pack_image")
+    w32 = torch.empty(64 * 7 * 32, dtype=torch.bfloat16, device=dev)
+    wd = w.to(dev).contiguous()
+    check(lib.gdrn_pack_stem_w32(ptr(wd), ptr(w32), dt, H.stream()), "pack_stem_w32")
+    rows = lib.gdrn_stem_stats_rows(B)
+    stats = torch.full((rows, 2, 64), float("nan"), dtype=torch.float32, device=dev)
+    y = torch.full((B, 128, 128, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    check(lib.gdrn_stem_conv(ptr(canvas), ptr(w32), ptr(y), ptr(stats), B, dt, H.stream()), "stem_conv")
+    torch.cuda.synchronize()
+    assert H.rel(H.nchw(y), ref) < TOL[dt]
+    s = stats.double().sum(0).cpu()
+    assert H.rel(s[0].float(), ref.sum((0, 2, 3))) < 2e-3 + 1e-2 and H.rel(s[1].float(), (ref ** 2).sum((0, 2, 3))) < 1e-2
