@@ -56,7 +56,7 @@ class Engine:
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
-        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "2048"))  # target workgroups of a grouped launch
+        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
         self.layers = OrderedDict()
         self._versions = {}
         self.bn_fold = {}  # bn key -> NS(scale, shift, layer): eval-mode BatchNorm folded into the preceding conv
