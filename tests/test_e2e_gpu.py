@@ -444,3 +444,28 @@ def test_bf16_training_reduces_the_loss():
     first, last = np.mean(hist[:3]), np.mean(hist[-3:])
     print("total loss: %.4f -> %.4f" % (first, last))
     assert last < 0.9 * first, hist
+
+
+@pytest.mark.parametrize("cfgname,B,classes,cam,sym", [("lmo", 32, 8, "lm", False), ("ycbv", 64, 21, "ycbv", True)])
+def test_other_baseline_configs_full_size(cfgname, B, classes, cam, sym):
+    """BASELINE.json configs[3] (LM-O, bs=32) and configs[4] (YCB-V, bs=64, symmetric PM loss) at full size in bf16:
+    two fused train steps with finite losses, R in SO(3), finite gradients; the graph is the LM-13 one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.cfg import lmo_cfg
+
+    cfgfn = lmo_cfg if cfgname == "lmo" else ycbv_cfg
+    model, opt = build("bf16", cfgfn)
+    model.train()
+    batch = to_dev(synth.make_batch(B, seed=13, num_classes=classes, cam=cam, with_sym=sym))
+    kw = synth.model_kwargs(batch, do_loss=True)
+    kw.pop("do_loss")
+    for _ in range(2):
+        losses = model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    assert torch.isfinite(losses).all() and float(losses.sum()) > 0
+    eng = model.engine()
+    plan = eng.plan(B, True, True)
+    R = plan.rot.double()
+    eye = torch.eye(3, dtype=torch.float64, device=DEV).expand(B, 3, 3)
+    assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-5
+    assert torch.isfinite(eng.grad_flat).all() and float(eng.grad_flat.abs().max()) > 0
