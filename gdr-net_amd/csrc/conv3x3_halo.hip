@@ -113,6 +113,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     const int cb0 = (co0 + wave * (BN / 4)) / 16;
     const char* wl = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
 
+    // weight stream: stage s = kc*9 + tap; per stage WQ loads of 1 KiB
+    auto wptr = [&](int kc, int tap, int a, int ks) -> const uint4* {
+        return reinterpret_cast<const uint4*>(wl + ((size_t)((((cb0 + a) * 9 + tap) * kch + kc) * 2 + ks) << 10));
+    };
+    uint4 wq0[WQ], wq1[WQ], wq2[WQ];  // 3-stage register ring (slot = tap % 3)
+
+#define LOADW(dst, kc_, tap_)                                                   \
+    {                                                                           \
+        _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_) {                     \
+            dst[a_ * 2 + 0] = *wptr(kc_, tap_, a_, 0);                          \
+            dst[a_ * 2 + 1] = *wptr(kc_, tap_, a_, 1);                          \
+        }                                                                       \
+    }
+    // the first three stages' weights go out before the patch geometry below is computed: their L2 latency hides under ~300
+    // address instructions instead of following them
+    LOADW(wq0, 0, 0) LOADW(wq1, 0, 1) LOADW(wq2, 0, 2)
+
     // ---- patch slice geometry of this thread (slice st = linear segment ids [st*PSLICE, (st+1)*PSLICE))
     unsigned poff[9];
     int pdst[9];
@@ -143,20 +160,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // weight stream: stage s = kc*9 + tap; per stage WQ loads of 1 KiB
-    auto wptr = [&](int kc, int tap, int a, int ks) -> const uint4* {
-        return reinterpret_cast<const uint4*>(wl + ((size_t)((((cb0 + a) * 9 + tap) * kch + kc) * 2 + ks) << 10));
-    };
-    uint4 wq0[WQ], wq1[WQ], wq2[WQ];  // 3-stage register ring (slot = tap % 3)
     uint4 rp = make_uint4(0, 0, 0, 0);
 
-#define LOADW(dst, kc_, tap_)                                                   \
-    {                                                                           \
-        _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_) {                     \
-            dst[a_ * 2 + 0] = *wptr(kc_, tap_, a_, 0);                          \
-            dst[a_ * 2 + 1] = *wptr(kc_, tap_, a_, 1);                          \
-        }                                                                       \
-    }
 #define LOADP(dst, kc_, st_)                                                    \
     {                                                                           \
         const uint4 v_ = *reinterpret_cast<const uint4*>(xg + (poff[st_] + (unsigned)((kc_) * ROWB))); \
@@ -167,12 +172,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         if (pdst[st_] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[st_]) = src; \
     }
 
-    // ---- prologue: patch of chunk 0 (nine slices in flight together), weights of stages 0..2
+    // ---- prologue: patch of chunk 0 (nine slices in flight together); the weights of stages 0..2 are already in flight
     {
         uint4 q0, q1, q2, q3, q4, q5, q6, q7, q8;
         LOADP(q0, 0, 0) LOADP(q1, 0, 1) LOADP(q2, 0, 2) LOADP(q3, 0, 3) LOADP(q4, 0, 4)
         LOADP(q5, 0, 5) LOADP(q6, 0, 6) LOADP(q7, 0, 7) LOADP(q8, 0, 8)
-        LOADW(wq0, 0, 0) LOADW(wq1, 0, 1) LOADW(wq2, 0, 2)
         WRITEP(q0, 0, 0) WRITEP(q1, 0, 1) WRITEP(q2, 0, 2) WRITEP(q3, 0, 3) WRITEP(q4, 0, 4)
         WRITEP(q5, 0, 5) WRITEP(q6, 0, 6) WRITEP(q7, 0, 7) WRITEP(q8, 0, 8)
     }
