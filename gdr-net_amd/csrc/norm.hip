@@ -432,18 +432,22 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 
 // ------------------------------------------------------------------------------------------ GroupNorm
 // one block per sample; CPG = C/G channels per group (4 at the benchmark configs).
+// grid (N, C / CS): a workgroup normalises the CS-channel slab blockIdx.y of sample blockIdx.x (groups never straddle a slab:
+// CS is a multiple of C/G).  One workgroup per sample -- the first version -- ran 64 workgroups on 256 CUs.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y,
-                                                          float* __restrict__ mean_rstd, int HW, int C, int G, float eps) {
+                                                          float* __restrict__ mean_rstd, int HW, int C, int G, float eps, int CS) {
     constexpr int V = Vec16<T>::VEC;
     __shared__ double sg[2 * 128];
-    const int n = blockIdx.x, cpg = C / G;
-    const int tpr = C / V, rpp = 256 / tpr;
+    __shared__ float kgb[2][512];
+    const int n = blockIdx.x, cpg = C / G, c0 = blockIdx.y * CS, g0 = c0 / cpg, GS = CS / cpg;
+    const int tpr = CS / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sg[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * GS; i += 256) sg[i] = 0.0;
+    for (int i = threadIdx.x; i < CS; i += 256) { kgb[0][i] = gamma[c0 + i]; kgb[1][i] = beta[c0 + i]; }
     __syncthreads();
-    const T* xb = x + (size_t)n * HW * C;
+    const T* xb = x + (size_t)n * HW * C + c0;
     float s1[V], s2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -457,31 +461,33 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
     for (int j = 0; j < V; ++j) {
         const int gi = (cv * V + j) / cpg;
         atomicAdd(&sg[gi], (double)s1[j]);
-        atomicAdd(&sg[G + gi], (double)s2[j]);
+        atomicAdd(&sg[GS + gi], (double)s2[j]);
     }
     __syncthreads();
     const double cnt = (double)HW * cpg;
-    float mu[V], rs[V];
+    float mu[V], rs[V], gm[V], bt[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int gi = (cv * V + j) / cpg;
         const double m = sg[gi] / cnt;
-        const double var = fmax(sg[G + gi] / cnt - m * m, 0.0);
+        const double var = fmax(sg[GS + gi] / cnt - m * m, 0.0);
         mu[j] = (float)m;
         rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+        gm[j] = kgb[0][cv * V + j];
+        bt[j] = kgb[1][cv * V + j];
     }
-    if (threadIdx.x < G) {
+    if (threadIdx.x < GS) {
         const double m = sg[threadIdx.x] / cnt;
-        const double var = fmax(sg[G + threadIdx.x] / cnt - m * m, 0.0);
-        mean_rstd[((size_t)n * G + threadIdx.x) * 2 + 0] = (float)m;
-        mean_rstd[((size_t)n * G + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        const double var = fmax(sg[GS + threadIdx.x] / cnt - m * m, 0.0);
+        mean_rstd[((size_t)n * G + g0 + threadIdx.x) * 2 + 0] = (float)m;
+        mean_rstd[((size_t)n * G + g0 + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    T* yb = y + (size_t)n * HW * C;
+    T* yb = y + (size_t)n * HW * C + c0;
     for (int r = rl; r < HW; r += rpp) {
         float v[V];
         Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
 #pragma unroll
-        for (int j = 0; j < V; ++j) v[j] = fmaxf((v[j] - mu[j]) * rs[j] * gamma[cv * V + j] + beta[cv * V + j], 0.f);
+        for (int j = 0; j < V; ++j) v[j] = fmaxf((v[j] - mu[j]) * rs[j] * gm[j] + bt[j], 0.f);
         Vec16<T>::store(yb + (size_t)r * C + cv * V, v);
     }
 }
@@ -490,24 +496,32 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                           const T* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ mean_rstd, T* __restrict__ dx,
-                                                          float* dgamma, float* dbeta, int HW, int C, int G) {
+                                                          float* dgamma, float* dbeta, int HW, int C, int G, int CS) {
     constexpr int V = Vec16<T>::VEC;
     __shared__ float sg[2 * 128];   // per group: sum g*gamma, sum g*gamma*xhat
     __shared__ float sc[2 * 512];   // per channel: sum g*xhat, sum g
-    const int n = blockIdx.x, cpg = C / G;
-    const int tpr = C / V, rpp = 256 / tpr;
+    __shared__ float kst[3][512];   // per channel: group mean, group rstd, gamma
+    const int n = blockIdx.x, cpg = C / G, c0 = blockIdx.y * CS, g0 = c0 / cpg, GS = CS / cpg;
+    const int tpr = CS / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sg[i] = 0.f;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sc[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * GS; i += 256) sg[i] = 0.f;
+    for (int i = threadIdx.x; i < CS; i += 256) {
+        sc[i] = 0.f;
+        sc[CS + i] = 0.f;
+        const int gi = g0 + i / cpg;
+        kst[0][i] = mean_rstd[((size_t)n * G + gi) * 2 + 0];
+        kst[1][i] = mean_rstd[((size_t)n * G + gi) * 2 + 1];
+        kst[2][i] = gamma[c0 + i];
+    }
     __syncthreads();
-    const size_t base = (size_t)n * HW * C;
+    const size_t base = (size_t)n * HW * C + c0;
     float mu[V], rs[V], gm[V], a1[V], a2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        const int c = cv * V + j, gi = c / cpg;
-        mu[j] = mean_rstd[((size_t)n * G + gi) * 2 + 0];
-        rs[j] = mean_rstd[((size_t)n * G + gi) * 2 + 1];
-        gm[j] = gamma[c];
+        const int c = cv * V + j;
+        mu[j] = kst[0][c];
+        rs[j] = kst[1][c];
+        gm[j] = kst[2][c];
         a1[j] = 0.f; a2[j] = 0.f;
     }
     for (int r = rl; r < HW; r += rpp) {
@@ -527,14 +541,14 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j, gi = c / cpg;
         atomicAdd(&sc[c], a2[j]);
-        atomicAdd(&sc[C + c], a1[j]);
+        atomicAdd(&sc[CS + c], a1[j]);
         atomicAdd(&sg[gi], a1[j] * gm[j]);
-        atomicAdd(&sg[G + gi], a2[j] * gm[j]);
+        atomicAdd(&sg[GS + gi], a2[j] * gm[j]);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        unsafeAtomicAdd(&dgamma[c], sc[c]);
-        unsafeAtomicAdd(&dbeta[c], sc[C + c]);
+    for (int c = threadIdx.x; c < CS; c += 256) {
+        unsafeAtomicAdd(&dgamma[c0 + c], sc[c]);
+        unsafeAtomicAdd(&dbeta[c0 + c], sc[CS + c]);
     }
     const float inv_m = 1.f / ((float)HW * cpg);
     float A[V], B[V];
@@ -542,7 +556,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
     for (int j = 0; j < V; ++j) {
         const int gi = (cv * V + j) / cpg;
         A[j] = sg[gi] * inv_m;
-        B[j] = sg[G + gi] * inv_m;
+        B[j] = sg[GS + gi] * inv_m;
     }
     for (int r = rl; r < HW; r += rpp) {
         float g[V], yv[V], xv[V], o[V];
@@ -760,16 +774,24 @@ extern "C" int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W
     return GDRN_OK;
 }
 
+// channel slab per workgroup for the GroupNorm kernels: 32 channels when groups and 16-byte vectors tile it, else all of C
+static int gn_slab(int C, int G, int V) {
+    const int cpg = C / G;
+    if (C % 32 == 0 && 32 % cpg == 0 && 32 % V == 0) return 32;
+    return C;
+}
+
 extern "C" int gdrn_gn_relu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N,
                                 int HW, int C, int G, float eps, int dtype, void* stream) {
     if (!x || !gamma || !beta || !y || !mean_rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 128 || C > 512 || (C % G) ||
         (C % 8))
         return GDRN_ERR_ARG;
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
-    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    const int CS = gn_slab(C, G, V);
+    if (256 % (CS / V)) return GDRN_ERR_SHAPE;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(N), dim3(256), 0, ST, (const float*)x, gamma, beta, (float*)y, mean_rstd, HW, C, G, eps),
-             hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, HW, C, G, eps));
+             hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)x, gamma, beta, (float*)y, mean_rstd, HW, C, G, eps, CS),
+             hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, HW, C, G, eps, CS));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -780,14 +802,15 @@ extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, co
         C > 512 || (C % G) || (C % 8))
         return GDRN_ERR_ARG;
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
-    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    const int CS = gn_slab(C, G, V);
+    if (256 % (CS / V)) return GDRN_ERR_SHAPE;
     if (hipMemsetAsync(dgamma, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     if (hipMemsetAsync(dbeta, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(gn_relu_bwd_kernel<float>, dim3(N), dim3(256), 0, ST, (const float*)dy, (const float*)y,
-                                (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, HW, C, G),
-             hipLaunchKernelGGL(gn_relu_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y,
-                                (const bf16_t*)x, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, HW, C, G));
+             hipLaunchKernelGGL(gn_relu_bwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)dy, (const float*)y,
+                                (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, HW, C, G, CS),
+             hipLaunchKernelGGL(gn_relu_bwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y,
+                                (const bf16_t*)x, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, HW, C, G, CS));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
