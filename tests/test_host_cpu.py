@@ -139,3 +139,17 @@ def test_ranger_rectification_scalars_match_reference_golden(golden_dir):
                 slow[i] += np.float32(0.5) * (p - slow[i])
                 p[...] = slow[i]
             np.testing.assert_allclose(p, g[f"step{step - 1}/p{i}"], rtol=2e-5, atol=2e-7)
+
+
+def test_postproc_has_no_cpu_fallback():
+    """the on-device inference post-processing refuses CPU tensors instead of silently computing on the host."""
+    import torch
+
+    from gdrnet_amd import cabi, postproc
+
+    cfg = lm13_cfg(device="cpu")
+    m = torch.rand(2, 1, 64, 64)
+    with pytest.raises(cabi.GdrnHipError):
+        postproc.get_out_mask(cfg, m)
+    with pytest.raises(cabi.GdrnHipError):
+        postproc.get_out_coor(cfg, m, m, m)
