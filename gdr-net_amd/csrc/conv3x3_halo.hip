@@ -453,7 +453,10 @@ int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
         attr_set = true;
     }
     const int grid = N * (p.Ho / TH) * (p.Wo / TW) * cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN>), dim3(grid), dim3(256), smem, st, p);
+    // a single 128-byte channel chunk (Cin = 64) never touches the second patch buffer: half the LDS -> a third workgroup per
+    // CU on the 64-channel variants (142 VGPRs), whose runs are all prologue / one chunk / epilogue
+    const size_t smem_used = (p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN>), dim3(grid), dim3(256), smem_used, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
