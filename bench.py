@@ -42,7 +42,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(bs=4, iters=2):
+def cpu_baseline(bs=16, iters=4):
     """Oracle fwd+bwd on the host cores (reported baseline, not a target)."""
     import torch
 
@@ -68,8 +68,19 @@ def cpu_baseline(bs=4, iters=2):
     for _ in range(iters):
         step()
     dt = (time.perf_counter() - t0) / iters
+
+    def infer():
+        with torch.no_grad():
+            O.gdrn_forward(sd, batch, do_loss=False, training=False)
+
+    infer()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        infer()
+    dti = (time.perf_counter() - t0) / iters
     return {"value": round(bs / dt, 3), "unit": "RoI/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU fp32) fwd+bwd, bs={bs}, {iters} timed steps after 1 warm-up, no optimizer step"}
+            "sample": f"oracle (torch CPU fp32) fwd+bwd, bs={bs}, {iters} timed steps after 1 warm-up, no optimizer step",
+            "inference_fwd_roi_s": round(bs / dti, 3)}
 
 
 def measure_roofline(model, plan, kctx, dtype):
