@@ -69,6 +69,14 @@ class RangerTask(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P), ("slow", P), ("rows", I), ("cols", I), ("gc", I), ("lr", F)]
 
 
+class RoiTask(C.Structure):
+    _fields_ = [
+        ("image", P), ("coord2d", P), ("xyz_crop", P), ("seg", P), ("trunc", P),
+        ("cx", D), ("cy", D), ("scale", D), ("bw", D), ("bh", D), ("ox", D), ("oy", D), ("tz", D),
+        ("H", I), ("W", I), ("x1", I), ("y1", I), ("x2", I), ("y2", I), ("cls", I), ("pad_", I),
+    ]
+
+
 def to_device_table(structs, device):
     """ctypes struct list -> uint8 device tensor holding the C array."""
     import torch
@@ -132,6 +140,9 @@ _SIGS = {
     "gdrn_pack_multi": [P, P, I, I, I, P],
     "gdrn_unpack_multi": [P, P, I, I, P],
     "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, P],
+    "gdrn_roi_affine": [P, I, I, I, P, P, P, P, P],
+    "gdrn_roi_crop_inputs": [P, P, I, I, I, C.POINTER(D), C.POINTER(D), P, P, P],
+    "gdrn_roi_targets": [P, P, I, I, P, I, P, P, P, P, P, P, P],
 }
 
 EXPORTS = tuple(_SIGS.keys())

@@ -278,3 +278,63 @@ def make_postproc_inputs(B=3, H=64):
     extents = (np.float32(0.05) + np.float32(0.25) * u("ext", B, 3)).astype(np.float32)
     im_hw = np.array([[480, 640], [480, 640], [540, 720], [480, 640]], dtype=np.float32)[np.arange(B) % 4]
     return dict(mask=mask, coor_x=cx, coor_y=cy, coor_z=cz, coord2d=coord2d, extents=extents, im_hw=im_hw)
+
+
+def make_roi_frames(B=8, seed=5, ncls=13, nfps=64, frame_sizes=((480, 640), (540, 720)), dzi_pad_scale=1.5):
+    """Synthetic inputs of the RoI cropper / target builder, numpy on the host:
+    a few u8 frames, and per RoI an annotated box with its object-coordinate patch (zeros = background holes),
+    visible mask, optional truncation mask, jittered crop centre / size (DZI-like, data_loader.py:417-423), pose
+    translation and projected centroid.  Edge cases by construction: RoI 0 hangs over the top-left frame corner,
+    RoI 1 has the crop size clamped to max(H, W), RoI 2 is a 1-pixel-wide box, RoI 3 touches the bottom-right corner."""
+    u = lambda tag, *shape: hash_uniform(seed, tag, shape)  # noqa: E731
+    frames = [np.floor(u(f"frame{i}", h, w, 3) * 256).astype(np.uint8) for i, (h, w) in enumerate(frame_sizes)]
+    extents = (0.05 + 0.25 * u("ext", ncls, 3)).astype(np.float32)
+    fps = ((u("fps", ncls, nfps, 3) - 0.5) * extents[:, None, :].astype(np.float64)).astype(np.float64)
+    rois = []
+    for n in range(B):
+        fi = n % len(frames)
+        H, W = frames[fi].shape[:2]
+        r = u(f"roi{n}", 12)
+        bw, bh = int(20 + r[0] * 160), int(20 + r[1] * 160)
+        x1, y1 = int(r[2] * (W - bw - 1)), int(r[3] * (H - bh - 1))
+        if n == 0:
+            x1, y1 = 0, 0
+        if n == 2:
+            bw = 1
+        if n == 3:
+            x1, y1 = W - 1 - bw, H - 1 - bh
+        x2, y2 = x1 + bw, y1 + bh
+        cls = int(r[4] * ncls)
+        xyz = ((u(f"xyz{n}", bh + 1, bw + 1, 3) - 0.5) * extents[cls].astype(np.float64)).astype(np.float32)
+        xyz[u(f"hole{n}", bh + 1, bw + 1) < 0.3] = 0  # background inside the box
+        seg = np.zeros((H, W), np.uint8)
+        seg[y1 : y2 + 1, x1 : x2 + 1] = u(f"seg{n}", bh + 1, bw + 1) < 0.8
+        trunc = (u(f"trunc{n}", H, W) < 0.7).astype(np.uint8) if n % 3 == 1 else None
+        cx = 0.5 * (x1 + x2) + bw * 0.25 * (2 * r[5] - 1)
+        cy = 0.5 * (y1 + y2) + bh * 0.25 * (2 * r[6] - 1)
+        scale = max(bw, bh) * (1 + 0.25 * (2 * r[7] - 1)) * dzi_pad_scale
+        if n == 1:
+            scale = 5000.0
+        scale = min(scale, max(H, W)) * 1.0
+        rois.append(dict(frame=fi, bbox=np.array([x1, y1, x2, y2], np.float64), xyxy=(x1, y1, x2, y2), xyz_crop=xyz, segmentation=seg,
+                         mask_trunc=trunc, bbox_center=np.array([cx, cy]), scale=float(scale), roi_cls=cls,
+                         trans=np.array([r[8] * 0.4 - 0.2, r[9] * 0.4 - 0.2, 0.5 + r[10]], np.float32),
+                         centroid_2d=np.array([0.5 * (x1 + x2) + 3 * r[11], 0.5 * (y1 + y2) - 2 * r[11]])))
+    return dict(frames=frames, rois=rois, extents=extents, fps_points=fps)
+
+
+def make_region_inputs(B=4, res=64, nfps=64):
+    """Inputs of golden G8 (``xyz_to_region``): cropped object-coordinate maps [B][res][res][3] fp32 with background
+    holes, and fps points [B][nfps][3]; batch 1 has a duplicated fps point (argmin tie -> first index) and batch 2
+    is all background."""
+    u = lambda tag, *shape: hash_uniform(83, tag, shape)  # noqa: E731
+    ext = (0.05 + 0.25 * u("ext", B, 3))
+    xyz = ((u("xyz", B, res, res, 3) - 0.5) * ext[:, None, None, :]).astype(np.float32)
+    xyz[u("hole", B, res, res) < 0.35] = 0
+    fps = (u("fps", B, nfps, 3) - 0.5) * ext[:, None, :]
+    if B > 1:
+        fps[1, 7] = fps[1, 3]
+        xyz[1, 0, 0] = fps[1, 3].astype(np.float32)
+    if B > 2:
+        xyz[2] = 0
+    return dict(xyz=xyz, fps_points=fps)

@@ -343,6 +343,50 @@ int gdrn_correspondences(const float* mask, const float* coor_x, const float* co
                          int pix_stride, const float* coord2d, const float* extents, const float* im_hw, float mask_thr, int N,
                          int HW, float* out_mask, float* out_xyz, float* img_pts, float* model_pts, int* counts, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GPU RoI cropper / target builder: what the reference's data loader does per instance on
+ * the host with cv2 + numpy, for a whole batch of RoIs cut from frames that are already resident in HBM.
+ *   replaces  crop_resize_by_warp_affine / get_affine_transform     core/utils/data_utils.py:80-137
+ *             roi_img + normalize_image, roi_coord_2d                core/gdrn_modeling/data_loader.py:425-439, 487-498;
+ *                                                                     core/base_data_loader.py:114-118
+ *             roi_mask_{trunc,visib,obj}, roi_xyz, xyz_to_region,    data_loader.py:460-545, 617-632;
+ *             roi_wh / resize_ratio / trans_ratio                     core/utils/data_utils.py:213-219
+ * cv2.getAffineTransform / cv2.warpAffine (INTER_LINEAR on u8 and fp32, INTER_NEAREST, BORDER_CONSTANT 0) are followed
+ * operation by operation (double LU + inversion, 10-bit fixed-point walk, 1/32-pixel bilinear table), rot = 0.
+ * One gdrn_roi_task per RoI, as a device array.  Train-only members may be NULL / 0 when only gdrn_roi_crop_inputs is
+ * used (test mode). */
+/*   image     [H][W][3] u8 frame (the reference reads BGR) this RoI is cut from
+ *   coord2d   [H][W][2] fp32 get_2d_coord_np(W, H, fmt="HWC") of that frame size
+ *   xyz_crop  [y2-y1+1][x2-x1+1][3] fp32 object coordinates (xyz_info["xyz_crop"]); x1..y2 = xyz_info["xyxy"], inclusive (train)
+ *   seg       [H][W] u8 0/1 visible-instance mask (anno["segmentation"]) (train)
+ *   trunc     [H][W] u8 0/1 mask from background replacement, or NULL: mask_trunc = mask_visib (train)
+ *   cx, cy, scale   bbox_center and the (clamped) square crop size in source pixels
+ *   bw, bh          max(x2 - x1, 1), max(y2 - y1, 1) of the annotated box
+ *   ox, oy, tz      anno["centroid_2d"] and trans[2] (train);  cls = row of fps_points / extents */
+typedef struct gdrn_roi_task {
+    const unsigned char* image;
+    const float* coord2d;
+    const float* xyz_crop;
+    const unsigned char* seg;
+    const unsigned char* trunc;
+    double cx, cy, scale, bw, bh, ox, oy, tz;
+    int H, W, x1, y1, x2, y2, cls, pad_;
+} gdrn_roi_task;
+/* minv [B][2][6] doubles: warpAffine's inverted 2x3 matrix (destination pixel -> source position) for the in_res and the
+ * out_res crop of every RoI;  roi_wh [B][2], resize_ratio [B], trans_ratio [B][3] fp32 (each may be NULL). */
+int gdrn_roi_affine(const gdrn_roi_task* tasks_dev, int B, int in_res, int out_res, double* minv, float* roi_wh, float* resize_ratio,
+                    float* trans_ratio, void* stream);
+/* roi_img [B][3][in_res][in_res] = (bilinear u8 crop - pixel_mean) / pixel_std (host arrays of 3 doubles, evaluated in
+ * double like numpy);  roi_coord_2d [B][2][out_res][out_res] bilinear fp32 crop.  Either output may be NULL. */
+int gdrn_roi_crop_inputs(const gdrn_roi_task* tasks_dev, const double* minv, int B, int in_res, int out_res, const double* pixel_mean,
+                         const double* pixel_std, float* roi_img, float* roi_coord_2d, void* stream);
+/* Train-mode targets at out_res (nearest crops): roi_xyz [B][3][r][r] = xyz / extent + 0.5, roi_mask_* [B][r][r] fp32,
+ * roi_region [B][r][r] int32 = 1 + argmin_k |xyz - fps_points[cls][k]| on object pixels, 0 elsewhere (NULL together with
+ * fps_points when NUM_REGIONS <= 1).  fps_points [ncls][nfps][3] double, extents [ncls][3] fp32, device arrays. */
+int gdrn_roi_targets(const gdrn_roi_task* tasks_dev, const double* minv, int B, int out_res, const double* fps_points, int nfps,
+                     const float* extents, float* roi_xyz, float* roi_mask_trunc, float* roi_mask_visib, float* roi_mask_obj,
+                     int* roi_region, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,8 +375,33 @@ def main():
         g[f"img_pts{i}"], g[f"model_pts{i}"] = np.asarray(ip, np.float32), np.asarray(mp, np.float32)
         print("G7 roi", i, "correspondences:", len(ip))
     np.savez_compressed(os.path.join(out_dir, "g7_postproc.npz"), **g)
+    golden_g8(out_dir)
     print("wrote goldens to", out_dir)
 
 
+def golden_g8(out_dir):
+    """G8: the cv2-free arithmetic of the RoI target builder (N3) from the reference's own functions:
+    xyz_to_region (core/utils/data_utils.py:213-219, scipy cdist + argmin) and get_2d_coord_np (:222-241).
+    cv2.warpAffine / getAffineTransform cannot be run here (OpenCV is absent) -- that part stays unpinned."""
+    from core.utils.data_utils import get_2d_coord_np, xyz_to_region
+    from gdrnet_amd import synth
+
+    inp = synth.make_region_inputs()
+    g = {}
+    for i in range(inp["xyz"].shape[0]):
+        g[f"region{i}"] = xyz_to_region(inp["xyz"][i], inp["fps_points"][i]).astype(np.int32)
+        print("G8 region", i, "labels used:", len(np.unique(g[f"region{i}"])))
+    c = get_2d_coord_np(640, 480, fmt="HWC")
+    g["coord2d_640x480_row0"] = c[0, :, 0].copy()
+    g["coord2d_640x480_col0"] = c[:, 0, 1].copy()
+    g["coord2d_720x540_sum"] = np.array([get_2d_coord_np(720, 540).astype(np.float64).sum()])
+    np.savez_compressed(os.path.join(out_dir, "g8_roi_targets.npz"), **g)
+
+
 if __name__ == "__main__":
-    main()
+    if "--g8-only" in sys.argv:
+        install_shims()
+        sys.path.insert(0, REF)
+        golden_g8(HERE)
+    else:
+        main()

@@ -38,14 +38,15 @@ def test_struct_layouts_match_the_header():
     """field order of the ctypes mirrors == field order of the C structs."""
     txt = open(os.path.join(ROOT, "include", "gdrn_hip.h")).read()
     for cname, cls in (("gdrn_conv_params", cabi.ConvParams), ("gdrn_wgrad_params", cabi.WgradParams), ("gdrn_pose_params", cabi.PoseParams),
-                       ("gdrn_pack_task", cabi.PackTask), ("gdrn_ranger_task", cabi.RangerTask), ("gdrn_wreduce_task", cabi.WreduceTask)):
+                       ("gdrn_pack_task", cabi.PackTask), ("gdrn_ranger_task", cabi.RangerTask), ("gdrn_wreduce_task", cabi.WreduceTask),
+                       ("gdrn_roi_task", cabi.RoiTask)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
             decl = decl.strip()
             if not decl:
                 continue
-            names = re.sub(r"^(const\s+)?(void|float|int|double|long long)\s*\*?", "", decl)
+            names = re.sub(r"^(const\s+)?(void|float|int|double|long long|unsigned char)\s*\*?", "", decl)
             fields += [n.strip().lstrip("*").strip() for n in names.split(",")]
         assert fields == [f[0] for f in cls._fields_], cname
 
