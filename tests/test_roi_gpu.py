@@ -100,3 +100,27 @@ def test_roi_c_abi_argument_errors():
         crop([])
     with pytest.raises(cabi.GdrnHipError):
         crop([dict(image=torch.zeros(8, 8, 3, dtype=torch.uint8), bbox_center=(4, 4), scale=8.0, bbox=(0, 0, 8, 8))])
+
+
+def test_cropped_batch_feeds_the_model():
+    """the cropper's device tensors are the model's inputs / targets as they are (engine_utils.py:6-60 key mapping)."""
+    from gdrnet_amd import GDRN
+
+    B = 4
+    d = synth.make_roi_frames(B, seed=11)
+    out = _cropper(d)(_device_rois(d), train=True)
+    batch = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in synth.make_batch(B, seed=1).items()}
+    for k in ("roi_img", "roi_coord_2d", "roi_xyz", "roi_mask_trunc", "roi_mask_visib", "roi_mask_obj", "roi_region", "roi_wh", "resize_ratio",
+              "roi_cls", "roi_extent"):
+        assert out[k].shape == batch[k].shape, k
+        batch[k] = out[k]
+    batch["roi_center"], batch["roi_trans_ratio"] = out["bbox_center"], out["trans_ratio"]
+    cfg = lm13_cfg(device=DEV)
+    cfg.MODEL.CDPN.HIP_DTYPE = "bf16"
+    model, _ = GDRN.build_model_optimizer(cfg)
+    model.load_state_dict(synth.make_state_dict(0))
+    model.train()
+    _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    total = sum(loss_dict.values())
+    assert bool(torch.isfinite(total)) and len(loss_dict) == 8
+    total.backward()
