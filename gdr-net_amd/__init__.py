@@ -9,5 +9,8 @@ Imported as ``gdrnet_amd`` (see ``gdrnet_amd/__init__.py``).  Sub-modules:
 * ``GDRN``    -- drop-in for ``core/gdrn_modeling/models/GDRN.py`` (GDRN, build_model_optimizer)
 * ``ranger``  -- fused Ranger optimizer step on HIP
 * ``dist``    -- RCCL gradient all-reduce for the one-process-per-GPU data-parallel path
+* ``postproc`` -- on-device inference post-processing (correspondence extraction for PnP-RANSAC)
+* ``roi_data`` -- GPU RoI cropper / target builder (the data loader's warpAffine crops, masks, region labels)
+* ``checkpoint`` -- MyCheckpointer / PeriodicCheckpointer in the reference's file format
 """
 __version__ = "0.1.0"
