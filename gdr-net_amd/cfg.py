@@ -59,6 +59,8 @@ def _base():
         MODEL=dict(
             DEVICE="cuda",
             WEIGHTS="",
+            PIXEL_MEAN=[0, 0, 0],  # gdrn_base.py:12-13: images to [0, 1]
+            PIXEL_STD=[255.0, 255.0, 255.0],
             CDPN=dict(
                 NAME="GDRN",
                 TASK="rot",
@@ -139,7 +141,21 @@ def _base():
             BASE_LR=1e-4,
             WEIGHT_DECAY=0.0,
             OPTIMIZER_CFG=dict(type="Ranger", lr=1e-4, weight_decay=0),
+            # schedule: configs/_base_/common_base.py:106-124 overridden by configs/gdrn/lm/a6_cPnP_lm13.py:22-32
+            TOTAL_EPOCHS=160,
+            GAMMA=0.1,
+            LR_SCHEDULER_NAME="flat_and_anneal",
+            WARMUP_METHOD="linear",
+            WARMUP_FACTOR=0.001,
+            WARMUP_ITERS=1000,
+            ANNEAL_METHOD="cosine",
+            ANNEAL_POINT=0.72,
+            POLY_POWER=0.9,
+            REL_STEPS=(0.5, 0.75),
+            CHECKPOINT_PERIOD=5,
+            CHECKPOINT_BY_EPOCH=True,
         ),
+        INPUT=dict(DZI_PAD_SCALE=1.5, SMOOTH_XYZ=False),  # common_base.py:49,53; a6_cPnP_lm13.py:5
         TEST=dict(USE_PNP=False),
     )
 

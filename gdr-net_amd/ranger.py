@@ -6,6 +6,7 @@ checkpoints interchange.  The per-parameter Python arithmetic of the reference (
 launches per tensor x 148 tensors) is one ``gdrn_ranger_step`` launch per tensor here; the RAdam
 rectification scalars (ranger.py:154-186) are computed on the host exactly as the reference does.
 """
+import ctypes
 import math
 
 import torch
@@ -33,6 +34,10 @@ def radam_step_size(step, beta1, beta2, n_sma_threshold):
     else:
         step_size = 1.0 / (1 - beta1 ** step)
     return n_sma, step_size
+
+
+_TASK_WORDS = ctypes.sizeof(cabi.RangerTask) // 4  # gdrn_ranger_task as 32-bit words
+_LR_WORD = cabi.RangerTask.lr.offset // 4
 
 
 class Ranger(Optimizer):
@@ -71,12 +76,14 @@ class Ranger(Optimizer):
 
     def _multi_table(self, gi, items, lr):
         """device task table of one param group for gdrn_ranger_multi, cached on the buffers' addresses."""
-        key = (lr,) + tuple((p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["slow_buffer"].data_ptr())
-                            for p, g in items)
+        key = tuple((p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["slow_buffer"].data_ptr()) for p, g in items)
         cache = self.__dict__.setdefault("_multi_cache", {})
         hit = cache.get(gi)
         if hit is not None and hit[0] == key:
-            return hit[1:]
+            if hit[5] != lr:  # an LR schedule moved the rate: patch the `lr` member of every task on the device (one async fill)
+                hit[1].view(torch.float32)[_LR_WORD::_TASK_WORDS].fill_(lr)
+                cache[gi] = hit[:5] + (lr,)
+            return hit[1:5]
         tasks, starts = [], [0]
         for p, g in items:
             st = self.state[p]
@@ -87,8 +94,8 @@ class Ranger(Optimizer):
         dev = items[0][0].device
         tab = cabi.to_device_table(tasks, dev)
         stt = torch.tensor(starts, dtype=torch.int32, device=dev)
-        cache[gi] = (key, tab, stt, len(tasks), starts[-1])
-        return cache[gi][1:]
+        cache[gi] = (key, tab, stt, len(tasks), starts[-1], lr)
+        return cache[gi][1:5]
 
     @torch.no_grad()
     def step(self, closure=None, grads=None):

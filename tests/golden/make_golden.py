@@ -376,6 +376,7 @@ def main():
         print("G7 roi", i, "correspondences:", len(ip))
     np.savez_compressed(os.path.join(out_dir, "g7_postproc.npz"), **g)
     golden_g8(out_dir)
+    golden_g9(out_dir)
     print("wrote goldens to", out_dir)
 
 
@@ -398,8 +399,42 @@ def golden_g8(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g8_roi_targets.npz"), **g)
 
 
+def golden_g9(out_dir):
+    """G9: LR schedules of the reference trainer (lib/torch_utils/solver/lr_scheduler.py:137-263) sampled over a
+    2000-iteration run: flat_and_anneal with every anneal method (the GDR-Net configs use cosine, a6_cPnP_lm13.py:22-32)
+    and WarmupMultiStepLR; stored: the learning rate the scheduler writes into param_groups[0] before each iteration."""
+    from lib.torch_utils.solver.lr_scheduler import WarmupMultiStepLR, flat_and_anneal_lr_scheduler
+
+    total, g = 2000, {}
+
+    def run(make):
+        p = [torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD(p, lr=1e-4)
+        sch = make(opt)
+        lrs = []
+        for _ in range(total):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return np.array(lrs, np.float64)
+
+    for m in ("cosine", "linear", "poly", "exp", "step", "none"):
+        g["flat_" + m] = run(lambda o: flat_and_anneal_lr_scheduler(
+            o, total_iters=total, warmup_iters=100, warmup_factor=0.001, warmup_method="linear", anneal_point=0.72, anneal_method=m,
+            target_lr_factor=0.05 if m != "cosine" else 0, poly_power=0.9, step_gamma=0.1, steps=[0.5, 0.75]))
+    g["flat_cosine_constwarm"] = run(lambda o: flat_and_anneal_lr_scheduler(
+        o, total_iters=total, warmup_iters=50, warmup_factor=0.1, warmup_method="constant", anneal_point=0.5, anneal_method="cosine"))
+    g["multistep"] = run(lambda o: WarmupMultiStepLR(o, [1000.0, 1500.0], 0.1, warmup_factor=0.001, warmup_iters=100, warmup_method="linear"))
+    np.savez_compressed(os.path.join(out_dir, "g9_lr_schedules.npz"), **g)
+    print("G9:", {k: (float(v[0]), float(v[-1])) for k, v in g.items()})
+
+
 if __name__ == "__main__":
-    if "--g8-only" in sys.argv:
+    if "--g9-only" in sys.argv:
+        install_shims()
+        sys.path.insert(0, REF)
+        golden_g9(HERE)
+    elif "--g8-only" in sys.argv:
         install_shims()
         sys.path.insert(0, REF)
         golden_g8(HERE)

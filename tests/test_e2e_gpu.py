@@ -235,6 +235,39 @@ def test_ranger_vs_reference_golden(golden_dir, multi):
             np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"step{step}/p{i}"], rtol=2e-5, atol=2e-7)
 
 
+def test_ranger_follows_an_lr_schedule_without_rebuilding_its_table():
+    """an LR schedule changes param_group["lr"] every iteration: the multi-tensor path patches the rate into its cached device task
+    table (one async fill) and must stay bit-identical to the per-tensor path, which takes the rate as a launch argument."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.ranger import Ranger
+    from gdrnet_amd.solver import flat_and_anneal_lr_scheduler
+
+    def run(multi):
+        ps = [torch.nn.Parameter(torch.from_numpy(synth.hash_normal(41, f"p{i}", s).astype(np.float32)).to(DEV))
+              for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
+        opt = Ranger(ps if multi else [{"params": [p]} for p in ps], lr=1e-2, weight_decay=1e-3)
+        sch = flat_and_anneal_lr_scheduler(opt, total_iters=12, warmup_iters=4, warmup_factor=0.01, anneal_point=0.5, anneal_method="cosine")
+        lrs = []
+        for step in range(12):
+            for i, p in enumerate(ps):
+                p.grad = torch.from_numpy(synth.hash_normal(42 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+            if multi:
+                tabs.add(opt._multi_cache[0][1].data_ptr())
+        return [p.detach().cpu() for p in ps], lrs
+
+    tabs = set()
+    pm, lrs = run(True)
+    pt, lrs_t = run(False)
+    assert lrs == lrs_t and len(set(lrs)) > 8  # the rate really moved
+    assert len(tabs) == 1  # ... and the device table was built once
+    for a, b in zip(pm, pt):
+        assert torch.equal(a, b)
+
+
 def test_full_size_properties_bs64():
     """BASELINE config 2 (bs=64, bf16): size-independent properties instead of an oracle run --
     finite losses / gradients, R in SO(3), losses invariant to the order of the RoIs in the batch
