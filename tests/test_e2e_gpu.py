@@ -251,7 +251,11 @@ def test_ranger_follows_an_lr_schedule_without_rebuilding_its_table():
         lrs = []
         for step in range(12):
             for i, p in enumerate(ps):
-                p.grad = torch.from_numpy(synth.hash_normal(42 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)
+                g = torch.from_numpy(synth.hash_normal(42 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)
+                if p.grad is None:
+                    p.grad = g  # the table is keyed on the buffer addresses: keep the gradient buffers, as the engine does
+                else:
+                    p.grad.copy_(g)
             lrs.append(opt.param_groups[0]["lr"])
             opt.step()
             sch.step()
