@@ -147,6 +147,28 @@ def measure_roofline(model, plan, kctx, dtype):
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "event_overhead_us": round(ovh_ms * 1e3, 2)}
 
 
+def roi_cropper_extras(B, dev, timed):
+    """the GPU RoI cropper / target builder that feeds the path -- train-mode batch of B RoIs cut from synthetic
+    640x480 / 720x540 frames resident in HBM (launches only; the per-RoI task table is prepared once, as a loader thread would)."""
+    import torch
+
+    from gdrnet_amd import roi_data, synth
+    from gdrnet_amd.cfg import lm13_cfg
+
+    d = synth.make_roi_frames(B, seed=9)
+    frames = [torch.from_numpy(f).to(dev) for f in d["frames"]]
+    rois = []
+    for r in d["rois"]:
+        q = dict(r)
+        q.update(image=frames[r["frame"]], xyz_crop=torch.from_numpy(r["xyz_crop"]).to(dev), segmentation=torch.from_numpy(r["segmentation"]).to(dev),
+                 mask_trunc=None if r["mask_trunc"] is None else torch.from_numpy(r["mask_trunc"]).to(dev))
+        rois.append(q)
+    crop = roi_data.RoiCropper(lm13_cfg(device=dev), extents=d["extents"], fps_points=d["fps_points"], device=dev)
+    prep = crop.prepare(rois, train=True)
+    t = timed(lambda: crop.launch(prep), 50)
+    return {"roi_cropper_train_targets_roi_s": round(B / t, 0), "roi_cropper_us_per_batch": round(t * 1e6, 1)}
+
+
 def main():
     args = parse()
     import torch
@@ -239,6 +261,7 @@ def main():
         also = {"fwd_bwd_without_optimizer_roi_s": round(B / t_noopt, 1), "fwd_bwd_without_optimizer_ms": round(t_noopt * 1e3, 3),
                 "inference_fwd_roi_s": round(B / t_inf, 1), "inference_fwd_ms": round(t_inf * 1e3, 3),
                 "inference_fwd_tflops": round(B / t_inf * 22.823e9 / 1e12, 1)}
+        also.update(roi_cropper_extras(B, dev, timed))
 
     if rank == 0:
         ms = dt / args.steps * 1e3

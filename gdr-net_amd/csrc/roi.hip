@@ -245,12 +245,19 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(const gdrn_roi_task* _
     m_visib[o] = visib;
     m_trunc[o] = tk.trunc ? visib * trunc : visib;
     if (region) {
+        // first index of min_k sqrt(d2_k), as numpy's argmin over scipy's cdist.  sqrt is monotone, so the running minimum of the
+        // distances is sqrt(running minimum of d2): only a candidate with a strictly smaller d2 can lower it, and it takes the
+        // label only if its ROUNDED distance is strictly smaller too (two different d2 may round to one distance: first wins).
         int best = 0;
-        double bd = INFINITY;
+        double bd2 = INFINITY, bd = INFINITY;
         for (int k = 0; k < nfps; k++) {
             const double dx = (double)v[0] - fp[k * 3], dy = (double)v[1] - fp[k * 3 + 1], dz = (double)v[2] - fp[k * 3 + 2];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
-            if (d < bd) { bd = d; best = k; }
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < bd2) {
+                bd2 = d2;
+                const double d = sqrt(d2);
+                if (d < bd) { bd = d; best = k; }
+            }
         }
         region[o] = obj != 0.f ? best + 1 : 0;
     }
