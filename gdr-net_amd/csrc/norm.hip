@@ -273,11 +273,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
                                                                   const float* __restrict__ shift, T* __restrict__ y,
                                                                   unsigned char* __restrict__ idx, int N, int H, int W, int C) {
     constexpr int V = Vec16<T>::VEC;
+    __shared__ float sc_s[512], sh_s[512];  // per-channel constants once per workgroup (dependent scalar loads per thread cost ~10 us)
+    for (int c = threadIdx.x; c < C; c += 256) { sc_s[c] = scale[c]; sh_s[c] = shift[c]; }
+    __syncthreads();
     const int Ho = H / 2, Wo = W / 2, cvn = C / V;
-    const long long total = (long long)N * Ho * Wo * cvn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)((long long)N * Ho * Wo * cvn);  // < 2^31, checked by the host wrapper: 32-bit index math
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvn);
-        long long t = i / cvn;
+        unsigned t = i / cvn;
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
@@ -294,13 +297,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
                 Vec16<T>::load(x + ((size_t)(n * H + iy) * W + ix) * C + cv * V, v);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    const float a = fmaxf(v[j] * scale[cv * V + j] + shift[cv * V + j], 0.f);
+                    const float a = fmaxf(v[j] * sc_s[cv * V + j] + sh_s[cv * V + j], 0.f);
                     if (a > best[j]) { best[j] = a; bi[j] = ky * 3 + kx; }
                 }
             }
         }
-        Vec16<T>::store(y + i * V, best);
-        unsigned char* ip = idx + i * V;
+        Vec16<T>::store(y + (size_t)i * V, best);
+        unsigned char* ip = idx + (size_t)i * V;
         if (V == 8) {
             uint2 pk;
             pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
@@ -318,11 +321,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ shift, T* __restrict__ g, int N, int H,
                                                           int W, int C) {
     constexpr int V = Vec16<T>::VEC;
+    __shared__ float sc_s[512], sh_s[512];
+    for (int c = threadIdx.x; c < C; c += 256) { sc_s[c] = scale[c]; sh_s[c] = shift[c]; }
+    __syncthreads();
     const int Ho = H / 2, Wo = W / 2, cvn = C / V;
-    const long long total = (long long)N * H * W * cvn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)((long long)N * H * W * cvn);  // < 2^31, checked by the host wrapper: 32-bit index math
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvn);
-        long long t = i / cvn;
+        unsigned t = i / cvn;
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
@@ -347,11 +353,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                 for (int j = 0; j < V; ++j) if (ip[j] == tap) acc[j] += d[j];
             }
         }
-        Vec16<T>::load(x + i * V, xv);
+        Vec16<T>::load(x + (size_t)i * V, xv);
 #pragma unroll
         for (int j = 0; j < V; ++j)
-            if (!(xv[j] * scale[cv * V + j] + shift[cv * V + j] > 0.f)) acc[j] = 0.f;
-        Vec16<T>::store(g + i * V, acc);
+            if (!(xv[j] * sc_s[cv * V + j] + sh_s[cv * V + j] > 0.f)) acc[j] = 0.f;
+        Vec16<T>::store(g + (size_t)i * V, acc);
     }
 }
 
@@ -362,10 +368,10 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
     constexpr int V = Vec16<T>::VEC;
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
     const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
-    const long long total = (long long)N * Ho * Wo * cvn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)((long long)N * Ho * Wo * cvn);  // < 2^31, checked by the host wrapper: 32-bit index math
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvn);
-        long long t = i / cvn;
+        unsigned t = i / cvn;
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
         Vec16<T>::load(b + ((size_t)yp * W + xp) * C, a11);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
-        Vec16<T>::store(y + i * V, o);
+        Vec16<T>::store(y + (size_t)i * V, o);
     }
 }
 
@@ -401,10 +407,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
     constexpr int V = Vec16<T>::VEC;
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
     const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
-    const long long total = (long long)N * H * W * cvn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned total = (unsigned)((long long)N * H * W * cvn);  // < 2^31, checked by the host wrapper: 32-bit index math
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int cv = (int)(i % cvn);
-        long long t = i / cvn;
+        unsigned t = i / cvn;
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
                 for (int j = 0; j < V; ++j) acc[j] += w * d[j];
             }
         }
-        Vec16<T>::store(dx + i * V, acc);
+        Vec16<T>::store(dx + (size_t)i * V, acc);
     }
 }
 
@@ -731,6 +737,7 @@ extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* 
 extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
                                         int N, int H, int W, int C, int dtype, void* stream) {
     if (!x || !scale || !shift || !y || !idx || N <= 0 || (H & 1) || (W & 1) || (C % 8)) return GDRN_ERR_ARG;
+    if (C > 512 || (long long)N * H * W * C / 4 >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * (H / 2) * (W / 2) * C;
     DISPATCH(dtype,
              hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x,
@@ -744,6 +751,7 @@ extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const
 extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale,
                                 const float* shift, void* g, int N, int H, int W, int C, int dtype, void* stream) {
     if (!dy || !idx || !x || !scale || !shift || !g || N <= 0 || (H & 1) || (W & 1) || (C % 8)) return GDRN_ERR_ARG;
+    if (C > 512 || (long long)N * H * W * C / 4 >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * H * W * C;
     DISPATCH(dtype,
              hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, idx,
@@ -756,6 +764,7 @@ extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const 
 
 extern "C" int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
     if (!x || !y || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
+    if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;  // 4x upsampled element count / 4 per thread, 32-bit index math
     const long long n = (long long)N * 4 * H * W * C;
     DISPATCH(dtype,
              hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C),
@@ -766,6 +775,7 @@ extern "C" int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, 
 
 extern "C" int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
     if (!dy || !dx || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
+    if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * H * W * C;
     DISPATCH(dtype,
              hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (float*)dx, N, H, W, C),
