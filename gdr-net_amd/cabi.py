@@ -94,6 +94,8 @@ _SIGS = {
     "gdrn_pack_stem_w32": [P, P, I, P],
     "gdrn_stem_stats_rows": [I],
     "gdrn_stem_conv": [P, P, P, P, I, I, P],
+    "gdrn_stem_wgrad_parts": [I],
+    "gdrn_stem_wgrad": [P, P, P, P, P, P, P, P, P, I, P, P, I, P],
     "gdrn_linear_splitk": [P, P, P, P, I, I, I, I, I, I, I, P, I, P],
     "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],

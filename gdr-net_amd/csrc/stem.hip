@@ -96,7 +96,195 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
 
 constexpr int STEM_WAVES = 4096;  // 1024 workgroups
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem weight gradient fused with the BatchNorm-backward "apply" that precedes it.  The stem has no data gradient, so the
+// gradient w.r.t. the conv output, dy = a*g + (b*x + c) per channel (bn_bwd_apply_kernel's formula, rounded to bf16 as that
+// kernel stores it), is consumed by this weight gradient only: it is evaluated here while the tile is staged, instead of
+// being written (134 MB at bs = 64) and read back seven times by the generic per-tap weight-gradient tiles.
+//   dW[co][ky][n = kx*4 + c] = sum_{pixels} dy[pixel][co] * canvas[2oy + ky][2ox*4 + n]        (n < 32, kx = 7 / c = 3 unused)
+// A stage = 64 consecutive output pixels of one row: dy^T fragments through the LDS transpose read from a [64 px][64 co]
+// tile; the seven canvas rows are kept as contiguous 1072-byte spans and read as a [pixel][32] operand with a 16-byte row
+// pitch (row p starts at pixel 2*p = 16 B further: the overlap IS the stride-2 window).  A wave owns 16 output channels x
+// all 224 columns (14 accumulator tiles); workgroups own contiguous stage ranges and leave fp32 partials [wg][64][224].
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+constexpr int SW_PA = 160;              // dy tile pitch (128 B + 32 B pad, as conv_wgrad.hip)
+constexpr int SW_SPAN = 1088;           // 67 segments of 16 B used, 68 allocated
+constexpr int SW_TILE = 64 * SW_PA + 7 * SW_SPAN;  // one stage buffer
+constexpr int SW_PARTS = 512;
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __restrict__ canvas, const bf16_t* __restrict__ gg,
+                                                            const bf16_t* __restrict__ raw, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ sums, float inv_n, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nstages, int per, float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SW_TILE];
+    __shared__ float kst[3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    if (tid < 64) {
+        float a = 1.f, b = 0.f, c = 0.f;
+        if (mean != nullptr) {
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < GDRN_BN_SUM_COPIES; ++r) { m1 += sums[r * 128 + tid]; m2 += sums[r * 128 + 64 + tid]; }
+            if (blockIdx.x == 0 && dgamma != nullptr) { dbeta[tid] = m1; dgamma[tid] = m2; }
+            m1 *= inv_n;
+            m2 *= inv_n;
+            const float is = invstd[tid];
+            a = gamma[tid] * is;
+            b = -a * is * m2;
+            c = -a * m1 - b * mean[tid];
+        }
+        kst[0][tid] = a; kst[1][tid] = b; kst[2][tid] = c;
+    }
+    __syncthreads();
+    const int segA = tid & 7, rowA = tid >> 3;  // this thread's 16-byte channel segment / first pixel row of the dy tile
+    float ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ka[j] = kst[0][segA * 8 + j]; kb[j] = kst[1][segA * 8 + j]; kc[j] = kst[2][segA * 8 + j]; }
+    const bool fused = mean != nullptr;
+
+    const int s_begin = blockIdx.x * per, s_end = min(nstages, s_begin + per);
+    uint4 rg[2], rx[2], rc[2];
+    auto load_stage = [&](int s) {
+        // stage s -> (image n, output row oy, half h): pixels (n, oy, h*64 .. h*64+63)
+        const int h = s & 1, oy = (s >> 1) & 127, n = s >> 8;
+        const size_t p0 = ((size_t)(n * 128 + oy) * 128 + h * 64) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t o = p0 + (size_t)(rowA + 32 * i) * 64 + segA * 8;
+            rg[i] = *reinterpret_cast<const uint4*>(gg + o);
+            rx[i] = fused ? *reinterpret_cast<const uint4*>(raw + o) : make_uint4(0, 0, 0, 0);
+        }
+        const bf16_t* cb = canvas + ((size_t)(n * HP + 2 * oy) * WP + 2 * (h * 64)) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = min(tid + 256 * i, 7 * 67 - 1);
+            const int ky = id / 67, sg = id - ky * 67;
+            rc[i] = *reinterpret_cast<const uint4*>(cb + (size_t)ky * WP * 4 + sg * 8);
+        }
+    };
+    auto write_stage = [&](int buf) {
+        unsigned char* tA = smem + buf * SW_TILE;
+        unsigned char* tX = tA + 64 * SW_PA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint4 v = rg[i];
+            if (fused) {
+                float gv[8], xv[8], o[8];
+                Vec16<bf16_t>::unpack(rg[i], gv);
+                Vec16<bf16_t>::unpack(rx[i], xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = ka[j] * gv[j] + (kb[j] * xv[j] + kc[j]);
+                v = Vec16<bf16_t>::pack(o);
+            }
+            *reinterpret_cast<uint4*>(tA + (rowA + 32 * i) * SW_PA + segA * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i;
+            if (id < 7 * 67) {
+                const int ky = id / 67, sg = id - ky * 67;
+                *reinterpret_cast<uint4*>(tX + ky * SW_SPAN + sg * 16) = rc[i];
+            }
+        }
+    };
+
+    f32x4_t acc[7][2];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) { acc[ky][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[ky][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    if (s_begin < s_end) {
+        load_stage(s_begin);
+        write_stage(0);
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_stage(s + 1);
+        const unsigned char* tA = smem + buf * SW_TILE;
+        const unsigned char* tX = tA + 64 * SW_PA;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // transpose-read map of conv_wgrad.hip: lane group g takes reduction rows {4g..4g+3} and {16+4g..} of the k-step
+            const int trow = ks * 32 + g * 4 + (r16 >> 2), tcol = (r16 & 3) * 4;
+            const unsigned char* qa = tA + trow * SW_PA + (wave * 16 + tcol) * 2;
+            const bf16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qa));
+            const bf16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qa + 16 * SW_PA));
+            const bf16x8_t fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    const unsigned char* qb = tX + ky * SW_SPAN + trow * 16 + (nf * 16 + tcol) * 2;
+                    const bf16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qb));
+                    const bf16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qb + 16 * 16));
+                    const bf16x8_t fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[ky][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[ky][nf], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < s_end) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i = g*4 + j -> co = wave*16 + i][col = r16 -> n = nf*16 + r16]; every workgroup writes its slab (zeros if it had no stage)
+    float* slab = ws + (size_t)blockIdx.x * 64 * 224;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[(wave * 16 + g * 4 + j) * 224 + ky * 32 + nf * 16 + r16] = acc[ky][nf][j];
+}
+
+// grad OIHW [64][3][7][7] = sum over the partial slabs; one workgroup per output channel
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ ws, int parts, float* __restrict__ grad) {
+    const int co = blockIdx.x, e = threadIdx.x;
+    if (e >= 224) return;
+    const float* p = ws + (size_t)co * 224 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = 0;
+    for (; q + 4 <= parts; q += 4) {
+        s0 += p[(size_t)(q + 0) * 64 * 224];
+        s1 += p[(size_t)(q + 1) * 64 * 224];
+        s2 += p[(size_t)(q + 2) * 64 * 224];
+        s3 += p[(size_t)(q + 3) * 64 * 224];
+    }
+    for (; q < parts; ++q) s0 += p[(size_t)q * 64 * 224];
+    const int ky = e >> 5, kx = (e >> 2) & 7, c = e & 3;
+    if (kx < 7 && c < 3) grad[((co * 3 + c) * 7 + ky) * 7 + kx] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace
+
+extern "C" int gdrn_stem_wgrad_parts(int N) {
+    const int nstages = N * 256;
+    const int per = cdiv(nstages, SW_PARTS);
+    return cdiv(nstages, per);
+}
+
+// Weight gradient of the stem conv, fused with the BatchNorm-backward apply in front of it (mean != NULL): see above.
+//   canvas [N][262][272][4] bf16; g, raw [N][128][128][64] bf16 (masked upstream gradient / the conv output BatchNorm saw);
+//   mean, invstd, gamma [64]; sums [GDRN_BN_SUM_COPIES][2][64] from gdrn_bn_bwd_reduce; dgamma, dbeta [64] (nullable) written here
+//   as gdrn_bn_bwd_apply does; mean == NULL: plain weight gradient with dy = g.
+//   ws: gdrn_stem_wgrad_parts(N) x 64 x 224 floats of scratch; grad: fp32 OIHW [64][3][7][7], overwritten.
+extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* mean, const float* invstd, const float* gamma,
+                               const float* sums, float* dgamma, float* dbeta, int N, float* ws, float* grad, int dtype, void* stream) {
+    if (!canvas || !g || !ws || !grad || N <= 0) return GDRN_ERR_ARG;
+    if (mean != nullptr && (!raw || !invstd || !gamma || !sums)) return GDRN_ERR_ARG;
+    if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
+    if ((long long)N * 128 * 128 * 64 >= (1ll << 40)) return GDRN_ERR_SHAPE;
+    const int nstages = N * 256;
+    const int per = cdiv(nstages, SW_PARTS);
+    const int parts = cdiv(nstages, per);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(parts), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(g),
+                       reinterpret_cast<const bf16_t*>(raw), mean, invstd, gamma, sums, 1.0f / ((float)N * 128.f * 128.f), dgamma, dbeta, nstages,
+                       per, ws);
+    GDRN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, ws, parts, grad);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
 
 extern "C" int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream) {
     if (!w || !dst) return GDRN_ERR_ARG;

@@ -52,6 +52,7 @@ class Engine:
         self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
         self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "0") == "1"  # bucket-end work on a 2nd stream (measured: no gain on one GPU)
         self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
+        self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
         self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
@@ -687,9 +688,27 @@ class Plan:
             d_raw0 = g_stem  # in place
             grp = [lambda st, ctx: check(lib.gdrn_maxpool_bwd(ptr(d_p0), ptr(idx0), ptr(raw0), ptr(s0.scale), ptr(s0.shift),
                                                               ptr(g_stem), B, 128, 128, 64, e.dt, st), "maxpool_bwd")]
-            grp += self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0)
-            grp.append(self._wgrad(Ls, self.img_p, d_raw0, 262, 272, 128, 128, 2, 0, 64, 64, 4, 64, KH=7, KW=1))
-            grp.append(self._unpack(Ls))
+            if e.stem_wgrad:
+                # the stem has no data gradient: its BatchNorm-backward apply is evaluated inside the weight-gradient kernel while
+                # the dy tile is staged (no 134 MB d_raw0 round trip, dy read once instead of once per kernel row)
+                sb = self.bn["backbone.bn1"]
+                gam, dgam, dbet = e.P["backbone.bn1.weight"], e.grads["backbone.bn1.weight"], e.grads["backbone.bn1.bias"]
+                gw = e.grads["backbone.conv1.weight"]
+                assert gw.is_contiguous() and gw.dtype == torch.float32
+                sw_ws = e._empty(int(lib.gdrn_stem_wgrad_parts(B)) * 64 * 224, dtype=torch.float32)
+                grp.append(self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0)[0])  # the reduce; the apply is fused below
+
+                def stem_wgrad(st, ctx, a=(self.img_p, g_stem, raw0, sb.mean, sb.invstd, gam, sb.sums, dgam, dbet, sw_ws, gw)):
+                    # tensors bound as a default argument: _build() reuses short local names further down (late-binding closures)
+                    check(lib.gdrn_stem_wgrad(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), ptr(a[6]), ptr(a[7]), ptr(a[8]), B,
+                                              ptr(a[9]), ptr(a[10]), e.dt, st), "stem_wgrad")
+
+                stem_wgrad.meta = dict(kernel="stem_wgrad_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1:wgrad")
+                grp.append(stem_wgrad)
+            else:
+                grp += self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0)
+                grp.append(self._wgrad(Ls, self.img_p, d_raw0, 262, 272, 128, 128, 2, 0, 64, 64, 4, 64, KH=7, KW=1))
+                grp.append(self._unpack(Ls))
             self.bwd_groups.append(grp)
         else:
             d_p0 = None

@@ -89,6 +89,16 @@ int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
 int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream);
 int gdrn_stem_stats_rows(int N);
 int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, int N, int dtype, void* stream);
+/* Stem weight gradient (backward-weight of nn.Conv2d(3, 64, 7, 2, 3), resnet_backbone.py:23, implicit in engine.py:279) fused with
+ * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel
+ * (gdrn_bn_bwd_apply's formula, rounded to bf16) is evaluated while the tile is staged instead of being written and re-read.
+ *   canvas [N][262][272][4] bf16; g, raw [N][128][128][64] bf16 (masked upstream gradient / the conv output BatchNorm saw);
+ *   mean, invstd, gamma [64]; sums [GDRN_BN_SUM_COPIES][2][64] from gdrn_bn_bwd_reduce; dgamma, dbeta [64] (nullable) are written
+ *   as gdrn_bn_bwd_apply writes them.  mean == NULL: plain weight gradient with dy = g (raw .. dbeta ignored).
+ *   ws: gdrn_stem_wgrad_parts(N) * 64 * 224 floats of scratch; grad: fp32 OIHW [64][3][7][7], overwritten.  bf16 only. */
+int gdrn_stem_wgrad_parts(int N);
+int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* mean, const float* invstd, const float* gamma,
+                    const float* sums, float* dgamma, float* dbeta, int N, float* ws, float* grad, int dtype, void* stream);
 /* Skinny-M linear layer (M <= 64 rows, bf16): y[m][n] = act(sum_k x[m][k]*w[n][k] + bias[n]) with the K range split
  * over workgroups (the layer is bound by reading w once).  Replaces F.linear + LeakyReLU of Patch-PnP's fc1
  * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in

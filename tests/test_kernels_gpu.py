@@ -643,3 +643,52 @@ def test_stem_conv_direct(H, B):
     assert H.rel(H.nchw(y), ref) < TOL[dt]
     s = stats.double().sum(0).cpu()
     assert H.rel(s[0].float(), ref.sum((0, 2, 3))) < 2e-3 + 1e-2 and H.rel(s[1].float(), (ref ** 2).sum((0, 2, 3))) < 1e-2
+
+
+@pytest.mark.parametrize("B,fused", [(1, False), (3, True), (2, True)])
+def test_stem_wgrad_fused_bn_backward(H, B, fused):
+    """dedicated stem weight gradient == autograd's conv weight gradient, with dy either given (fused=False) or evaluated on the
+    fly as the BatchNorm-backward apply dy = a*g + (b*raw + c) (bn_bwd_apply's formula, bf16-rounded), incl. dgamma / dbeta."""
+    lib = cabi.load()
+    dev, dt = H.DEV, BF16
+    gen = torch.Generator().manual_seed(11 + B)
+    img = torch.rand(B, 3, 256, 256, generator=gen)
+    g = H.rounded(torch.randn(B, 64, 128, 128, generator=gen) * 0.1, dt)
+    raw = H.rounded(torch.randn(B, 64, 128, 128, generator=gen), dt)
+    canvas = torch.zeros(B, 262, 272, 4, dtype=torch.bfloat16, device=dev)
+    imgd = img.to(dev).contiguous()
+    check(lib.gdrn_pack_image(ptr(imgd), ptr(canvas), B, 256, 256, 262, 272, dt, H.stream()), "pack_image")
+    gd, rawd = H.nhwc(g, dt), H.nhwc(raw, dt)
+    npix = B * 128 * 128
+    mean, invstd, gamma = torch.randn(64, generator=gen) * 0.1, 0.5 + torch.rand(64, generator=gen), 0.5 + torch.rand(64, generator=gen)
+    if fused:
+        s1 = g.sum((0, 2, 3))
+        s2 = (g * (raw - mean[None, :, None, None]) * invstd[None, :, None, None]).sum((0, 2, 3))
+        a = gamma * invstd
+        b = -a * invstd * (s2 / npix)
+        c = -a * (s1 / npix) - b * mean
+        dy = H.rounded(a[None, :, None, None] * g + (b[None, :, None, None] * raw + c[None, :, None, None]), dt)
+        sums = torch.zeros(16, 2, 64)
+        sums[3, 0], sums[5, 1] = s1 * 0.25, s2 * 0.5  # spread over the copies: the kernel adds them up
+        sums[9, 0], sums[0, 1] = s1 * 0.75, s2 * 0.5
+    else:
+        dy = g
+    x = H.rounded(img, dt).requires_grad_(False)
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    (F.conv2d(x, w, None, 2, 3) * dy).sum().backward()
+    parts = lib.gdrn_stem_wgrad_parts(B)
+    ws = torch.full((parts * 64 * 224,), float("nan"), dtype=torch.float32, device=dev)
+    grad = torch.full((64, 3, 7, 7), float("nan"), dtype=torch.float32, device=dev)
+    dgam = torch.full((64,), float("nan"), dtype=torch.float32, device=dev)
+    dbet = torch.full((64,), float("nan"), dtype=torch.float32, device=dev)
+    if fused:
+        md, isd, gmd, sd = mean.to(dev), invstd.to(dev), gamma.to(dev), sums.to(dev).contiguous()
+        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), ptr(rawd), ptr(md), ptr(isd), ptr(gmd), ptr(sd), ptr(dgam), ptr(dbet), B, ptr(ws), ptr(grad),
+                                  dt, H.stream()), "stem_wgrad")
+    else:
+        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, None, None, None, None, None, None, B, ptr(ws), ptr(grad), dt, H.stream()), "stem_wgrad")
+    torch.cuda.synchronize()
+    assert H.rel(grad.cpu(), w.grad) < (4e-3 if fused else 1e-4)  # fused: dy is re-rounded to bf16 from fp32 constants
+    if fused:
+        assert H.rel(dbet.cpu(), s1) < 1e-5 and H.rel(dgam.cpu(), s2) < 1e-5
+    assert lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, ptr(dgam), None, None, None, None, None, B, ptr(ws), ptr(grad), dt, H.stream()) == -1
