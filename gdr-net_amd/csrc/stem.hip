@@ -144,63 +144,51 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __rest
     const bool fused = mean != nullptr;
 
     const int s_begin = blockIdx.x * per, s_end = min(nstages, s_begin + per);
-    uint4 rg[2], rx[2], rc[2];
-    auto load_stage = [&](int s) {
-        // stage s -> (image n, output row oy, half h): pixels (n, oy, h*64 .. h*64+63)
-        const int h = s & 1, oy = (s >> 1) & 127, n = s >> 8;
-        const size_t p0 = ((size_t)(n * 128 + oy) * 128 + h * 64) * 64;
+    // two register sets: the loads of stage s+2 are issued before the MFMAs of stage s.  Named registers and macros, not arrays
+    // behind lambda pointers: hipcc put those in scratch (80 B / lane, a scratch round trip per stage).
+    uint4 g0a, g0b, x0a, x0b, c0a, c0b, g1a, g1b, x1a, x1b, c1a, c1b;
+    const int cid0 = tid, cid1 = min(tid + 256, 7 * 67 - 1);
+    const int cky0 = cid0 / 67, cky1 = cid1 / 67;
+    const unsigned coff0 = (unsigned)(cky0 * WP * 4 + (cid0 - cky0 * 67) * 8), coff1 = (unsigned)(cky1 * WP * 4 + (cid1 - cky1 * 67) * 8);
+    const int cdst0 = cky0 * SW_SPAN + (cid0 - cky0 * 67) * 16, cdst1 = (tid + 256 < 7 * 67) ? cky1 * SW_SPAN + (cid1 - cky1 * 67) * 16 : -1;
+    const unsigned aoff0 = (unsigned)(rowA * 64 + segA * 8), aoff1 = (unsigned)((rowA + 32) * 64 + segA * 8);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define SW_LOAD(S_, GA, GB, XA, XB, CA, CB)                                                                      \
+    {                                                                                                            \
+        const int h_ = (S_) & 1, oy_ = ((S_) >> 1) & 127, n_ = (S_) >> 8;                                        \
+        const size_t p0_ = ((size_t)(n_ * 128 + oy_) * 128 + h_ * 64) * 64;                                      \
+        GA = *reinterpret_cast<const uint4*>(gg + p0_ + aoff0);                                                  \
+        GB = *reinterpret_cast<const uint4*>(gg + p0_ + aoff1);                                                  \
+        XA = fused ? *reinterpret_cast<const uint4*>(raw + p0_ + aoff0) : zero4;                                 \
+        XB = fused ? *reinterpret_cast<const uint4*>(raw + p0_ + aoff1) : zero4;                                 \
+        const bf16_t* cb_ = canvas + ((size_t)(n_ * HP + 2 * oy_) * WP + 2 * (h_ * 64)) * 4;                     \
+        CA = *reinterpret_cast<const uint4*>(cb_ + coff0);                                                       \
+        CB = *reinterpret_cast<const uint4*>(cb_ + coff1);                                                       \
+    }
+    auto bn_apply = [&](uint4 gq, uint4 xq) -> uint4 {
+        if (!fused) return gq;
+        float gv[8], xv[8], o[8];
+        Vec16<bf16_t>::unpack(gq, gv);
+        Vec16<bf16_t>::unpack(xq, xv);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t o = p0 + (size_t)(rowA + 32 * i) * 64 + segA * 8;
-            rg[i] = *reinterpret_cast<const uint4*>(gg + o);
-            rx[i] = fused ? *reinterpret_cast<const uint4*>(raw + o) : make_uint4(0, 0, 0, 0);
-        }
-        const bf16_t* cb = canvas + ((size_t)(n * HP + 2 * oy) * WP + 2 * (h * 64)) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = min(tid + 256 * i, 7 * 67 - 1);
-            const int ky = id / 67, sg = id - ky * 67;
-            rc[i] = *reinterpret_cast<const uint4*>(cb + (size_t)ky * WP * 4 + sg * 8);
-        }
+        for (int j = 0; j < 8; ++j) o[j] = ka[j] * gv[j] + (kb[j] * xv[j] + kc[j]);
+        return Vec16<bf16_t>::pack(o);
     };
-    auto write_stage = [&](int buf) {
-        unsigned char* tA = smem + buf * SW_TILE;
-        unsigned char* tX = tA + 64 * SW_PA;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uint4 v = rg[i];
-            if (fused) {
-                float gv[8], xv[8], o[8];
-                Vec16<bf16_t>::unpack(rg[i], gv);
-                Vec16<bf16_t>::unpack(rx[i], xv);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = ka[j] * gv[j] + (kb[j] * xv[j] + kc[j]);
-                v = Vec16<bf16_t>::pack(o);
-            }
-            *reinterpret_cast<uint4*>(tA + (rowA + 32 * i) * SW_PA + segA * 16) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
-            if (id < 7 * 67) {
-                const int ky = id / 67, sg = id - ky * 67;
-                *reinterpret_cast<uint4*>(tX + ky * SW_SPAN + sg * 16) = rc[i];
-            }
-        }
-    };
+#define SW_WRITE(BUF_, GA, GB, XA, XB, CA, CB)                                                                   \
+    {                                                                                                            \
+        unsigned char* tA_ = smem + (BUF_) * SW_TILE;                                                            \
+        unsigned char* tX_ = tA_ + 64 * SW_PA;                                                                   \
+        *reinterpret_cast<uint4*>(tA_ + rowA * SW_PA + segA * 16) = bn_apply(GA, XA);                            \
+        *reinterpret_cast<uint4*>(tA_ + (rowA + 32) * SW_PA + segA * 16) = bn_apply(GB, XB);                     \
+        *reinterpret_cast<uint4*>(tX_ + cdst0) = CA;                                                             \
+        if (cdst1 >= 0) *reinterpret_cast<uint4*>(tX_ + cdst1) = CB;                                             \
+    }
 
     f32x4_t acc[7][2];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) { acc[ky][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[ky][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
-    if (s_begin < s_end) {
-        load_stage(s_begin);
-        write_stage(0);
-    }
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) load_stage(s + 1);
+    auto compute = [&](int buf) {
         const unsigned char* tA = smem + buf * SW_TILE;
         const unsigned char* tX = tA + 64 * SW_PA;
 #pragma unroll
@@ -223,9 +211,28 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __rest
                 }
             }
         }
-        if (s + 1 < s_end) write_stage(buf ^ 1);
+    };
+    if (s_begin < s_end) {
+        SW_LOAD(s_begin, g0a, g0b, x0a, x0b, c0a, c0b)
+        if (s_begin + 1 < s_end) SW_LOAD(s_begin + 1, g1a, g1b, x1a, x1b, c1a, c1b)
+        SW_WRITE(0, g0a, g0b, x0a, x0b, c0a, c0b)
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; s += 2) {
+        // even step: buffer 0 holds stage s, set 1 holds stage s+1 (in flight), set 0 is free for stage s+2
+        if (s + 2 < s_end) SW_LOAD(s + 2, g0a, g0b, x0a, x0b, c0a, c0b)
+        compute(0);
+        if (s + 1 < s_end) SW_WRITE(1, g1a, g1b, x1a, x1b, c1a, c1b)
+        __syncthreads();
+        if (s + 1 >= s_end) break;
+        // odd step: buffer 1 holds stage s+1, set 0 holds stage s+2, set 1 is free for stage s+3
+        if (s + 3 < s_end) SW_LOAD(s + 3, g1a, g1b, x1a, x1b, c1a, c1b)
+        compute(1);
+        if (s + 2 < s_end) SW_WRITE(0, g0a, g0b, x0a, x0b, c0a, c0b)
         __syncthreads();
     }
+#undef SW_LOAD
+#undef SW_WRITE
     // D[i = g*4 + j -> co = wave*16 + i][col = r16 -> n = nf*16 + r16]; every workgroup writes its slab (zeros if it had no stage)
     float* slab = ws + (size_t)blockIdx.x * 64 * 224;
 #pragma unroll
@@ -236,22 +243,24 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __rest
             for (int j = 0; j < 4; ++j) slab[(wave * 16 + g * 4 + j) * 224 + ky * 32 + nf * 16 + r16] = acc[ky][nf][j];
 }
 
-// grad OIHW [64][3][7][7] = sum over the partial slabs; one workgroup per output channel
+// grad OIHW [64][3][7][7] (zeroed by the caller) += sum over a slice of the partial slabs; grid (64 output channels, SW_SLICES)
+constexpr int SW_SLICES = 8;
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ ws, int parts, float* __restrict__ grad) {
     const int co = blockIdx.x, e = threadIdx.x;
     if (e >= 224) return;
+    const int per = (parts + SW_SLICES - 1) / SW_SLICES, q0 = blockIdx.y * per, q1 = min(parts, q0 + per);
     const float* p = ws + (size_t)co * 224 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int q = 0;
-    for (; q + 4 <= parts; q += 4) {
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {
         s0 += p[(size_t)(q + 0) * 64 * 224];
         s1 += p[(size_t)(q + 1) * 64 * 224];
         s2 += p[(size_t)(q + 2) * 64 * 224];
         s3 += p[(size_t)(q + 3) * 64 * 224];
     }
-    for (; q < parts; ++q) s0 += p[(size_t)q * 64 * 224];
+    for (; q < q1; ++q) s0 += p[(size_t)q * 64 * 224];
     const int ky = e >> 5, kx = (e >> 2) & 7, c = e & 3;
-    if (kx < 7 && c < 3) grad[((co * 3 + c) * 7 + ky) * 7 + kx] = (s0 + s1) + (s2 + s3);
+    if (kx < 7 && c < 3) atomicAdd(grad + ((co * 3 + c) * 7 + ky) * 7 + kx, (s0 + s1) + (s2 + s3));
 }
 
 }  // namespace
@@ -281,7 +290,8 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
                        reinterpret_cast<const bf16_t*>(raw), mean, invstd, gamma, sums, 1.0f / ((float)N * 128.f * 128.f), dgamma, dbeta, nstages,
                        per, ws);
     GDRN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(256), 0, st, ws, parts, grad);
+    if (hipMemsetAsync(grad, 0, 64 * 147 * sizeof(float), st) != hipSuccess) return GDRN_ERR_LAUNCH;
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64, SW_SLICES), dim3(256), 0, st, ws, parts, grad);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
