@@ -155,7 +155,7 @@ def _base():
             CHECKPOINT_PERIOD=5,
             CHECKPOINT_BY_EPOCH=True,
         ),
-        INPUT=dict(DZI_PAD_SCALE=1.5, SMOOTH_XYZ=False),  # common_base.py:49,53; a6_cPnP_lm13.py:5
+        INPUT=dict(DZI_TYPE="uniform", DZI_PAD_SCALE=1.5, DZI_SCALE_RATIO=0.25, DZI_SHIFT_RATIO=0.25, SMOOTH_XYZ=False),  # common_base.py:49,53; a6_cPnP_lm13.py:5
         TEST=dict(USE_PNP=False),
     )
 

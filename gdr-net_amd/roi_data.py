@@ -34,6 +34,48 @@ def get_2d_coord_np(width, height, low=0, high=1, fmt="CHW"):
     raise ValueError(f"Unknown format: {fmt}")
 
 
+def aug_bbox(cfg, bbox_xyxy, im_H, im_W, rng=np.random):
+    """Dynamic zoom-in of a training box (core/base_data_loader.py:120-152): returns (bbox_center, scale), the crop centre and
+    square crop size ``RoiCropper`` takes.  ``rng`` needs ``random_sample`` / ``rand`` (numpy's global generator by default, as
+    in the reference, so a seeded run draws the same numbers in the same order)."""
+    x1, y1, x2, y2 = np.asarray(bbox_xyxy).copy()
+    cx, cy = 0.5 * (x1 + x2), 0.5 * (y1 + y2)
+    bh, bw = y2 - y1, x2 - x1
+    inp = cfg.INPUT
+    dzi = inp.DZI_TYPE.lower()
+    if dzi == "uniform":
+        scale_ratio = 1 + inp.DZI_SCALE_RATIO * (2 * rng.random_sample() - 1)
+        shift_ratio = inp.DZI_SHIFT_RATIO * (2 * rng.random_sample(2) - 1)
+        bbox_center = np.array([cx + bw * shift_ratio[0], cy + bh * shift_ratio[1]])
+        scale = max(y2 - y1, x2 - x1) * scale_ratio * inp.DZI_PAD_SCALE
+    elif dzi == "roi10d":
+        lo, hi = -0.15, 0.15  # every corner coordinate moves by up to 15 % of the box size
+        x1 += bw * (rng.rand() * (hi - lo) + lo)
+        x2 += bw * (rng.rand() * (hi - lo) + lo)
+        y1 += bh * (rng.rand() * (hi - lo) + lo)
+        y2 += bh * (rng.rand() * (hi - lo) + lo)
+        x1 = min(max(x1, 0), im_W)
+        x2 = min(max(x1, 0), im_W)  # the reference clamps x2 from x1 (base_data_loader.py:141); kept for identical crops
+        y1 = min(max(y1, 0), im_H)
+        y2 = min(max(y2, 0), im_H)
+        bbox_center = np.array([0.5 * (x1 + x2), 0.5 * (y1 + y2)])
+        scale = max(y2 - y1, x2 - x1) * inp.DZI_PAD_SCALE
+    elif dzi == "truncnorm":
+        raise NotImplementedError("DZI truncnorm not implemented yet.")
+    else:
+        bbox_center = np.array([cx, cy])
+        scale = max(y2 - y1, x2 - x1)
+    return bbox_center, min(scale, max(im_H, im_W)) * 1.0
+
+
+def detection_box_to_roi(cfg, bbox_xyxy, im_H, im_W):
+    """Test-mode crop geometry of a detection box (core/gdrn_modeling/data_loader.py:411-423): (bbox_center, scale)."""
+    x1, y1, x2, y2 = bbox_xyxy
+    bbox_center = np.array([0.5 * (x1 + x2), 0.5 * (y1 + y2)])
+    scale = max(max(y2 - y1, 1), max(x2 - x1, 1)) * cfg.INPUT.DZI_PAD_SCALE
+    return bbox_center, min(scale, max(im_H, im_W)) * 1.0
+
+
 def _dev(t, dtype, device, what):
     if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
         raise cabi.GdrnHipError(f"{what} must be a device tensor: the RoI cropper runs on the GPU (no CPU fallback)")

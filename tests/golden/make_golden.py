@@ -396,6 +396,21 @@ def golden_g8(out_dir):
     g["coord2d_640x480_row0"] = c[0, :, 0].copy()
     g["coord2d_640x480_col0"] = c[:, 0, 1].copy()
     g["coord2d_720x540_sum"] = np.array([get_2d_coord_np(720, 540).astype(np.float64).sum()])
+    # aug_bbox (core/base_data_loader.py:120-152) under numpy's seeded global generator, both DZI types of the configs
+    from core.base_data_loader import Base_DatasetFromList
+    from gdrnet_amd.cfg import lm13_cfg
+
+    boxes = np.array([[100.0, 80.0, 260.0, 200.0], [5.0, 3.0, 40.0, 90.0], [600.0, 400.0, 639.0, 479.0], [300.0, 200.0, 301.0, 330.0]])
+    for dzi in ("uniform", "roi10d", "none"):
+        cfg = lm13_cfg(device="cpu")
+        cfg.INPUT.DZI_TYPE = dzi
+        np.random.seed(1234)
+        out = []
+        for b in boxes:
+            c, sc = Base_DatasetFromList.aug_bbox(None, cfg, b, 480, 640)
+            out.append([c[0], c[1], sc])
+        g["aug_bbox_" + dzi] = np.array(out, np.float64)
+    g["aug_bbox_boxes"] = boxes
     np.savez_compressed(os.path.join(out_dir, "g8_roi_targets.npz"), **g)
 
 

@@ -113,3 +113,27 @@ def test_product_module_has_no_cpu_fallback():
         roi_data.RoiCropper(cfg)
     src = open(roi_data.__file__).read()
     assert "oracle" not in src.replace("no CPU fallback", "")
+
+
+def test_g8_aug_bbox_matches_the_reference():
+    """aug_bbox (core/base_data_loader.py:120-152) draws the same numbers in the same order as the reference under numpy's
+    seeded global generator, for the uniform (all GDR-Net configs), roi10d and "none" DZI types."""
+    from gdrnet_amd import roi_data
+    from gdrnet_amd.cfg import lm13_cfg
+
+    g = np.load(os.path.join(HERE, "golden", "g8_roi_targets.npz"))
+    for dzi in ("uniform", "roi10d", "none"):
+        cfg = lm13_cfg(device="cpu")
+        cfg.INPUT.DZI_TYPE = dzi
+        np.random.seed(1234)
+        got = []
+        for b in g["aug_bbox_boxes"]:
+            c, sc = roi_data.aug_bbox(cfg, b, 480, 640)
+            got.append([c[0], c[1], sc])
+        assert np.array_equal(np.array(got), g["aug_bbox_" + dzi]), dzi
+    cfg.INPUT.DZI_TYPE = "truncnorm"
+    with pytest.raises(NotImplementedError):
+        roi_data.aug_bbox(cfg, g["aug_bbox_boxes"][0], 480, 640)
+    c, sc = roi_data.detection_box_to_roi(lm13_cfg(device="cpu"), (100.0, 80.0, 260.0, 200.0), 480, 640)
+    assert c.tolist() == [180.0, 140.0] and sc == 240.0
+    assert roi_data.detection_box_to_roi(lm13_cfg(device="cpu"), (0.0, 0.0, 639.0, 479.0), 480, 640)[1] == 640.0  # clamped to max(H, W)
