@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rp = make_uint4(0, 0, 0, 0);
+    // next-chunk patch slices in flight: slice s is loaded at stage s-1 (0 and 1 at stage 0) and written to LDS at stage s+2, i.e.
+    // three tap stages (~1500 cycles) after its load: with a single register written one stage later every stage waited on HBM
+    uint4 rp0 = make_uint4(0, 0, 0, 0), rp1 = rp0, rp2 = rp0;
+#define RP(i_) (((i_) % 3) == 0 ? rp0 : (((i_) % 3) == 1 ? rp1 : rp2))
 
 #define LOADP(dst, kc_, st_)                                                    \
     {                                                                           \
@@ -203,8 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #define STEP(WQ_, TAP_)                                                                                         \
     {                                                                                                           \
         if (more_p) {                                                                                           \
-            if constexpr ((TAP_) > 0) WRITEP(rp, pb ^ 1, (TAP_) - 1)                                            \
-            LOADP(rp, kc + 1, TAP_)                                                                             \
+            if constexpr ((TAP_) >= 2) WRITEP(RP((TAP_) + 1), pb ^ 1, (TAP_) - 2)                               \
+            if constexpr ((TAP_) == 0) { LOADP(rp0, kc + 1, 0) LOADP(rp1, kc + 1, 1) }                          \
+            else if constexpr ((TAP_) <= 7) LOADP(RP((TAP_) + 1), kc + 1, (TAP_) + 1)                           \
         }                                                                                                       \
         RD(fbB, TAP_, 1)                                                                                        \
         \
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         STEP(wq0, 0) STEP(wq1, 1) STEP(wq2, 2)
         STEP(wq0, 3) STEP(wq1, 4) STEP(wq2, 5)
         STEP(wq0, 6) STEP(wq1, 7) STEP(wq2, 8)
-        if (more_p) WRITEP(rp, pb ^ 1, 8)
+        if (more_p) { WRITEP(rp1, pb ^ 1, 7) WRITEP(rp2, pb ^ 1, 8) }
         __syncthreads();
     }
 #undef LOADW
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #undef RD
 #undef MM
 #undef STEP
+#undef RP
 
     // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
     // Fast path for what the engine actually launches (full channel tiles, bf16 out, bias / ReLU / addend / statistics
