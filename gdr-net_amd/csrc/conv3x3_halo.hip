@@ -298,34 +298,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t1[a][j] = 0.f; t2[a][j] = 0.f; }
                 }
+                // All tile loads of the epilogue go out first (the ring / fragment registers of the loop are dead: 96 VGPRs of
+                // uint2), then the arithmetic and the stores.  Written as load-use-store per fragment row, hipcc kept that order
+                // (the stores may alias the loads) and every one of the FM rows waited a full memory round trip: 8 serialized
+                // HBM latencies per workgroup.
+                constexpr int HB_ = FM / 2;  // in two halves: all FM rows at once (96 VGPRs for three tensors) spilled on the 128-wide tile
 #pragma unroll
-                for (int b = 0; b < FM; ++b) {
-                    const unsigned pr = (unsigned)(prow0 + b * pstep);
-                    uint2 av[FN], xq[FN], mq[FN];
+                for (int h = 0; h < 2; ++h) {
+                    uint2 xq[HB_][FN], av[HB_][FN], mq[HB_][FN];
 #pragma unroll
-                    for (int a = 0; a < FN; ++a) {
-                        xq[a] = *reinterpret_cast<const uint2*>(xb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
-                        av[a] = ab ? *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u) : make_uint2(0u, 0u);
-                        mq[a] = mb ? *reinterpret_cast<const uint2*>(mb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u) : make_uint2(0x3f803f80u, 0x3f803f80u);
+                    for (int bb = 0; bb < HB_; ++bb) {
+                        const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
+#pragma unroll
+                        for (int a = 0; a < FN; ++a) {
+                            xq[bb][a] = *reinterpret_cast<const uint2*>(xb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
+                            av[bb][a] = make_uint2(0u, 0u);
+                            mq[bb][a] = make_uint2(0x3f803f80u, 0x3f803f80u);
+                        }
+                    }
+                    if (ab != nullptr) {
+#pragma unroll
+                        for (int bb = 0; bb < HB_; ++bb) {
+                            const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
+#pragma unroll
+                            for (int a = 0; a < FN; ++a) av[bb][a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
+                        }
+                    }
+                    if (mb != nullptr) {
+#pragma unroll
+                        for (int bb = 0; bb < HB_; ++bb) {
+                            const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
+#pragma unroll
+                            for (int a = 0; a < FN; ++a) mq[bb][a] = *reinterpret_cast<const uint2*>(mb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
+                        }
                     }
 #pragma unroll
-                    for (int a = 0; a < FN; ++a) {
-                        const float xv[4] = {__uint_as_float(xq[a].x << 16), __uint_as_float(xq[a].x & 0xffff0000u),
-                                             __uint_as_float(xq[a].y << 16), __uint_as_float(xq[a].y & 0xffff0000u)};
-                        const float mv[4] = {__uint_as_float(mq[a].x << 16), __uint_as_float(mq[a].x & 0xffff0000u),
-                                             __uint_as_float(mq[a].y << 16), __uint_as_float(mq[a].y & 0xffff0000u)};
-                        const float ad[4] = {__uint_as_float(av[a].x << 16), __uint_as_float(av[a].x & 0xffff0000u),
-                                             __uint_as_float(av[a].y << 16), __uint_as_float(av[a].y & 0xffff0000u)};
-                        float v[4];
+                    for (int bb = 0; bb < HB_; ++bb) {
+                        const int b = h * HB_ + bb;
+                        const unsigned pr = (unsigned)(prow0 + b * pstep);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float gv = acc[a][b][j] + ad[j];
-                            if (!(mv[j] > 0.f) || !(xv[j] * ksc[a][j] + ksh[a][j] > 0.f)) gv = 0.f;
-                            v[j] = gv;
-                            t1[a][j] += gv;
-                            t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
+                        for (int a = 0; a < FN; ++a) {
+                            const uint2 xw = xq[bb][a], aw = av[bb][a], mw = mq[bb][a];
+                            const float xv[4] = {__uint_as_float(xw.x << 16), __uint_as_float(xw.x & 0xffff0000u),
+                                                 __uint_as_float(xw.y << 16), __uint_as_float(xw.y & 0xffff0000u)};
+                            const float mv[4] = {__uint_as_float(mw.x << 16), __uint_as_float(mw.x & 0xffff0000u),
+                                                 __uint_as_float(mw.y << 16), __uint_as_float(mw.y & 0xffff0000u)};
+                            const float ad[4] = {__uint_as_float(aw.x << 16), __uint_as_float(aw.x & 0xffff0000u),
+                                                 __uint_as_float(aw.y << 16), __uint_as_float(aw.y & 0xffff0000u)};
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool keep = (mv[j] > 0.f) && (xv[j] * ksc[a][j] + ksh[a][j] > 0.f);
+                                const float gv = keep ? acc[a][b][j] + ad[j] : 0.f;
+                                v[j] = gv;
+                                t1[a][j] += gv;
+                                t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
+                            }
+                            *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                         }
-                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     }
                 }
                 // per-tile partial rows with plain stores (as the forward statistics); gdrn_bn_fold_rows folds them into the
@@ -354,16 +384,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
             }
             const bool relu = p.act == 1;
             if (ab != nullptr) {
+                uint2 avq[FM][FN];  // all addend loads first (see the fused BatchNorm path above)
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
                     const unsigned pr = (unsigned)(prow0 + b * pstep);
-                    uint2 av[FN];
 #pragma unroll
-                    for (int a = 0; a < FN; ++a) av[a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
+                    for (int a = 0; a < FN; ++a) avq[b][a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const unsigned pr = (unsigned)(prow0 + b * pstep);
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
-                        float v0 = acc[a][b][0] + bq[a][0] + __uint_as_float(av[a].x << 16), v1 = acc[a][b][1] + bq[a][1] + __uint_as_float(av[a].x & 0xffff0000u);
-                        float v2 = acc[a][b][2] + bq[a][2] + __uint_as_float(av[a].y << 16), v3 = acc[a][b][3] + bq[a][3] + __uint_as_float(av[a].y & 0xffff0000u);
+                        const uint2 av_ = avq[b][a];
+                        float v0 = acc[a][b][0] + bq[a][0] + __uint_as_float(av_.x << 16), v1 = acc[a][b][1] + bq[a][1] + __uint_as_float(av_.x & 0xffff0000u);
+                        float v2 = acc[a][b][2] + bq[a][2] + __uint_as_float(av_.y << 16), v3 = acc[a][b][3] + bq[a][3] + __uint_as_float(av_.y & 0xffff0000u);
                         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     }
