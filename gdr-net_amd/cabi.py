@@ -31,6 +31,8 @@ class ConvParams(C.Structure):
         ("KH", I), ("KW", I), ("stride", I), ("pad", I),
         ("mode", I), ("act", I), ("out_f32", I),
         ("M", I), ("w_rows", I), ("dtype", I),
+        ("xf_mode", I), ("xf_relu", I),
+        ("xf_x2", P), ("xf_a", P), ("xf_b", P), ("xf_c", P), ("xf_c2", P), ("xf_msc", P), ("xf_msh", P), ("xf_out", P),
     ]
 
 
@@ -122,6 +124,7 @@ _SIGS = {
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
     "gdrn_bn_bwd_reduce": [P, P, P, P, P, P, P, LL, I, P, I, P],
     "gdrn_bn_fold_rows": [P, I, I, P, P],
+    "gdrn_bn_bwd_coef": [P, I, I, LL, P, P, P, P, P, P, P, P, P],
     "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],

@@ -73,7 +73,50 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ s
     }
 }
 
-template <typename T, int TH, int TW, int BN>
+// ---- operand transform while staging (p.xf_mode, see gdrn_hip.h): the per-channel vectors live in an LDS table
+// [xf_nk(XF)][Cin] behind the patch buffers; a thread's granule always covers the same 8 channels of a chunk (PSLICE is a
+// multiple of 8 in these instantiations), so one transform = 2 ds_read_b128 per vector + ~30 VALU beside the MFMAs.
+__host__ __device__ constexpr int xf_nk(int XF) { return XF == 0 ? 0 : (XF == 1 ? 2 : (XF == 4 ? 5 : 3)); }
+
+// one half granule (4 channels): v1h / v2h = two dwords of bf16 pairs, t = table row of those 4 channels
+template <int XF>
+__device__ __forceinline__ uint2 xf_half(uint2 v1h, uint2 v2h, const float* t, int Cin, float lo) {
+    const float4 a = *reinterpret_cast<const float4*>(t), c = *reinterpret_cast<const float4*>(t + Cin);
+    float x[4] = {__uint_as_float(v1h.x << 16), __uint_as_float(v1h.x & 0xffff0000u), __uint_as_float(v1h.y << 16), __uint_as_float(v1h.y & 0xffff0000u)};
+    const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+    float y[4];
+    if constexpr (XF == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fmaxf(__builtin_fmaf(x[j], av[j], cv[j]), lo);      // bn_apply_kernel's arithmetic
+    } else {
+        const float x2[4] = {__uint_as_float(v2h.x << 16), __uint_as_float(v2h.x & 0xffff0000u), __uint_as_float(v2h.y << 16), __uint_as_float(v2h.y & 0xffff0000u)};
+        const float4 b = *reinterpret_cast<const float4*>(t + 2 * Cin);
+        const float bv[4] = {b.x, b.y, b.z, b.w};
+        if constexpr (XF == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaxf(__builtin_fmaf(x2[j], bv[j], __builtin_fmaf(x[j], av[j], cv[j])), lo);
+        } else {
+            if constexpr (XF == 4) {
+                const float4 s = *reinterpret_cast<const float4*>(t + 3 * Cin), h = *reinterpret_cast<const float4*>(t + 4 * Cin);
+                const float ms[4] = {s.x, s.y, s.z, s.w}, mh[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (__builtin_fmaf(x2[j], ms[j], mh[j]) > 0.f) ? x[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaxf(__builtin_fmaf(av[j], x[j], __builtin_fmaf(bv[j], x2[j], cv[j])), lo);  // bn_bwd_apply_kernel's
+        }
+    }
+    return make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
+}
+
+template <int XF>
+__device__ __forceinline__ uint4 xf_apply(uint4 v1, uint4 v2, const float* tab, int Cin, float lo) {
+    const uint2 h0 = xf_half<XF>(make_uint2(v1.x, v1.y), make_uint2(v2.x, v2.y), tab, Cin, lo);
+    const uint2 h1 = xf_half<XF>(make_uint2(v1.z, v1.w), make_uint2(v2.z, v2.w), tab + 4, Cin, lo);
+    return make_uint4(h0.x, h0.y, h1.x, h1.y);
+}
+
+template <typename T, int TH, int TW, int BN, int XF>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);
     constexpr int BM = TH * TW;
@@ -81,8 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     constexpr int HB = half_bytes(PPIX);      // odd-granule array offset
     constexpr int PBYTES = 2 * HB;
     constexpr int PSEG = PPIX * 8;            // 16-byte segments of one patch chunk
-    constexpr int PSLICE = (PSEG + 8) / 9;    // segments fetched per tap stage
+    constexpr int PSLICE = XF ? ((PSEG + 8) / 9 + 7) / 8 * 8 : (PSEG + 8) / 9;    // segments fetched per tap stage
     static_assert(PSLICE <= 256, "one patch segment per thread per stage");
+    static_assert(XF == 0 || sizeof(T) == 2, "operand transforms are bf16 only");
     constexpr int FM = BM / 16;               // pixel fragments per wave (all pixels)
     constexpr int FN = BN / 64;               // 16-channel fragments per wave
     constexpr int WQ = FN * 2;                // weight 1-KiB loads per wave per stage (FN frags x 2 k-steps)
@@ -133,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     // ---- patch slice geometry of this thread (slice st = linear segment ids [st*PSLICE, (st+1)*PSLICE))
     unsigned poff[9];
     int pdst[9];
-    unsigned pokm = 0;
+    unsigned pokm = 0, pinm = 0, ppm = 0;  // slice st: input pixel inside the image / one of this tile's own (interior) pixels / slot exists
 #pragma unroll
     for (int st = 0; st < 9; ++st) {
         const int id = st * PSLICE + tid;
@@ -146,6 +190,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         poff[st] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * (unsigned)sizeof(T) + sg * 16;
         pdst[st] = inpatch ? (pp * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
         pokm |= ok ? (1u << st) : 0u;
+        if constexpr (XF != 0) {
+            pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= TW) ? (1u << st) : 0u;
+            ppm |= inpatch ? (1u << st) : 0u;
+        }
+    }
+    // PSLICE % 8 == 0 in the transform instantiations: the LDS slot of slice st is pdst0 + st * PDSTEP (no per-slice register)
+    constexpr int PDSTEP = (PSLICE / 8) * PITCH;
+    const int pdst0 = (tid >> 3) * PITCH + (tid & 1) * HB + ((tid & 7) >> 1) * 16;
+    // operand transform state: LDS table of the per-channel vectors (built below, behind the patch buffers), second input,
+    // optional copy-out of the transformed tile (first channel tile of a pixel tile only)
+    const float* xtab = nullptr;
+    const char* xg2 = nullptr;
+    char* xo = nullptr;
+    float xlo = 0.f;
+    if constexpr (XF != 0) {
+        float* tabw = reinterpret_cast<float*>(smem + (kch == 1 ? 1 : 2) * PBYTES);
+        for (int c = tid; c < p.Cin; c += 256) {
+            tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
+            tabw[p.Cin + c] = p.xf_c[c] + (p.xf_c2 ? p.xf_c2[c] : 0.f);
+            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
+            if constexpr (XF == 4) { tabw[3 * p.Cin + c] = p.xf_msc[c]; tabw[4 * p.Cin + c] = p.xf_msh[c]; }
+        }
+        xtab = tabw + (tid & 7) * 8;   // + kc * 64: this thread's 8 channels of chunk kc
+        xg2 = reinterpret_cast<const char*>(p.xf_x2);
+        xo = (nt == 0) ? reinterpret_cast<char*>(p.xf_out) : nullptr;
+        xlo = p.xf_relu ? 0.f : -__builtin_inff();
     }
 
     // ---- pixel-fragment lane base inside a patch: fragment b, lane column r16 -> pixel (oy, ox)
@@ -163,25 +233,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     // next-chunk patch slices in flight: slice s is loaded at stage s-1 (0 and 1 at stage 0) and written to LDS at stage s+2, i.e.
     // three tap stages (~1500 cycles) after its load: with a single register written one stage later every stage waited on HBM
     uint4 rp0 = make_uint4(0, 0, 0, 0), rp1 = rp0, rp2 = rp0;
+    uint4 rq0 = rp0, rq1 = rp0, rq2 = rp0;  // second input of the operand transform (XF >= 2)
 #define RP(i_) (((i_) % 3) == 0 ? rp0 : (((i_) % 3) == 1 ? rp1 : rp2))
+#define RQ(i_) (((i_) % 3) == 0 ? rq0 : (((i_) % 3) == 1 ? rq1 : rq2))
 
-#define LOADP(dst, kc_, st_)                                                    \
+    // XF == 0: out-of-image granules are zeroed at the load; XF != 0: at the write, AFTER the transform (the padding is a
+    // property of the conv's input v, and v(0) != 0)
+#define LOADP(dst, dst2, kc_, st_)                                              \
     {                                                                           \
         const uint4 v_ = *reinterpret_cast<const uint4*>(xg + (poff[st_] + (unsigned)((kc_) * ROWB))); \
-        dst = ((pokm >> (st_)) & 1u) ? v_ : make_uint4(0, 0, 0, 0);            \
+        if constexpr (XF == 0) dst = ((pokm >> (st_)) & 1u) ? v_ : make_uint4(0, 0, 0, 0);            \
+        else dst = v_;                                                          \
+        if constexpr (XF >= 2) dst2 = *reinterpret_cast<const uint4*>(xg2 + (poff[st_] + (unsigned)((kc_) * ROWB))); \
     }
-#define WRITEP(src, pb_, st_)                                                   \
+#define WRITEP(src, src2, pb_, st_, kc_)                                        \
     {                                                                           \
-        if (pdst[st_] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[st_]) = src; \
+        if constexpr (XF == 0) {                                                \
+            if (pdst[st_] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[st_]) = src; \
+        } else {                                                                \
+            if ((ppm >> (st_)) & 1u) {                                          \
+                uint4 t_ = xf_apply<XF>(src, src2, xtab + (kc_) * EPS, p.Cin, xlo); \
+                t_ = ((pokm >> (st_)) & 1u) ? t_ : make_uint4(0, 0, 0, 0);     \
+                *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst0 + (st_) * PDSTEP) = t_; \
+                if (xo != nullptr && ((pinm >> (st_)) & 1u))                    \
+                    *reinterpret_cast<uint4*>(xo + (poff[st_] + (unsigned)((kc_) * ROWB))) = t_; \
+            }                                                                   \
+        }                                                                       \
     }
 
     // ---- prologue: patch of chunk 0 (nine slices in flight together); the weights of stages 0..2 are already in flight
     {
         uint4 q0, q1, q2, q3, q4, q5, q6, q7, q8;
-        LOADP(q0, 0, 0) LOADP(q1, 0, 1) LOADP(q2, 0, 2) LOADP(q3, 0, 3) LOADP(q4, 0, 4)
-        LOADP(q5, 0, 5) LOADP(q6, 0, 6) LOADP(q7, 0, 7) LOADP(q8, 0, 8)
-        WRITEP(q0, 0, 0) WRITEP(q1, 0, 1) WRITEP(q2, 0, 2) WRITEP(q3, 0, 3) WRITEP(q4, 0, 4)
-        WRITEP(q5, 0, 5) WRITEP(q6, 0, 6) WRITEP(q7, 0, 7) WRITEP(q8, 0, 8)
+        uint4 u0 = rp0, u1 = rp0, u2 = rp0, u3 = rp0, u4 = rp0, u5 = rp0, u6 = rp0, u7 = rp0, u8 = rp0;
+        LOADP(q0, u0, 0, 0) LOADP(q1, u1, 0, 1) LOADP(q2, u2, 0, 2) LOADP(q3, u3, 0, 3) LOADP(q4, u4, 0, 4)
+        LOADP(q5, u5, 0, 5) LOADP(q6, u6, 0, 6) LOADP(q7, u7, 0, 7) LOADP(q8, u8, 0, 8)
+        if constexpr (XF != 0) __syncthreads();  // the transform table is complete
+        WRITEP(q0, u0, 0, 0, 0) WRITEP(q1, u1, 0, 1, 0) WRITEP(q2, u2, 0, 2, 0) WRITEP(q3, u3, 0, 3, 0) WRITEP(q4, u4, 0, 4, 0)
+        WRITEP(q5, u5, 0, 5, 0) WRITEP(q6, u6, 0, 6, 0) WRITEP(q7, u7, 0, 7, 0) WRITEP(q8, u8, 0, 8, 0)
     }
     __syncthreads();
 
@@ -206,9 +294,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #define STEP(WQ_, TAP_)                                                                                         \
     {                                                                                                           \
         if (more_p) {                                                                                           \
-            if constexpr ((TAP_) >= 2) WRITEP(RP((TAP_) + 1), pb ^ 1, (TAP_) - 2)                               \
-            if constexpr ((TAP_) == 0) { LOADP(rp0, kc + 1, 0) LOADP(rp1, kc + 1, 1) }                          \
-            else if constexpr ((TAP_) <= 7) LOADP(RP((TAP_) + 1), kc + 1, (TAP_) + 1)                           \
+            if constexpr ((TAP_) >= 2) WRITEP(RP((TAP_) + 1), RQ((TAP_) + 1), pb ^ 1, (TAP_) - 2, kc + 1)       \
+            if constexpr ((TAP_) == 0) { LOADP(rp0, rq0, kc + 1, 0) LOADP(rp1, rq1, kc + 1, 1) }                \
+            else if constexpr ((TAP_) <= 7) LOADP(RP((TAP_) + 1), RQ((TAP_) + 1), kc + 1, (TAP_) + 1)           \
         }                                                                                                       \
         RD(fbB, TAP_, 1)                                                                                        \
         \
@@ -232,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
         STEP(wq0, 0) STEP(wq1, 1) STEP(wq2, 2)
         STEP(wq0, 3) STEP(wq1, 4) STEP(wq2, 5)
         STEP(wq0, 6) STEP(wq1, 7) STEP(wq2, 8)
-        if (more_p) { WRITEP(rp1, pb ^ 1, 7) WRITEP(rp2, pb ^ 1, 8) }
+        if (more_p) { WRITEP(rp1, rq1, pb ^ 1, 7, kc + 1) WRITEP(rp2, rq2, pb ^ 1, 8, kc + 1) }
         __syncthreads();
     }
 #undef LOADW
@@ -242,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
 #undef MM
 #undef STEP
 #undef RP
+#undef RQ
 
     // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
     // Fast path for what the engine actually launches (full channel tiles, bf16 out, bias / ReLU / addend / statistics
@@ -482,23 +571,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
     }
 }
 
-template <typename T, int TH, int TW, int BN>
+constexpr int XF_MAX_CIN = 512;  // channels of the operand-transform table
+
+template <typename T, int TH, int TW, int BN, int XF>
 int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
     constexpr size_t smem = 2 * 2 * (size_t)half_bytes((TH + 2) * (TW + 2));
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN, XF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + xf_nk(XF) * XF_MAX_CIN * sizeof(float))) != hipSuccess)
             return GDRN_ERR_LAUNCH;
         attr_set = true;
     }
     const int grid = N * (p.Ho / TH) * (p.Wo / TW) * cdiv(p.Cout, BN);
     // a single 128-byte channel chunk (Cin = 64) never touches the second patch buffer: half the LDS -> a third workgroup per
     // CU on the 64-channel variants (142 VGPRs), whose runs are all prologue / one chunk / epilogue
-    const size_t smem_used = (p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN>), dim3(grid), dim3(256), smem_used, st, p);
+    const size_t smem_used = ((p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem) + (size_t)xf_nk(XF) * p.Cin * sizeof(float);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN, XF>), dim3(grid), dim3(256), smem_used, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
+}
+
+template <int XF>
+int launch_tile(const gdrn_conv_params& p, int tw, int bn, int N, hipStream_t st) {
+    if (tw == 16) return bn == 64 ? launch<bf16_t, 8, 16, 64, XF>(p, N, st) : launch<bf16_t, 8, 16, 128, XF>(p, N, st);
+    return bn == 64 ? launch<bf16_t, 8, 8, 64, XF>(p, N, st) : launch<bf16_t, 8, 8, 128, XF>(p, N, st);
 }
 
 }  // namespace
@@ -567,8 +664,18 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }
     if ((unsigned long long)p.M * (unsigned long long)std::max(p.y_cs, p.add_cs) * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
+    if (p.xf_mode) {  // operand transform while staging
+        if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
+        if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
+        if (p.xf_mode == 4 && (!p.xf_msc || !p.xf_msh)) return GDRN_ERR_ARG;
+    }
     const int N = p.M / hw;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (tw == 16) return bn == 64 ? launch<bf16_t, 8, 16, 64>(p, N, st) : launch<bf16_t, 8, 16, 128>(p, N, st);
-    return bn == 64 ? launch<bf16_t, 8, 8, 64>(p, N, st) : launch<bf16_t, 8, 8, 128>(p, N, st);
+    switch (p.xf_mode) {
+        case 0: return launch_tile<0>(p, tw, bn, N, st);
+        case 1: return launch_tile<1>(p, tw, bn, N, st);
+        case 2: return launch_tile<2>(p, tw, bn, N, st);
+        case 3: return launch_tile<3>(p, tw, bn, N, st);
+        default: return launch_tile<4>(p, tw, bn, N, st);
+    }
 }

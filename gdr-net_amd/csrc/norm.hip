@@ -12,53 +12,44 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ BN
-// Two launches for many partial rows: bn_reduce_rows_kernel, grid (C/16, S), sums rows sl, sl+S, ... of 16 channels in
-// fp64 and stores one fp64 row per slice; bn_finalize_kernel then reduces the (few) rows and finalises the statistics.
-// (A single launch with a last-arriver ticket was tried: the agent-scope release/acquire it needs writes back the XCD's
-// L2 -- full of the conv's fresh output -- per workgroup, 13-23 us per layer; the one-block-per-16-channels version
-// walked up to 4096 rows serially, 17 us.)
-__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __restrict__ partial, int rows, int C, double* __restrict__ out) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + cl;
-    const int S = gridDim.y;
-    double s1 = 0.0, s2 = 0.0;
-    if (ch < C) {
-        for (int r = blockIdx.y * 16 + rl; r < rows; r += 16 * S) {
-            s1 += (double)partial[((size_t)r * 2 + 0) * C + ch];
-            s2 += (double)partial[((size_t)r * 2 + 1) * C + ch];
-        }
+// Per-tile partial rows [rows][2][C] -> per-channel totals in ONE launch: a workgroup owns 4 consecutive channels (one float4 per
+// statistic and row), thread t walks rows t, t+256, ... with all its loads independent (a few L2 round trips even for the
+// 2048-8192 rows of the 64x64 maps), fp64 accumulation (the parity mode sits at the fp32 noise floor), shuffle + LDS tree.
+// Replaces the bn_reduce_rows + bn_finalize pair (two dependent ~5 us launches per BatchNorm, 43 BatchNorms per step); the
+// single-launch variants tried before serialised up to 4096 rows per thread (17 us) or needed an agent-scope fence.
+__device__ __forceinline__ void rows_total4(const float* __restrict__ rows, int nrows, int C, int c4, double (&tot)[8], double (*red)[8]) {
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(rows + ((size_t)r * 2 + 0) * C + c4);
+        const float4 b = *reinterpret_cast<const float4*>(rows + ((size_t)r * 2 + 1) * C + c4);
+        s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+        s[4] += (double)b.x; s[5] += (double)b.y; s[6] += (double)b.z; s[7] += (double)b.w;
     }
-    red[0][rl][cl] = s1;
-    red[1][rl][cl] = s2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x >> 6][j] = s[j];
+    }
     __syncthreads();
-    if (rl == 0 && ch < C) {
-        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
-        out[((size_t)blockIdx.y * 2 + 0) * C + ch] = s1;  // fp64 rows: the parity mode sits at the fp32 noise floor
-        out[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2;
-    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
 }
 
-template <typename P>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ partial, int rows, int C, double count,
-                                                          const float* gamma, const float* beta, float* running_mean,
-                                                          float* running_var, long long* nbt, float momentum, float eps,
-                                                          float* mean, float* invstd, float* scale, float* shift) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (ch < C) {
-        for (int r = rl; r < rows; r += 16) {
-            s1 += (double)partial[((size_t)r * 2 + 0) * C + ch];
-            s2 += (double)partial[((size_t)r * 2 + 1) * C + ch];
-        }
-    }
-    red[0][rl][cl] = s1;
-    red[1][rl][cl] = s2;
-    __syncthreads();
-    if (rl == 0 && ch < C) {
-        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
+__global__ __launch_bounds__(256) void bn_finalize_rows_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                               const float* gamma, const float* beta, float* running_mean,
+                                                               float* running_var, long long* nbt, float momentum, float eps,
+                                                               float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double red[4][8];
+    double tot[8];
+    const int c4 = blockIdx.x * 4;
+    rows_total4(partial, rows, C, c4, tot, red);
+    if (threadIdx.x < 4) {
+        const int ch = c4 + threadIdx.x;
+        const double s1 = tot[threadIdx.x], s2 = tot[4 + threadIdx.x];
         const double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -75,6 +66,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const P* __restrict__ 
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
+}
+
+// BatchNorm-backward sums (per-tile rows of the fused data-gradient epilogue, or the GDRN_BN_SUM_COPIES rows of
+// gdrn_bn_bwd_reduce) -> the per-channel coefficients of dx = a*g + (b*x + c) (bn_bwd_apply_kernel's prologue arithmetic),
+// dgamma / dbeta: what a consumer that applies the BatchNorm backward while staging its operand needs.
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ rows, int nrows, int C, float inv_n,
+                                                          const float* gamma, const float* mean, const float* invstd,
+                                                          float* ka, float* kb, float* kc, float* dgamma, float* dbeta) {
+    __shared__ double red[4][8];
+    double tot[8];
+    const int c4 = blockIdx.x * 4;
+    rows_total4(rows, nrows, C, c4, tot, red);
+    if (threadIdx.x < 4) {
+        const int ch = c4 + threadIdx.x;
+        float m1 = (float)tot[threadIdx.x], m2 = (float)tot[4 + threadIdx.x];
+        if (dgamma != nullptr) { dbeta[ch] = m1; dgamma[ch] = m2; }
+        m1 *= inv_n;
+        m2 *= inv_n;
+        const float is = invstd[ch], a = gamma[ch] * is, b = -a * is * m2;
+        ka[ch] = a;
+        kb[ch] = b;
+        kc[ch] = -a * m1 - b * mean[ch];
+    }
 }
 
 // fold per-tile partial rows into GDRN_BN_SUM_COPIES rows (the layout of the BatchNorm-backward sums)
@@ -647,17 +661,20 @@ inline int ew_grid(long long n) { return (int)std::min<long long>((n + 255) / 25
 extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream) {
-    if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0) return GDRN_ERR_ARG;
-    // many rows (large feature maps): first fold them into S <= 64 fp64 rows with S x C/16 workgroups (needs the workspace)
-    if (ws != nullptr && rows >= 256) {
-        const int S = std::min(64, rows / 64);
-        hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(C, 16), S), dim3(256), 0, ST, partial, rows, C, ws);
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, ST, (const double*)ws, S, C, count, gamma, beta,
-                           running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
-    } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, ST, partial, rows, C, count, gamma, beta,
-                           running_mean, running_var, nbt, momentum, eps, mean, invstd, scale, shift);
-    }
+    (void)ws;  // no workspace any more: one launch whatever the row count
+    if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || (C & 3)) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3(C / 4), dim3(256), 0, ST, partial, rows, C, count, gamma, beta, running_mean,
+                       running_var, nbt, momentum, eps, mean, invstd, scale, shift);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long npix, const float* gamma, const float* mean,
+                                const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream) {
+    if (!rows || !gamma || !mean || !invstd || !a || !b || !c || nrows <= 0 || C <= 0 || (C & 3) || npix <= 0) return GDRN_ERR_ARG;
+    if ((dgamma != nullptr) != (dbeta != nullptr)) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C / 4), dim3(256), 0, ST, rows, nrows, C, (float)(1.0 / (double)npix), gamma, mean,
+                       invstd, a, b, c, dgamma, dbeta);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

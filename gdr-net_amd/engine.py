@@ -34,8 +34,9 @@ def _ru(a, b):
 class Engine:
     """Owns the packed (kernel-layout) weight copies and the per-batch-size plans for one GDRN module."""
 
-    def __init__(self, params, buffers, dtype="bf16", num_regions=64, wgrad_variant=0):
-        """params / buffers: dict name -> tensor with the reference's state_dict names."""
+    def __init__(self, params, buffers, dtype="bf16", num_regions=64, wgrad_variant=0, dry=False):
+        """params / buffers: dict name -> tensor with the reference's state_dict names.
+        dry: build-only engine on host tensors for inspecting the launch lists without a GPU (tests); it cannot run."""
         self.lib = cabi.load()
         self.P = params
         self.Bf = buffers
@@ -43,7 +44,8 @@ class Engine:
         self.tdt = torch.bfloat16 if self.dt == BF16 else torch.float32
         self.esz = 2 if self.dt == BF16 else 4
         self.dev = next(iter(params.values())).device
-        if self.dev.type != "cuda":
+        self.dry = bool(dry)
+        if self.dev.type != "cuda" and not self.dry:
             raise cabi.GdrnHipError("the HIP engine needs parameters on a GPU device (no CPU fallback)")
         self.nreg = num_regions
         self.wgrad_variant = wgrad_variant
@@ -56,6 +58,9 @@ class Engine:
         self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
+        # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
+        # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
+        self.fuse_xf = self.dt == BF16 and self.use_halo and self.fuse_bnb and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
         self.layers = OrderedDict()
@@ -326,6 +331,7 @@ class Plan:
         self._unpack_pending = []  # (forward group index, layer)
         self._wreduce = {}         # layer key -> (workspace, nsplit, Cout, Cin) of the halo weight-gradient partials
         self._wgrad_deferred = []  # (forward group index, layer, WgradParams, flops) of the halo weight gradients
+        self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
         self._build()
         if self.has_backward:
             self._finish_unpack()
@@ -334,10 +340,12 @@ class Plan:
 
     # ---- op builders -------------------------------------------------------------------------
     def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
-              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False):
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False, xf=None):
         """bnb = (bn key, raw input of that BN, stored activation or None, affine mask?): data-gradient launch whose
         output is the gradient w.r.t. that BatchNorm(+ReLU)'s output -- the halo kernel's epilogue masks it and
-        accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass."""
+        accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass.
+        xf = dict(mode, x2, a, b, c, c2, msc, msh, out, relu): the conv's input is v(x, x2) evaluated while the patch is staged
+        (gdrn_hip.h, xf_mode), `out` (same shape as x) receives v -- halo launches only."""
         e = self.e
         cp = ConvParams()
         cp.x, cp.w, cp.y = ptr(x), ptr(w if w is not None else L.wf), ptr(y)
@@ -372,18 +380,36 @@ class Plan:
             cp.bnb_mean, cp.bnb_invstd, cp.bnb_rows = ptr(sb.mean), ptr(sb.invstd), ptr(self.stats)  # stats scratch is idle in backward
             if baffine:
                 cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
+        if xf is not None:
+            assert use_halo and e.dt == BF16, L.key
+            assert xf["out"] is None or (xf["out"].shape == x.shape and xf["out"].dtype == x.dtype), L.key
+            assert xf.get("x2") is None or xf["x2"].shape == x.shape, L.key
+            cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
+            cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf["c"]), ptr(xf.get("c2"))
+            cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
         if bnb is not None:
             nrows_b, sums_b, lib_ = int(cp._stats_rows), self.bn[bnb[0]].sums, e.lib
             assert nrows_b * 2 * cp.Cout <= self.stats.numel(), (L.key, nrows_b)
+            sbn = self.bn[bnb[0]]
+            if getattr(sbn, "xf_bwd", False):
+                # the BatchNorm whose sums this epilogue reduced has its backward apply fused into ITS consumer conv: turn the
+                # rows straight into that consumer's coefficient vectors (+ dgamma / dbeta) instead of the 16-copy sums
+                coef = self._bn_coef_op(bnb[0], self.stats, nrows_b)
 
-            def run(st, ctx):
-                s = fn(ref, st)
-                if s:
-                    check(s, f"conv {L.key}")
-                check(lib_.gdrn_bn_fold_rows(ptr(self.stats), nrows_b, cp.Cout, ptr(sums_b), st), "bn_fold_rows")
+                def run(st, ctx):
+                    s = fn(ref, st)
+                    if s:
+                        check(s, f"conv {L.key}")
+                    coef(st, ctx)
+            else:
+                def run(st, ctx):
+                    s = fn(ref, st)
+                    if s:
+                        check(s, f"conv {L.key}")
+                    check(lib_.gdrn_bn_fold_rows(ptr(self.stats), nrows_b, cp.Cout, ptr(sums_b), st), "bn_fold_rows")
         else:
             def run(st, ctx):
                 s = fn(ref, st)
@@ -404,7 +430,7 @@ class Plan:
                 sp = 8 * 8  # Hin*Win*Cin*Cout*k^2
             macs = self.B * sp * L.O * L.I * L.KK
         dn = "bf16" if e.dt == BF16 else "f32"
-        kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value}>" if use_halo else f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
+        kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>" if use_halo else f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
         run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key)
         return run, cp
 
@@ -489,6 +515,22 @@ class Plan:
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
 
+    def _xf_ok(self, L):
+        """can layer L's halo launches (forward and data gradient) take a fused operand transform?"""
+        e = self.e
+        return e.fuse_xf and self.bn_train and L.kind == "conv" and L.wfF is not None and L.KK == 9 and not L.s2
+
+    def _bn_coef_op(self, bnkey, rows, nrows):
+        """rows [nrows][2][C] of BatchNorm-backward sums -> (ka, kb, kc) of dx = ka*g + kb*x + kc, dgamma, dbeta (one launch)."""
+        e, lib = self.e, self.e.lib
+        s = self.bn[bnkey]
+        if getattr(s, "ka", None) is None:
+            s.ka, s.kb, s.kc = (e._empty(s.C, dtype=torch.float32) for _ in range(3))
+        g = e.P[bnkey + ".weight"]
+        dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
+        return lambda st, ctx: check(lib.gdrn_bn_bwd_coef(ptr(rows), nrows, s.C, s.npix, ptr(g), ptr(s.mean), ptr(s.invstd), ptr(s.ka), ptr(s.kb),
+                                                          ptr(s.kc), ptr(dg), ptr(db), st), "bn_bwd_coef")
+
     def _conv_bn_eval(self, L, bnkey, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, relu, residual=None, add_cs=0, **kw):
         """eval mode: conv -> BatchNorm (-> +residual) (-> ReLU) as ONE launch, y = act(conv_{w*scale}(x) + shift + residual)."""
         f = self.e.fold(bnkey, L)
@@ -504,11 +546,22 @@ class Plan:
         e = self.e
         return e.fuse_bnb and e.use_halo and e.dt == BF16 and L.kind == "conv" and L.wfF is not None
 
-    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False):
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False):
         """affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
-        evaluated) instead of reading the stored activation `ymask` -- one tensor pass less in both kernels."""
+        evaluated) instead of reading the stored activation `ymask` -- one tensor pass less in both kernels.
+        xf: the apply pass is left to the consumer halo conv (returns (ops, xf dict for _conv); dx is written by that conv)."""
         e, lib = self.e, self.e.lib
         s = self.bn[bnkey]
+        if xf:
+            assert g_out is None and (prereduced or affine_mask)
+            if prereduced:  # the producing data-gradient launch has already turned its rows into (ka, kb, kc): see _conv
+                assert getattr(s, "xf_bwd", False), bnkey
+                self._bn_coef_op(bnkey, self.stats, 1)  # allocates the vectors
+                return [], dict(mode=3, x2=raw, a=s.ka, b=s.kb, c=s.kc, out=dx, relu=False)
+            coef = self._bn_coef_op(bnkey, s.sums, BN_SUM_COPIES)
+            ops = [lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), None, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(s.scale), ptr(s.shift),
+                                                               s.npix, s.C, ptr(s.sums), e.dt, st), "bn_bwd_reduce"), coef]
+            return ops, dict(mode=4, x2=raw, a=s.ka, b=s.kb, c=s.kc, msc=s.scale, msh=s.shift, out=dx, relu=False)
         g = e.P[bnkey + ".weight"]
         dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
         msc, msh = (ptr(s.scale), ptr(s.shift)) if affine_mask else (None, None)
@@ -714,7 +767,10 @@ class Plan:
             d_p0 = None
 
         # ---------------- residual blocks
+        # `pend`: the block input `x` is not materialised yet -- it is v = relu(a*x1 + b*x2 + c) of the previous block's bn2 output
+        # and identity, evaluated (and written to `x`) by THIS block's conv1 while it stages its patch (xf, see _conv)
         x, d_x, Hc, inpl = p0, d_p0, 64, 64
+        pend = None
         for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
             for b in range(nb):
                 pfx = f"backbone.layer{li}.{b}"
@@ -724,6 +780,7 @@ class Plan:
                 Ld = e.layers.get(pfx + ".downsample.0")
                 npo = B * Ho * Ho
                 raw1, a1, raw2, out = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                self.tensors.update({pfx + ".raw1": raw1, pfx + ".a1": a1, pfx + ".raw2": raw2, pfx + ".out": out})
                 if FOLD:  # eval: three (four) launches per block, no BatchNorm passes
                     self.fwd.append(self._conv_bn_eval(L1, pfx + ".bn1", x, inpl, a1, Hc, Hc, Ho, Ho, stride, 1, relu=True))
                     res = x
@@ -733,30 +790,56 @@ class Plan:
                     self.fwd.append(self._conv_bn_eval(L2, pfx + ".bn2", a1, pl, out, Ho, Ho, Ho, Ho, 1, 1, relu=True, residual=res, add_cs=pl))
                     x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
                     continue
-                op, cp = self._conv(L1, x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None)
+                assert pend is None or self._xf_ok(L1)
+                op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
+                                    xf=dict(pend["xf"], out=x) if pend else None)
                 self.fwd.append(op)
-                self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, a1)
-                op, cp = self._conv(L2, a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None)
+                xf1 = self._xf_ok(L2)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
+                self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, None if xf1 else a1)
+                s1 = self.bn[pfx + ".bn1"]
+                op, cp = self._conv(L2, raw1 if xf1 else a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None,
+                                    xf=dict(mode=1, a=s1.scale, c=s1.shift, relu=True, out=a1) if xf1 else None)
                 self.fwd.append(op)
+                # block output relu(bn2(raw2) + identity): left to the next block's conv1 when that is a halo launch
+                nxt1 = e.layers.get(f"backbone.layer{li}.{b + 1}.conv1")
+                xf_out = nxt1 is not None and self._xf_ok(nxt1)
                 if Ld is not None:
-                    rawd, idn = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                    rawd, idn = E(B, Ho, Ho, pl), (None if xf_out else E(B, Ho, Ho, pl))
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
                     op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
                     self.fwd.append(op)
                     self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd, pl, npo, idn, relu=0)
-                    s2 = self.bn[pfx + ".bn2"]
-                    self.fwd.append(lambda st, ctx, raw2=raw2, s2=s2, idn=idn, out=out, npo=npo, pl=pl: check(
-                        lib.gdrn_bn_apply(ptr(raw2), ptr(s2.scale), ptr(s2.shift), ptr(idn), ptr(out), npo, pl, 1, e.dt, st), "bn_apply"))
+                    s2, sd = self.bn[pfx + ".bn2"], self.bn[pfx + ".downsample.1"]
+                    if xf_out:   # relu(scale2*raw2 + scale_d*rawd + shift2 + shift_d)
+                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=rawd, a=s2.scale, b=sd.scale, c=s2.shift, c2=sd.shift, relu=True))
+                    else:
+                        self.fwd.append(lambda st, ctx, raw2=raw2, s2=s2, idn=idn, out=out, npo=npo, pl=pl: check(
+                            lib.gdrn_bn_apply(ptr(raw2), ptr(s2.scale), ptr(s2.shift), ptr(idn), ptr(out), npo, pl, 1, e.dt, st), "bn_apply"))
                 else:
-                    self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, out, residual=x)
+                    self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None if xf_out else out, residual=x)
+                    s2 = self.bn[pfx + ".bn2"]
+                    if xf_out:   # relu(scale2*raw2 + x + shift2)
+                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=x, a=s2.scale, c=s2.shift, relu=True))
+                if not xf_out:
+                    nxt_pend = None
                 if T:
                     d_out = E(B, Ho, Ho, pl)
                     d_raw2, d_a1, d_raw1 = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
+                    self.tensors.update({pfx + ".d_out": d_out, pfx + ".d_raw2": d_raw2, pfx + ".d_a1": d_a1, pfx + ".d_raw1": d_raw1})
                     # d_out comes from the next block's conv1 data gradient when that is a plain (stride-1) block of the
                     # same layer: its halo epilogue has then already applied this block's output ReLU mask and reduced
                     # the bn2-backward sums (and d_out itself is the residual-path gradient g2)
                     pre2 = (b + 1 < nb) and self._fusable(e.layers[f"backbone.layer{li}.{b + 1}.conv1"])
-                    if pre2:
+                    # BatchNorm-backward apply passes fused into the data-gradient conv that consumes their result (xf modes 3 / 4)
+                    xfb2 = pre2 and self._xf_ok(L2)
+                    need_dx = d_x is not None
+                    xfb1 = self._fusable(L2) and self._xf_ok(L1) and Ld is None and need_dx
+                    self.bn[pfx + ".bn2"].xf_bwd, self.bn[pfx + ".bn1"].xf_bwd = xfb2, xfb1
+                    xd2 = xd1 = None
+                    if xfb2:
+                        g2 = d_out
+                        grp, xd2 = self._bn_bwd(pfx + ".bn2", d_out, None, raw2, d_raw2, prereduced=True, xf=True)
+                    elif pre2:
                         g2 = d_out
                         grp = self._bn_bwd(pfx + ".bn2", d_out, None, raw2, d_raw2, prereduced=True)
                     else:
@@ -765,13 +848,16 @@ class Plan:
                     grp.append(self._wgrad(L2, a1, d_raw2, Ho, Ho, Ho, Ho, 1, 1, pl, pl, pl, pl))
                     grp.append(self._unpack(L2))
                     pre1 = self._fusable(L2)
-                    op, _ = self._conv(L2, d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl,
-                                       bnb=(pfx + ".bn1", raw1, None, True) if pre1 else None)
+                    op, _ = self._conv(L2, d_out if xfb2 else d_raw2, pl, d_a1, Ho, Ho, Ho, Ho, 1, 1, w=L2.wd, rows=L2.rows_d, cin=L2.cin_d, cout=pl,
+                                       bnb=(pfx + ".bn1", raw1, None, True) if pre1 else None, xf=xd2)
                     grp.append(op)
-                    grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True, prereduced=pre1)
+                    if xfb1:
+                        ops1, xd1 = self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True, prereduced=True, xf=True)
+                        grp += ops1
+                    else:
+                        grp += self._bn_bwd(pfx + ".bn1", d_a1, a1, raw1, d_raw1, affine_mask=True, prereduced=pre1)
                     grp.append(self._wgrad(L1, x, d_raw1, Hc, Hc, Ho, Ho, stride, 1, inpl, pl, inpl, pl))
                     grp.append(self._unpack(L1))
-                    need_dx = d_x is not None
                     if Ld is not None:
                         d_rawd, d_xd = E(B, Ho, Ho, pl), E(B, Hc, Hc, inpl)
                         grp += self._bn_bwd(pfx + ".downsample.1", g2, None, rawd, d_rawd)
@@ -786,25 +872,27 @@ class Plan:
                         # previous block of the same layer: d_x is the gradient w.r.t. its output (mask = x, stored) and
                         # feeds its bn2 backward (raw input prev_raw2)
                         fuse_prev = b >= 1 and self._fusable(L1)
-                        op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 1, 1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d, cout=inpl,
+                        op, _ = self._conv(L1, d_a1 if xfb1 else d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 1, 1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d, cout=inpl,
                                            addend=g2, add_cs=pl,
-                                           bnb=(f"backbone.layer{li}.{b - 1}.bn2", prev_raw2, x, False) if fuse_prev else None)
+                                           bnb=(f"backbone.layer{li}.{b - 1}.bn2", prev_raw2, x, False) if fuse_prev else None, xf=xd1)
                         grp.append(op)
                     self.bwd_groups.append(grp)
                     d_x = d_out
-                x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
+                x, Hc, inpl, prev_raw2, pend = out, Ho, pl, raw2, nxt_pend
+        assert pend is None
         feat, d_feat = x, d_x
 
         # ---------------- geometric head
         h = "rot_head_net.features."
         LT = e.layers[h + "0"]
         rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
+        xf_first = (not FOLD) and (not HEAD_CONVS[0][2]) and self._xf_ok(e.layers[h + str(HEAD_CONVS[0][0])])
         if FOLD:
             self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
         else:
             op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
             self.fwd.append(op)
-            self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, h0)
+            self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, None if xf_first else h0)
         if T:
             d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
             pre_t = (not HEAD_CONVS[0][2]) and self._fusable(e.layers[h + str(HEAD_CONVS[0][0])])
@@ -817,10 +905,13 @@ class Plan:
             self.bwd_groups.append(grp)
         hx, d_hx, Hh = h0, (d_h0 if T else None), 16
         prev_bn, prev_raw = h + "1", rawt
+        # pend_h: hx = relu(bn(prev_raw)) is evaluated (and written to hx) by the next head conv while it stages its patch
+        pend_h = dict(x1=rawt, xf=dict(mode=1, a=self.bn[h + "1"].scale, c=self.bn[h + "1"].shift, relu=True)) if xf_first else None
         for hi, (ci, bi, up) in enumerate(HEAD_CONVS):
             Lc = e.layers[h + str(ci)]
             grp = []
             if up:
+                assert pend_h is None
                 u = E(B, 2 * Hh, 2 * Hh, 256)
                 self.fwd.append(lambda st, ctx, hx=hx, u=u, Hh=Hh: check(lib.gdrn_upsample2x_fwd(ptr(hx), ptr(u), B, Hh, Hh, 256, e.dt, st), "upsample_fwd"))
                 if T:
@@ -833,30 +924,44 @@ class Plan:
                 d_in = d_hx
                 up_bwd = None
             raw, act = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
+            self.tensors.update({h + f"{ci}.raw": raw, h + f"{ci}.act": act})
+            nxt = HEAD_CONVS[hi + 1] if hi + 1 < len(HEAD_CONVS) else None
+            # this conv's BatchNorm + ReLU is applied by the next head conv on load when no upsampling sits in between
+            xf_next = (not FOLD) and nxt is not None and not nxt[2] and self._xf_ok(e.layers[h + str(nxt[0])])
             if FOLD:
                 self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
             else:
-                op, cp = self._conv(Lc, xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None)
+                op, cp = self._conv(Lc, pend_h["x1"] if pend_h else xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None,
+                                    xf=dict(pend_h["xf"], out=xin) if pend_h else None)
                 self.fwd.append(op)
-                self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, act)
+                self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, None if xf_next else act)
             if T:
                 d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
+                self.tensors.update({h + f"{ci}.d_act": d_act, h + f"{ci}.d_raw": d_raw})
                 # d_act is produced by the NEXT head conv's data gradient; when no upsampling sits in between, that
                 # launch masks it and reduces this BN's backward sums
-                nxt = HEAD_CONVS[hi + 1] if hi + 1 < len(HEAD_CONVS) else None
                 pre = nxt is not None and not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])
-                grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre)
+                xfb = self._xf_ok(Lc)  # this BN's backward apply inside Lc's data-gradient launch (mode 3, or 4 = with the ReLU mask)
+                self.bn[h + str(bi)].xf_bwd = xfb and pre
+                xd = None
+                if xfb:
+                    ops, xd = self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre, xf=True)
+                    grp += ops
+                else:
+                    grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre)
                 grp.append(self._wgrad(Lc, xin, d_raw, Hh, Hh, Hh, Hh, 1, 1, 256, 256, 256, 256))
                 grp.append(self._unpack(Lc))
                 fuse_in = (not up) and self._fusable(Lc)  # d_in is the gradient w.r.t. the previous BN+ReLU's output
-                op, _ = self._conv(Lc, d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256,
-                                   bnb=(prev_bn, prev_raw, None, True) if fuse_in else None)
+                op, _ = self._conv(Lc, d_act if xfb else d_raw, 256, d_in, Hh, Hh, Hh, Hh, 1, 1, w=Lc.wd, rows=Lc.rows_d, cin=256, cout=256,
+                                   bnb=(prev_bn, prev_raw, None, True) if fuse_in else None, xf=xd)
                 grp.append(op)
                 if up_bwd is not None:
                     grp.append(up_bwd)
                 self.bwd_groups.append(grp)
                 d_hx = d_act
+            pend_h = dict(x1=raw, xf=dict(mode=1, a=self.bn[h + str(bi)].scale, c=self.bn[h + str(bi)].shift, relu=True)) if xf_next else None
             hx, prev_bn, prev_raw = act, h + str(bi), raw
+        assert pend_h is None
         LO = e.layers[h + "23"]
         M = B * 64 * 64
         self.hs = 72
@@ -997,6 +1102,8 @@ class Plan:
     # ---- execution ---------------------------------------------------------------------------
     def run_forward(self, ctx):
         e = self.e
+        if e.dry:
+            raise cabi.GdrnHipError("dry (build-only) engine: there is no CPU execution path")
         st = e._stream()
         if self.bn_train:
             e.bn_epoch += 1  # the kernels update the running statistics behind autograd's back
@@ -1013,6 +1120,8 @@ class Plan:
         """ctx as in forward; self.gw must hold dL/dloss_k.  on_bucket(i) is called after the ops that
         complete gradient bucket i have been enqueued (used to overlap the RCCL all-reduce)."""
         e = self.e
+        if e.dry:
+            raise cabi.GdrnHipError("dry (build-only) engine: there is no CPU execution path")
         main = torch.cuda.current_stream(e.dev)
         st = main.cuda_stream
         e.dwp_flat.zero_()

@@ -57,6 +57,18 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *      of its pixel tile to bnb_rows[tile][2][Cout] (gdrn_conv3x3_stats_rows tiles, plain stores); gdrn_bn_fold_rows
  *      turns the rows into the [GDRN_BN_SUM_COPIES][2][Cout] sums gdrn_bn_bwd_apply reads: the separate reduction pass
  *      over (dy, x, mask) disappears.
+ *   xf_mode != 0 (gdrn_conv3x3_halo only): the conv's INPUT is v(x, x2) evaluated per element while the patch is staged
+ *      in LDS, rounded to bf16, zero outside the image (the padding applies to v, not to x), with per-input-channel
+ *      fp32 vectors [Cin] (NULL a / b = 1, NULL c2 = 0):
+ *        1: v = a*x + (c + c2)                      BatchNorm(+ReLU) forward apply of the producer (a = scale, c = shift)
+ *        2: v = b*x2 + (a*x + (c + c2))             ... with a residual / second normalised branch (BasicBlock output)
+ *        3: v = a*x + (b*x2 + c)                    BatchNorm backward apply: x = masked dy, x2 = the BN's raw input,
+ *                                                   (a, b, c) from gdrn_bn_bwd_coef
+ *        4: v = a*(x2*msc + msh > 0 ? x : 0) + (b*x2 + c)   the same with the ReLU mask recomputed from the forward affine
+ *      then v = max(v, 0) when xf_relu.  x2 has the geometry and channel stride of x.  xf_out (nullable, same geometry
+ *      and channel stride as x): v of every in-image pixel is also stored there once, so the tensor exists for the
+ *      weight-gradient launch / the next residual without a separate pass.  Replaces gdrn_bn_apply /
+ *      gdrn_bn_bwd_apply launches between two halo convs (BasicBlock, cdpn_rot_head_region.py:103-123 and backward).
  */
 typedef struct gdrn_conv_params {
     const void* x;
@@ -79,6 +91,15 @@ typedef struct gdrn_conv_params {
     int KH, KW, stride, pad;
     int mode, act, out_f32;
     int M, w_rows, dtype;
+    int xf_mode, xf_relu;
+    const void* xf_x2;
+    const float* xf_a;
+    const float* xf_b;
+    const float* xf_c;
+    const float* xf_c2;
+    const float* xf_msc;
+    const float* xf_msh;
+    void* xf_out;
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
@@ -183,8 +204,8 @@ int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, float* dst, in
  * BatchNorm2d (train / eval), fused with ReLU, residual add and max-pool where the graph has them.
  * Replaces nn.BatchNorm2d + nn.ReLU + `out += identity` + nn.MaxPool2d at resnet_backbone.py:24-26,
  * BasicBlock, cdpn_rot_head_region.py:92-93,113-114 and their backward. */
-/* ws: optional workspace of 64*2*C doubles (no initialisation needed): with it, and 256 or
- * more per-tile partial rows, the rows are first folded into <= 64 rows by a wide launch; NULL = one pass per 16 channels */
+/* partial: [rows][2][C] per-tile sums / sums of squares from a conv epilogue; one launch of C/4 workgroups whatever the row
+ * count (fp64 accumulation).  ws: unused (kept for ABI stability; was a 64*2*C-double workspace of a two-launch scheme). */
 int gdrn_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                      float eps, float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream);
@@ -207,6 +228,12 @@ int gdrn_bn_fold_rows(const float* rows, int nrows, int C, float* sums, void* st
 int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
                       const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
                       long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream);
+/* BatchNorm-backward sums -> the per-channel coefficients of dx = a*g + (b*x + c) (what gdrn_bn_bwd_apply evaluates) for a
+ * consumer that applies them itself while staging its operand (gdrn_conv3x3_halo xf_mode 3 / 4), plus dgamma = sum g*xhat,
+ * dbeta = sum g (both or neither NULL).  rows: [nrows][2][C] -- the per-tile rows of a fused data-gradient epilogue
+ * (bnb_rows) or the [GDRN_BN_SUM_COPIES][2][C] sums of gdrn_bn_bwd_reduce; npix = elements per channel. */
+int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long npix, const float* gamma, const float* mean,
+                     const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream);
 int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
                              int N, int H, int W, int C, int dtype, void* stream);
 int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale, const float* shift,

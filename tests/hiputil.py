@@ -78,9 +78,10 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
-              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None):
+              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None):
     """bnb (halo only): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
-    the second return value is then the [16][2][Cout] sums buffer."""
+    the second return value is then the [16][2][Cout] sums buffer.
+    xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging."""
     lib = cabi.load()
     if halo:  # the halo kernel takes the fragment-major permutation of the same operand
         wf = torch.empty_like(w)
@@ -112,6 +113,10 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
         cp.bnb_rows = ptr(rows_t)
         stats = sums
+    if xf is not None:
+        cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
+        cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
+        cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
     check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
     if bnb is not None:
         check(lib.gdrn_bn_fold_rows(ptr(rows_t), nrows, Cout, ptr(sums), stream()), "bn_fold_rows")

@@ -303,6 +303,52 @@ def test_full_size_properties_bs64():
         assert abs(L[k].item() - L2[k].item()) <= 2e-2 * max(abs(L[k].item()), 1e-3), k
 
 
+def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch, capsys):
+    """bf16 engine with the BatchNorm apply passes evaluated inside the consumer halo convs (GDRN_FUSE_XF=1, the default)
+    against the same engine with separate gdrn_bn_apply / gdrn_bn_bwd_apply launches: the fused arithmetic is the separate
+    kernels' arithmetic, so layer1 (no downsample branch) is bit-identical in the forward pass; further down the fused path
+    skips the bf16 rounding of the normalised downsample branch (3 places) and the sums take another summation order, which
+    the random-init graph amplifies -- checked stage by stage against a loose bound and reported."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 4
+    batch = to_dev(synth.make_batch(B, seed=5))
+    res = {}
+    for fx in ("0", "1"):
+        monkeypatch.setenv("GDRN_FUSE_XF", fx)
+        model, _ = build("bf16")
+        model.train()
+        kw = synth.model_kwargs(batch, do_loss=True)
+        kw.pop("do_loss")
+        losses = model.train_step(batch["roi_img"], optimizer=None, **kw).clone()
+        torch.cuda.synchronize()
+        eng = model.engine()
+        assert eng.fuse_xf == (fx == "1")
+        plan = eng.plan(B, True, True)
+        n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith("conv3x3_halo") and not op.meta["kernel"].endswith(",0>"))
+        assert n_xf == (63 if fx == "1" else 0), n_xf
+        res[fx] = (losses.cpu(), {k: v.float().cpu().clone() for k, v in plan.tensors.items()}, {n: g.cpu().clone() for n, g in eng.grads.items()},
+                   plan.head_out.cpu().clone())
+    l0, t0, g0, h0 = res["0"]
+    l1, t1, g1, h1 = res["1"]
+    for k in t0:
+        if k.startswith("backbone.layer1.") and k.split(".")[-1] in ("raw1", "a1", "raw2", "out"):
+            assert torch.equal(t0[k], t1[k]), k
+    report = []
+    for k in t0:
+        assert torch.isfinite(t1[k]).all(), k
+        r = rel(t1[k], t0[k])
+        report.append((r, k))
+        assert r < (0.08 if ".d_" in k else 0.03), (k, r)
+    assert rel(h1, h0) < 0.03
+    worst_g = max((rel(g1[n], g0[n]), n) for n in g0 if g0[n].numel() > 4096)
+    with capsys.disabled():
+        print("\nfused vs separate BN applies: worst activation %.3e (%s), worst gradient tensor %.3e (%s), losses %s vs %s"
+              % (max(report)[0], max(report)[1], worst_g[0], worst_g[1], l1.tolist(), l0.tolist()))
+    assert worst_g[0] < 0.15
+    assert ((l1 - l0).abs() / (l0.abs() + 1e-3))[:5].max() < 0.03
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_train_step_graph_replay_equals_eager(dtype, monkeypatch):
     """train_step through the captured hipGraph (third call onwards) == train_step issued launch by launch:

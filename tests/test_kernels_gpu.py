@@ -275,6 +275,112 @@ def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
     assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (1, 256, 256, 64), (2, 512, 512, 8)])
+def test_conv3x3_halo_operand_transform(H, case, mode):
+    """xf_mode 1-4 (gdrn_hip.h): the conv consumes v(x, x2) evaluated while the patch is staged -- the BatchNorm forward apply
+    (+residual, +ReLU) of the producer / the BatchNorm backward apply in front of a data gradient -- and xf_out receives v.
+    Reference: v in fp32 with torch, rounded to bf16, zero padding applied to v, F.conv2d."""
+    B, I, O, Hh = case
+    dt, dev = BF16, H.DEV
+    gen = lambda sd, *sh: H.randn(sd, *sh)
+    x = H.rounded(gen(70, B, I, Hh, Hh) * 1.3 + 0.2, dt)
+    x2 = H.rounded(gen(71, B, I, Hh, Hh), dt)
+    w = H.rounded(gen(72, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    a = torch.rand(I, generator=torch.Generator().manual_seed(73)) + 0.5
+    b = gen(74, I) * 0.7
+    c, c2 = gen(75, I) * 0.3, gen(76, I) * 0.2
+    msc, msh = torch.rand(I, generator=torch.Generator().manual_seed(77)) + 0.5, gen(78, I) * 0.4
+    V = lambda t: t.view(1, -1, 1, 1)
+    relu = mode in (1, 2)
+    if mode == 1:
+        v = x * V(a) + V(c + c2)
+    elif mode == 2:
+        v = x2 * V(b) + (x * V(a) + V(c + c2))
+    elif mode == 3:
+        v = V(a) * x + (V(b) * x2 + V(c))
+    else:
+        v = V(a) * (x * ((x2 * V(msc) + V(msh)) > 0)) + (V(b) * x2 + V(c))
+    if relu:
+        v = F.relu(v)
+    vb = H.rounded(v, dt)
+    ref = F.conv2d(vb, w, None, 1, 1)
+    d = lambda t: t.to(dev).float().contiguous()
+    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
+    xf = dict(mode=mode, relu=relu, a=d(a), c=d(c), out=out)
+    if mode in (1, 2):
+        xf["c2"] = d(c2)
+    if mode >= 2:
+        xf.update(x2=H.nhwc(x2, dt), b=d(b))
+    if mode == 4:
+        xf.update(msc=d(msc), msh=d(msh))
+    y, stats = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True, xf=xf)
+    # v itself: identical up to fp32 association (fma) -> at most rare one-ulp bf16 flips
+    got_v = H.nchw(out, I)
+    assert torch.isfinite(got_v).all()
+    assert H.rel(got_v, vb) < 2e-3, H.rel(got_v, vb)
+    assert float((got_v != vb).float().mean()) < 0.02
+    assert H.rel(H.nchw(y, O), ref) < TOL[dt]
+    st = stats.sum(0).cpu()
+    assert H.rel(st[1], (ref ** 2).sum((0, 2, 3))) < 2e-3
+    # without xf_out and with NULL a / b (= 1): same conv result
+    if mode == 2:
+        xf2 = dict(mode=2, relu=True, x2=H.nhwc(x2, dt), c=d(c))
+        y2, _ = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, xf=xf2)
+        ref2 = F.conv2d(H.rounded(F.relu(x2 + (x + V(c))), dt), w, None, 1, 1)
+        assert H.rel(H.nchw(y2, O), ref2) < TOL[dt]
+
+
+def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H):
+    """the launch the engine uses for a BasicBlock conv1 data gradient: xf_mode 3 prologue (bn1 backward apply) + addend
+    (residual-path gradient) + the fused mask / BatchNorm-backward sums epilogue of the previous block's bn2."""
+    B, I, O, Hh = 2, 128, 128, 16
+    dt, dev = BF16, H.DEV
+    g = H.rounded(H.randn(50, B, I, Hh, Hh), dt)          # masked gradient w.r.t. bn1's output
+    raw = H.rounded(H.randn(51, B, I, Hh, Hh) * 1.2, dt)  # bn1's raw input
+    w = H.rounded(H.randn(52, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    add = H.rounded(H.randn(53, B, O, Hh, Hh), dt)
+    ka, kb, kc = torch.rand(I) + 0.5, H.randn(54, I) * 0.1, H.randn(55, I) * 0.05
+    bx = H.rounded(H.randn(56, B, O, Hh, Hh) * 1.5 + 0.3, dt)
+    ystored = H.rounded(F.relu(bx + H.randn(57, B, O, Hh, Hh)), dt)
+    mean, invstd = H.randn(58, O) * 0.2, torch.rand(O, generator=torch.Generator().manual_seed(59)) + 0.5
+    V = lambda t: t.view(1, -1, 1, 1)
+    v = H.rounded(V(ka) * g + (V(kb) * raw + V(kc)), dt)
+    gg = (F.conv2d(v, w, None, 1, 1) + add) * (ystored > 0)
+    xhat = (bx - V(mean)) * V(invstd)
+    d = lambda t: t.to(dev).float().contiguous()
+    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
+    y, sums = H.conv_gemm(H.nhwc(g, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True,
+                          bnb=dict(x=H.nhwc(bx, dt), mask=H.nhwc(ystored, dt), mean=d(mean), invstd=d(invstd)),
+                          xf=dict(mode=3, relu=False, x2=H.nhwc(raw, dt), a=d(ka), b=d(kb), c=d(kc), out=out))
+    assert H.rel(H.nchw(out, I), v) < 2e-3
+    assert H.rel(H.nchw(y, O), gg) < 1e-2
+    got = sums.sum(0).cpu()
+    assert H.rel(got[0], gg.sum((0, 2, 3))) < 1e-2 and H.rel(got[1], (gg * xhat).sum((0, 2, 3))) < 1e-2
+
+
+@pytest.mark.parametrize("nrows,C_", [(16, 64), (128, 256), (2048, 256), (37, 512)])
+def test_bn_bwd_coef(H, nrows, C_):
+    """rows of BatchNorm-backward sums -> (a, b, c) of dx = a*g + b*x + c, dgamma, dbeta (gdrn_bn_bwd_apply's coefficients)."""
+    lib, dev = cabi.load(), H.DEV
+    rows = H.randn(60, nrows, 2, C_)
+    gamma, mean = torch.rand(C_) + 0.5, H.randn(61, C_) * 0.3
+    invstd = torch.rand(C_, generator=torch.Generator().manual_seed(62)) + 0.5
+    npix = 4096
+    d = lambda t: t.to(dev).float().contiguous()
+    o = [torch.full((C_,), float("nan"), device=dev) for _ in range(5)]
+    check(lib.gdrn_bn_bwd_coef(ptr(d(rows)), nrows, C_, npix, ptr(d(gamma)), ptr(d(mean)), ptr(d(invstd)), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]),
+                               ptr(o[4]), H.stream()), "bn_bwd_coef")
+    torch.cuda.synchronize()
+    s = rows.double().sum(0)
+    m1, m2 = s[0] / npix, s[1] / npix
+    a = gamma.double() * invstd.double()
+    b = -a * invstd.double() * m2
+    c = -a * m1 - b * mean.double()
+    assert H.rel(o[0], a) < 1e-6 and H.rel(o[1], b) < 1e-5 and H.rel(o[2], c) < 1e-5
+    assert H.rel(o[3], s[1]) < 1e-6 and H.rel(o[4], s[0]) < 1e-6
+
+
 def test_conv3x3_wgrad_grouped(H):
     """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
