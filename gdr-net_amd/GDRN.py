@@ -223,6 +223,7 @@ class _PathFn(torch.autograd.Function):
         plan.run_forward(kctx)
         ctx.model, ctx.plan, ctx.kctx = model, plan, kctx
         ctx.keep = kctx.get("_keep")
+        ctx.generation = plan.generation
         return plan.losses.clone()
 
     @staticmethod
@@ -230,8 +231,17 @@ class _PathFn(torch.autograd.Function):
         plan, e = ctx.plan, ctx.plan.e
         if not plan.has_backward:
             raise cabi.GdrnHipError("backward needs train-mode BatchNorm (model.train()) together with do_loss=True")
+        if plan.generation != ctx.generation:
+            # the plan keeps ONE set of activations per (batch size, mode): a second forward overwrote what this backward needs
+            raise cabi.GdrnHipError("backward of a forward pass whose activations were overwritten by a later forward of the same "
+                                    "batch size: call loss.backward() before the next model(...) call")
         plan.gw.copy_(glosses.to(torch.float32))
         plan.run_backward(ctx.kctx, on_bucket=ctx.model._on_bucket)
+        red = getattr(ctx.model, "_reducer", None)
+        if red is not None:
+            # autograd clones these views into .grad on the compute stream right after we return: the bucket all-reduces
+            # running on the reducer's side stream must have landed (and the mean be applied) before that
+            red.finish()
         return (None, None, None) + tuple(e.grads[n] for n in e.param_names)
 
 
@@ -393,6 +403,8 @@ class GDRN(nn.Module):
             return out_dict
 
         need_grad = torch.is_grad_enabled() and plan.has_backward
+        if torch.is_grad_enabled() and not plan.has_backward and any(p.requires_grad for p in eng.P.values()):
+            logger.warning("do_loss=True in eval mode (model.eval()): the losses carry no grad_fn -- the backward graph needs model.train()")
         if need_grad:
             losses = _PathFn.apply(self, plan, kctx, *[eng.P[n] for n in eng.param_names])
         else:
@@ -424,11 +436,22 @@ class GDRN(nn.Module):
         plan.gw.copy_(self._loss_w if loss_weights is None else self._loss_w * loss_weights)
         plan.run_backward(kctx, on_bucket=self._on_bucket)
         red = getattr(self, "_reducer", None)
+        gs = 1.0
         if red is not None:
             red.wait()
+            gs = red.grad_scale  # 1/world, folded into the fused optimizer's gradient read
         if optimizer is not None:
             eng = plan.e
-            optimizer.step(grads={eng.P[n]: eng.grads[n] for n in eng.param_names})
+            grads = {eng.P[n]: eng.grads[n] for n in eng.param_names}
+            if gs != 1.0 and not getattr(optimizer, "takes_grad_scale", False):
+                eng.grad_flat.mul_(gs)
+                gs = 1.0
+            if gs != 1.0:
+                optimizer.step(grads=grads, grad_scale=gs)
+            else:
+                optimizer.step(grads=grads)
+        elif gs != 1.0:
+            plan.e.grad_flat.mul_(gs)
         return plan.losses * self._loss_w  # weighted like forward()'s loss_dict
 
     def _train_step_graph(self, x, optimizer, a):
@@ -465,6 +488,7 @@ class GDRN(nn.Module):
                 st["ok"] = False
                 return None
         st["graph"].replay()
+        eng.bn_epoch += 1  # the replayed kernels moved the BatchNorm running statistics (run_forward was not called)
         if optimizer is not None:
             optimizer.step(grads={eng.P[n]: eng.grads[n] for n in eng.param_names})
         return plan.losses * self._loss_w  # weighted like forward()'s loss_dict
@@ -540,9 +564,14 @@ def build_model_optimizer(cfg):
             logger.warning("Randomly initialize weights for backbone!")
         elif os.path.exists(pre):
             sd = torch.load(pre, map_location="cpu")
-            model.backbone.load_state_dict(sd.get("state_dict", sd), strict=False)
+            sd = sd.get("state_dict", sd)
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}  # as mmcv's load_checkpoint (GDRN.py:721)
+            model.backbone.load_state_dict(sd, strict=False)
         else:
-            logger.warning(f"backbone weights {pre!r} not found (no network access); random init")
+            # the reference resolves "torchvision://resnet34" / http(s) URLs through mmcv's load_checkpoint; silently training
+            # from the std=0.001 random init instead would change convergence -- ask for a local file (as checkpoint.py does)
+            raise FileNotFoundError(f"cfg.MODEL.CDPN.BACKBONE.PRETRAINED={pre!r} is not a local file (URL schemes need network access): "
+                                    "download the weights and point PRETRAINED at the file, or set it to '' for random init")
     model.to(torch.device(cfg.MODEL.DEVICE))
     return model, optimizer
 

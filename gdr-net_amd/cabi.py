@@ -97,7 +97,7 @@ _SIGS = {
     "gdrn_stem_stats_rows": [I],
     "gdrn_stem_conv": [P, P, P, P, I, I, P],
     "gdrn_stem_wgrad_parts": [I],
-    "gdrn_stem_wgrad": [P, P, P, P, P, P, P, P, P, I, P, P, I, P],
+    "gdrn_stem_wgrad": [P, P, P, P, P, P, I, P, P, I, P],
     "gdrn_linear_splitk": [P, P, P, P, I, I, I, I, I, I, I, P, I, P],
     "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],
@@ -122,10 +122,10 @@ _SIGS = {
     "gdrn_bn_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P, P, P, P],
     "gdrn_bn_eval_params": [P, P, P, P, F, I, P, P, P],
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
+    "gdrn_bn_bwd_reduce_rows": [LL, I, I],
     "gdrn_bn_bwd_reduce": [P, P, P, P, P, P, P, LL, I, P, I, P],
-    "gdrn_bn_fold_rows": [P, I, I, P, P],
     "gdrn_bn_bwd_coef": [P, I, I, LL, P, P, P, P, P, P, P, P, P],
-    "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, LL, I, P, P, P, P, I, P],
+    "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, LL, I, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
@@ -144,7 +144,7 @@ _SIGS = {
     "gdrn_pack_chunk": [],
     "gdrn_pack_multi": [P, P, I, I, I, P],
     "gdrn_unpack_multi": [P, P, I, I, P],
-    "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, P],
+    "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, F, P],
     "gdrn_roi_affine": [P, I, I, I, P, P, P, P, P],
     "gdrn_roi_crop_inputs": [P, P, I, I, I, C.POINTER(D), C.POINTER(D), P, P, P],
     "gdrn_roi_targets": [P, P, I, I, P, I, P, P, P, P, P, P, P],

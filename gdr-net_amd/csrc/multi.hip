@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const gdrn_pack_task*
 // one workgroup per (tensor, row): gradient centralisation (row mean), RAdam moments, update, optional lookahead
 __global__ __launch_bounds__(256) void ranger_multi_kernel(const gdrn_ranger_task* __restrict__ tasks, const int* __restrict__ row_start,
                                                            int ntasks, float beta1, float beta2, float eps, float wd, float step_size,
-                                                           int adaptive, int lookahead, float alpha) {
+                                                           int adaptive, int lookahead, float alpha, float grad_scale) {
     __shared__ float red[4];
     const int t = find_task(row_start, ntasks, blockIdx.x);
     const gdrn_ranger_task k = tasks[t];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void ranger_multi_kernel(const gdrn_ranger_tas
     }
     for (int i = threadIdx.x; i < k.cols; i += 256) {
         const size_t j = base + i;
-        const float gr = k.g[j] - mean;
+        const float gr = (k.g[j] - mean) * grad_scale;  // grad_scale = 1/world: the gradient buffer holds the all-reduced SUM
         const float vv = k.v[j] * beta2 + (1.f - beta2) * gr * gr;
         const float mm = k.m[j] * beta1 + (1.f - beta1) * gr;
         k.v[j] = vv;
@@ -243,11 +243,11 @@ extern "C" int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk
 }
 
 extern "C" int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
-                                 float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha,
+                                 float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha, float grad_scale,
                                  void* stream) {
     if (!tasks_dev || !row_start_dev || ntasks <= 0 || total_rows <= 0) return GDRN_ERR_ARG;
     hipLaunchKernelGGL(ranger_multi_kernel, dim3(total_rows), dim3(256), 0, ST, tasks_dev, row_start_dev, ntasks, beta1, beta2, eps,
-                       weight_decay, step_size, adaptive, lookahead, alpha);
+                       weight_decay, step_size, adaptive, lookahead, alpha, grad_scale);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -91,28 +91,6 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
     }
 }
 
-// fold per-tile partial rows into GDRN_BN_SUM_COPIES rows (the layout of the BatchNorm-backward sums)
-__global__ __launch_bounds__(256) void bn_fold_rows_kernel(const float* __restrict__ rows, int nrows, int C, float* __restrict__ sums) {
-    __shared__ float red[2][16][16];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int ch = blockIdx.x * 16 + cl;
-    float s1 = 0.f, s2 = 0.f;
-    if (ch < C) {
-        for (int r = blockIdx.y + GDRN_BN_SUM_COPIES * rl; r < nrows; r += GDRN_BN_SUM_COPIES * 16) {
-            s1 += rows[((size_t)r * 2 + 0) * C + ch];
-            s2 += rows[((size_t)r * 2 + 1) * C + ch];
-        }
-    }
-    red[0][rl][cl] = s1;
-    red[1][rl][cl] = s2;
-    __syncthreads();
-    if (rl == 0 && ch < C) {
-        for (int r = 1; r < 16; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
-        sums[((size_t)blockIdx.y * 2 + 0) * C + ch] = s1;
-        sums[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2;
-    }
-}
-
 __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       int C, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         if (res != nullptr) Vec16<T>::load(res + o, q);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float t = v[j] * sc[j] + sh[j];
+            float t = __builtin_fmaf(v[j], sc[j], sh[j]);
             if (res != nullptr) t += q[j];
             if (relu) t = fmaxf(t, 0.f);
             v[j] = t;
@@ -158,13 +136,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
-// per-channel sums of g and g*xhat; rows strided over threads, LDS + global fp32 atomics
+// per-channel sums of g and g*xhat; rows strided over threads, LDS reduction, ONE partial row [2][C] per workgroup (plain
+// stores -- gdrn_bn_bwd_coef adds the rows up in fp64: deterministic, no pre-zeroed accumulator, no same-address atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ msc,
                                                             const float* __restrict__ msh, long long npix, int C,
-                                                            float* sums, int rows_per_block) {
+                                                            float* __restrict__ rows, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
     __shared__ float acc[2 * 512];
     const int tpr = C / V, rpp = 256 / tpr;
@@ -199,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int j = 0; j < V; ++j) {
                 float gg = g[j];
                 if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
-                if (!(xv[j] * ksc[j] + ksh[j] > 0.f)) gg = 0.f;  // ReLU mask recomputed from x (no-op without msc)
+                if (!(__builtin_fmaf(xv[j], ksc[j], ksh[j]) > 0.f)) gg = 0.f;  // ReLU mask recomputed from x (no-op without msc)
                 s1[j] += gg;
                 s2[j] += gg * (xv[j] - mu[j]) * is[j];
             }
@@ -219,34 +198,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    // same-address global atomics run at only a few G/s: spread the workgroups over GDRN_BN_SUM_COPIES copies of the sums
-    float* dst = sums + (size_t)(blockIdx.x % GDRN_BN_SUM_COPIES) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) unsafeAtomicAdd(&dst[i], acc[i]);
+    float* dst = rows + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = acc[i];
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ ym,
-                                                           const T* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, const float* __restrict__ msc,
-                                                           const float* __restrict__ msh, long long npix, int C, float inv_n,
-                                                           T* __restrict__ dx, T* __restrict__ gout, float* dgamma,
-                                                           float* dbeta, int rows_per_block) {
+                                                           const T* __restrict__ x, const float* __restrict__ ca,
+                                                           const float* __restrict__ cb, const float* __restrict__ cc,
+                                                           const float* __restrict__ msc, const float* __restrict__ msh,
+                                                           long long npix, int C, T* __restrict__ dx, T* __restrict__ gout,
+                                                           int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
-    // per-channel constants computed once per workgroup (thread = channel) and handed out through LDS:
-    // dx = a*(g - m1) - a*xhat*m2  with xhat = (x - mu)*is  ->  dx = a*g + (b*x + c), b = -a*is*m2, c = -a*m1 - b*mu
+    // dx = a*g + (b*x + c) with the per-channel (a, b, c) of gdrn_bn_bwd_coef, handed out through LDS
     __shared__ float kst[5][512];
     for (int c = threadIdx.x; c < C; c += 256) {
-        float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < GDRN_BN_SUM_COPIES; ++r) { m1 += sums[(size_t)r * 2 * C + c]; m2 += sums[(size_t)r * 2 * C + C + c]; }
-        if (blockIdx.x == 0 && dgamma != nullptr) { dbeta[c] = m1; dgamma[c] = m2; }
-        m1 *= inv_n;
-        m2 *= inv_n;
-        const float is = invstd[c], a = gamma[c] * is, b = -a * is * m2;
-        kst[0][c] = a;
-        kst[1][c] = b;
-        kst[2][c] = -a * m1 - b * mean[c];
+        kst[0][c] = ca[c];
+        kst[1][c] = cb[c];
+        kst[2][c] = cc[c];
         kst[3][c] = msc ? msc[c] : 0.f;
         kst[4][c] = msc ? msh[c] : 1.f;
     }
@@ -272,9 +241,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int j = 0; j < V; ++j) {
             float gg = g[j];
             if (ym != nullptr && !(yv[j] > 0.f)) gg = 0.f;
-            if (!(xv[j] * ksc[j] + ksh[j] > 0.f)) gg = 0.f;
+            if (!(__builtin_fmaf(xv[j], ksc[j], ksh[j]) > 0.f)) gg = 0.f;
             g[j] = gg;
-            o[j] = ka[j] * gg + (kb[j] * xv[j] + kc[j]);
+            o[j] = __builtin_fmaf(ka[j], gg, __builtin_fmaf(kb[j], xv[j], kc[j]));
         }
         Vec16<T>::store(dx + off, o);
         if (gout != nullptr) Vec16<T>::store(gout + off, g);
@@ -679,13 +648,6 @@ extern "C" int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long n
     return GDRN_OK;
 }
 
-extern "C" int gdrn_bn_fold_rows(const float* rows, int nrows, int C, float* sums, void* stream) {
-    if (!rows || !sums || nrows <= 0 || C <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(bn_fold_rows_kernel, dim3(cdiv(C, 16), GDRN_BN_SUM_COPIES), dim3(256), 0, ST, rows, nrows, C, sums);
-    GDRN_CHECK_LAUNCH();
-    return GDRN_OK;
-}
-
 extern "C" int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                                    float* scale, float* shift, void* stream) {
     if (!gamma || !beta || !rm || !rv || !scale || !shift || C <= 0) return GDRN_ERR_ARG;
@@ -710,43 +672,60 @@ extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shi
     return GDRN_OK;
 }
 
-extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                                  const float* mask_scale, const float* mask_shift, long long npix, int C, float* sums, int dtype,
-                                  void* stream) {
-    if (!dy || !x || !mean || !invstd || !sums || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
-    if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
+// grid of the reduce pass: >= 4 rows per thread, at most 1024 workgroups (= partial rows)
+static void bwd_reduce_grid(long long npix, int C, int dtype, int* rpb_out, int* blocks_out) {
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
-    if (256 % (C / V)) return GDRN_ERR_SHAPE;
     const int rpp = 256 / (C / V);
     int rpb = rpp * 4;  // >= 4 rows per thread, as many workgroups as that allows (small layers were latency-bound at 64)
     long long blocks = (npix + rpb - 1) / rpb;
     if (blocks > 1024) { rpb = (int)(((npix + 1023) / 1024 + rpp - 1) / rpp * rpp); blocks = (npix + rpb - 1) / rpb; }
+    *rpb_out = rpb;
+    *blocks_out = (int)blocks;
+}
+
+extern "C" int gdrn_bn_bwd_reduce_rows(long long npix, int C, int dtype) {
+    if (npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    int rpb, blocks;
+    bwd_reduce_grid(npix, C, dtype, &rpb, &blocks);
+    return blocks;
+}
+
+extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
+                                  const float* mask_scale, const float* mask_shift, long long npix, int C, float* rows, int dtype,
+                                  void* stream) {
+    if (!dy || !x || !mean || !invstd || !rows || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
+    if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
+    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    int rpb, blocks;
+    bwd_reduce_grid(npix, C, dtype, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, ST, (const float*)dy,
-                                (const float*)ymask, (const float*)x, mean, invstd, mask_scale, mask_shift, npix, C, sums, rpb),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, ST, (const bf16_t*)dy,
-                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, mask_scale, mask_shift, npix, C, sums, rpb));
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
+                                (const float*)ymask, (const float*)x, mean, invstd, mask_scale, mask_shift, npix, C, rows, rpb),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
+                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, mask_scale, mask_shift, npix, C, rows, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
-extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                                 const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
-                                 long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream) {
-    if (!dy || !x || !mean || !invstd || !gamma || !sums || !dx || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
+extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* a, const float* b, const float* c,
+                                 const float* mask_scale, const float* mask_shift, long long npix, int C, void* dx, void* g_out,
+                                 int dtype, void* stream) {
+    if (!dy || !x || !a || !b || !c || !dx || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
     if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
-    const float inv_n = (float)(1.0 / (double)npix);
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
     if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
     int rpb, blocks;
     ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
              hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
-                                (const float*)ymask, (const float*)x, mean, invstd, gamma, sums, mask_scale, mask_shift, npix, C, inv_n,
-                                (float*)dx, (float*)g_out, dgamma, dbeta, rpb),
+                                (const float*)ymask, (const float*)x, a, b, c, mask_scale, mask_shift, npix, C,
+                                (float*)dx, (float*)g_out, rpb),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
-                                (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, gamma, sums, mask_scale, mask_shift, npix, C, inv_n,
-                                (bf16_t*)dx, (bf16_t*)g_out, dgamma, dbeta, rpb));
+                                (const bf16_t*)ymask, (const bf16_t*)x, a, b, c, mask_scale, mask_shift, npix, C,
+                                (bf16_t*)dx, (bf16_t*)g_out, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -113,27 +113,15 @@ constexpr int SW_TILE = 64 * SW_PA + 7 * SW_SPAN;  // one stage buffer
 constexpr int SW_PARTS = 512;
 
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __restrict__ canvas, const bf16_t* __restrict__ gg,
-                                                            const bf16_t* __restrict__ raw, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ sums, float inv_n, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int nstages, int per, float* __restrict__ ws) {
+                                                            const bf16_t* __restrict__ raw, const float* __restrict__ ca,
+                                                            const float* __restrict__ cb, const float* __restrict__ cc,
+                                                            int nstages, int per, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SW_TILE];
     __shared__ float kst[3][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     if (tid < 64) {
         float a = 1.f, b = 0.f, c = 0.f;
-        if (mean != nullptr) {
-            float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < GDRN_BN_SUM_COPIES; ++r) { m1 += sums[r * 128 + tid]; m2 += sums[r * 128 + 64 + tid]; }
-            if (blockIdx.x == 0 && dgamma != nullptr) { dbeta[tid] = m1; dgamma[tid] = m2; }
-            m1 *= inv_n;
-            m2 *= inv_n;
-            const float is = invstd[tid];
-            a = gamma[tid] * is;
-            b = -a * is * m2;
-            c = -a * m1 - b * mean[tid];
-        }
+        if (ca != nullptr) { a = ca[tid]; b = cb[tid]; c = cc[tid]; }  // gdrn_bn_bwd_coef's vectors
         kst[0][tid] = a; kst[1][tid] = b; kst[2][tid] = c;
     }
     __syncthreads();
@@ -141,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __rest
     float ka[8], kb[8], kc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ka[j] = kst[0][segA * 8 + j]; kb[j] = kst[1][segA * 8 + j]; kc[j] = kst[2][segA * 8 + j]; }
-    const bool fused = mean != nullptr;
+    const bool fused = ca != nullptr;
 
     const int s_begin = blockIdx.x * per, s_end = min(nstages, s_begin + per);
     // two register sets: the loads of stage s+2 are issued before the MFMAs of stage s.  Named registers and macros, not arrays
@@ -271,15 +259,14 @@ extern "C" int gdrn_stem_wgrad_parts(int N) {
     return cdiv(nstages, per);
 }
 
-// Weight gradient of the stem conv, fused with the BatchNorm-backward apply in front of it (mean != NULL): see above.
+// Weight gradient of the stem conv, fused with the BatchNorm-backward apply in front of it (a != NULL): see above.
 //   canvas [N][262][272][4] bf16; g, raw [N][128][128][64] bf16 (masked upstream gradient / the conv output BatchNorm saw);
-//   mean, invstd, gamma [64]; sums [GDRN_BN_SUM_COPIES][2][64] from gdrn_bn_bwd_reduce; dgamma, dbeta [64] (nullable) written here
-//   as gdrn_bn_bwd_apply does; mean == NULL: plain weight gradient with dy = g.
+//   a, b, c [64]: the coefficients of dy = a*g + (b*raw + c) from gdrn_bn_bwd_coef; a == NULL: plain weight gradient with dy = g.
 //   ws: gdrn_stem_wgrad_parts(N) x 64 x 224 floats of scratch; grad: fp32 OIHW [64][3][7][7], overwritten.
-extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* mean, const float* invstd, const float* gamma,
-                               const float* sums, float* dgamma, float* dbeta, int N, float* ws, float* grad, int dtype, void* stream) {
+extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* a, const float* b, const float* c, int N,
+                               float* ws, float* grad, int dtype, void* stream) {
     if (!canvas || !g || !ws || !grad || N <= 0) return GDRN_ERR_ARG;
-    if (mean != nullptr && (!raw || !invstd || !gamma || !sums)) return GDRN_ERR_ARG;
+    if (a != nullptr && (!raw || !b || !c)) return GDRN_ERR_ARG;
     if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
     if ((long long)N * 128 * 128 * 64 >= (1ll << 40)) return GDRN_ERR_SHAPE;
     const int nstages = N * 256;
@@ -287,8 +274,7 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
     const int parts = cdiv(nstages, per);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(parts), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(g),
-                       reinterpret_cast<const bf16_t*>(raw), mean, invstd, gamma, sums, 1.0f / ((float)N * 128.f * 128.f), dgamma, dbeta, nstages,
-                       per, ws);
+                       reinterpret_cast<const bf16_t*>(raw), a, b, c, nstages, per, ws);
     GDRN_CHECK_LAUNCH();
     if (hipMemsetAsync(grad, 0, 64 * 147 * sizeof(float), st) != hipSuccess) return GDRN_ERR_LAUNCH;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64, SW_SLICES), dim3(256), 0, st, ws, parts, grad);

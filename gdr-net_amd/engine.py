@@ -20,10 +20,10 @@ import torch
 from . import cabi
 from .cabi import BF16, F32, ConvParams, PoseParams, WgradParams, check, ptr
 
-BN_SUM_COPIES = 16  # GDRN_BN_SUM_COPIES of include/gdrn_hip.h
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
 HEAD_CONVS = ((3, 4, False), (6, 7, False), (10, 11, True), (13, 14, False), (17, 18, True), (20, 21, False))
+BUCKET_FIRST_GROUP = (25, 17, 14, 8, 0)  # lowest forward-order backward-group index of gradient buckets pnp | head | layer4 | layer3 | rest
 LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_PM_R", "loss_centroid", "loss_z")
 
 
@@ -61,6 +61,9 @@ class Engine:
         # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
         self.fuse_xf = self.dt == BF16 and self.use_halo and self.fuse_bnb and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
+        # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
+        self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
+        self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
         self.layers = OrderedDict()
@@ -99,8 +102,10 @@ class Engine:
         return torch.zeros(*shape, dtype=dtype or self.tdt, device=self.dev)
 
     def _bucket_bounds(self):
-        """Flat-gradient slices in the order backward completes them: pnp, head, layer4+3, rest."""
-        marks = ["rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer2.3.bn2.bias"]
+        """Flat-gradient slices in the order backward completes them: pnp (36 MB fp32), head (19), layer4 (52), layer3 (27),
+        rest = layer2 + layer1 + stem (5.4): the big layer4 exchange starts nine blocks before the end of backward and the
+        exposed tail is the smallest bucket."""
+        marks = ["rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer3.5.bn2.bias", "backbone.layer2.3.bn2.bias"]
         cuts = [0]
         for m in marks:
             cuts.append(self.grad_offsets[m])
@@ -178,11 +183,7 @@ class Engine:
         for L in self.layers.values():
             L.dwp_off = tot
             tot += _ru(int(math.prod(L.dwp_shape)), 4)
-        # tail: the BN backward per-channel sums of a plan -- accumulated with atomics like the packed weight gradients,
-        # so one fill per backward pass clears both
-        self.bn_sums_cap = 1 << 20
-        self.dwp_flat = torch.zeros(tot + self.bn_sums_cap, dtype=torch.float32, device=self.dev)
-        self.bn_sums_flat = self.dwp_flat[tot:]
+        self.dwp_flat = torch.zeros(tot, dtype=torch.float32, device=self.dev)
         for L in self.layers.values():
             L.dwp = self.dwp_flat[L.dwp_off: L.dwp_off + int(math.prod(L.dwp_shape))]
         self.bn_ws = torch.zeros(64 * 2 * 512, dtype=torch.float64, device=self.dev)  # gdrn_bn_finalize workspace (64*2*C doubles)
@@ -332,6 +333,7 @@ class Plan:
         self._wreduce = {}         # layer key -> (workspace, nsplit, Cout, Cin) of the halo weight-gradient partials
         self._wgrad_deferred = []  # (forward group index, layer, WgradParams, flops) of the halo weight gradients
         self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
+        self.generation = 0        # bumped by every run_forward: a backward checks its activations are still the plan's
         self._build()
         if self.has_backward:
             self._finish_unpack()
@@ -391,25 +393,17 @@ class Plan:
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
         if bnb is not None:
-            nrows_b, sums_b, lib_ = int(cp._stats_rows), self.bn[bnb[0]].sums, e.lib
+            nrows_b = int(cp._stats_rows)
             assert nrows_b * 2 * cp.Cout <= self.stats.numel(), (L.key, nrows_b)
-            sbn = self.bn[bnb[0]]
-            if getattr(sbn, "xf_bwd", False):
-                # the BatchNorm whose sums this epilogue reduced has its backward apply fused into ITS consumer conv: turn the
-                # rows straight into that consumer's coefficient vectors (+ dgamma / dbeta) instead of the 16-copy sums
-                coef = self._bn_coef_op(bnb[0], self.stats, nrows_b)
+            # the epilogue's per-tile rows -> that BatchNorm's backward coefficients (+ dgamma / dbeta), for its apply pass or
+            # for the conv that applies them on load
+            coef = self._bn_coef_op(bnb[0], self.stats, nrows_b)
 
-                def run(st, ctx):
-                    s = fn(ref, st)
-                    if s:
-                        check(s, f"conv {L.key}")
-                    coef(st, ctx)
-            else:
-                def run(st, ctx):
-                    s = fn(ref, st)
-                    if s:
-                        check(s, f"conv {L.key}")
-                    check(lib_.gdrn_bn_fold_rows(ptr(self.stats), nrows_b, cp.Cout, ptr(sums_b), st), "bn_fold_rows")
+            def run(st, ctx):
+                s = fn(ref, st)
+                if s:
+                    check(s, f"conv {L.key}")
+                coef(st, ctx)
         else:
             def run(st, ctx):
                 s = fn(ref, st)
@@ -483,18 +477,11 @@ class Plan:
         self._unpack_pending.append((len(self.bwd_groups), L))
         return None  # marker, dropped when the groups are flattened
 
-    def _bn_sums(self, n):
-        off = getattr(self, "_bn_sums_off", 0)
-        assert off + n <= self.e.bn_sums_cap
-        self._bn_sums_off = off + n
-        return self.e.bn_sums_flat[off: off + n]
-
     def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
         """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
         e, lib = self.e, self.e.lib
         s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
-               scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32),
-               sums=self._bn_sums(2 * C_ * BN_SUM_COPIES), C=C_, npix=npix)
+               scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
         self.bn[bnkey] = s
         g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
         rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
@@ -515,9 +502,11 @@ class Plan:
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
 
-    def _xf_ok(self, L):
-        """can layer L's halo launches (forward and data gradient) take a fused operand transform?"""
+    def _xf_ok(self, L, mode=None, hw=0):
+        """can layer L's halo launches (forward and data gradient) take a fused operand transform (of that mode, on hw x hw maps)?"""
         e = self.e
+        if mode is not None and (not (e.xf_mask >> (mode - 1)) & 1 or hw > e.xf_maxhw):
+            return False
         return e.fuse_xf and self.bn_train and L.kind == "conv" and L.wfF is not None and L.KK == 9 and not L.s2
 
     def _bn_coef_op(self, bnkey, rows, nrows):
@@ -546,37 +535,35 @@ class Plan:
         e = self.e
         return e.fuse_bnb and e.use_halo and e.dt == BF16 and L.kind == "conv" and L.wfF is not None
 
-    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False):
-        """affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False, apply=True):
+        """BatchNorm(+ReLU) backward: [reduce -> coef ->] apply.  prereduced: dy arrives masked and the producing data-gradient
+        launch has already turned its epilogue rows into the coefficients (see _conv, bnb).
+        affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
         evaluated) instead of reading the stored activation `ymask` -- one tensor pass less in both kernels.
-        xf: the apply pass is left to the consumer halo conv (returns (ops, xf dict for _conv); dx is written by that conv)."""
+        xf: the apply pass is left to the consumer halo conv (returns (ops, xf dict for _conv); dx is written by that conv).
+        apply=False: only reduce + coef (the stem's weight-gradient kernel applies the coefficients itself)."""
         e, lib = self.e, self.e.lib
         s = self.bn[bnkey]
+        msc, msh = (s.scale, s.shift) if affine_mask else (None, None)
+        ym = None if affine_mask else ymask
+        ops = []
+        if prereduced:
+            self._bn_coef_op(bnkey, self.stats, 1)  # (allocates the coefficient vectors; the launch itself sits in _conv)
+            msc = msh = ym = None                    # dy is already masked
+        else:
+            nrows = int(lib.gdrn_bn_bwd_reduce_rows(s.npix, s.C, e.dt))
+            assert nrows > 0 and nrows * 2 * s.C <= self.stats.numel(), (bnkey, nrows)
+            coef = self._bn_coef_op(bnkey, self.stats, nrows)
+            ops += [lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ptr(ym), ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(msc), ptr(msh), s.npix,
+                                                                s.C, ptr(self.stats), e.dt, st), "bn_bwd_reduce"), coef]
         if xf:
-            assert g_out is None and (prereduced or affine_mask)
-            if prereduced:  # the producing data-gradient launch has already turned its rows into (ka, kb, kc): see _conv
-                assert getattr(s, "xf_bwd", False), bnkey
-                self._bn_coef_op(bnkey, self.stats, 1)  # allocates the vectors
-                return [], dict(mode=3, x2=raw, a=s.ka, b=s.kb, c=s.kc, out=dx, relu=False)
-            coef = self._bn_coef_op(bnkey, s.sums, BN_SUM_COPIES)
-            ops = [lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), None, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(s.scale), ptr(s.shift),
-                                                               s.npix, s.C, ptr(s.sums), e.dt, st), "bn_bwd_reduce"), coef]
-            return ops, dict(mode=4, x2=raw, a=s.ka, b=s.kb, c=s.kc, msc=s.scale, msh=s.shift, out=dx, relu=False)
-        g = e.P[bnkey + ".weight"]
-        dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
-        msc, msh = (ptr(s.scale), ptr(s.shift)) if affine_mask else (None, None)
-        ym = None if affine_mask else ptr(ymask)
-        if prereduced:  # dy arrives masked and the sums are complete (fused into the producing data-gradient conv)
-            return [lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), None, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g), ptr(s.sums),
-                                                                None, None, s.npix, s.C, ptr(dx), None, ptr(dg), ptr(db), e.dt, st),
-                                          "bn_bwd_apply")]
-        return [
-            lambda st, ctx: check(lib.gdrn_bn_bwd_reduce(ptr(dy), ym, ptr(raw), ptr(s.mean), ptr(s.invstd), msc, msh, s.npix, s.C,
-                                                         ptr(s.sums), e.dt, st), "bn_bwd_reduce"),
-            lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ym, ptr(raw), ptr(s.mean), ptr(s.invstd), ptr(g),
-                                                        ptr(s.sums), msc, msh, s.npix, s.C, ptr(dx), ptr(g_out), ptr(dg), ptr(db), e.dt, st),
-                                  "bn_bwd_apply"),
-        ]
+            assert g_out is None and ym is None
+            mode = 4 if msc is not None else 3
+            return ops, dict(mode=mode, x2=raw, a=s.ka, b=s.kb, c=s.kc, msc=msc, msh=msh, out=dx, relu=False)
+        if apply:
+            ops.append(lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ptr(ym), ptr(raw), ptr(s.ka), ptr(s.kb), ptr(s.kc), ptr(msc), ptr(msh), s.npix,
+                                                                   s.C, ptr(dx), ptr(g_out), e.dt, st), "bn_bwd_apply"))
+        return ops
 
     def _unpack_task(self, L, packed_ptr, grad, rows_valid, rows_off=0):
         from .cabi import PackTask
@@ -591,7 +578,7 @@ class Plan:
                         st=st, sb=sb, n=A1v * A2v * T * Bv, frag=0, pad_=0)
 
     def _finish_unpack(self):
-        """One gdrn_unpack_multi per gradient bucket (pnp | head | layer4+3 | rest), appended to the backward group that
+        """One gdrn_unpack_multi per gradient bucket (pnp | head | layer4 | layer3 | rest), appended to the backward group that
         completes the bucket, so the RCCL exchange of a bucket still starts as soon as its gradients exist."""
         from .cabi import to_device_table
 
@@ -599,13 +586,15 @@ class Plan:
         chunk = lib.gdrn_pack_chunk()
         ng = len(self.bwd_groups)
         assert ng == 29, ng
-        first_group = (25, 17, 8, 0)  # forward index of the LAST-executed group of buckets 0..3
+        # backward groups in forward order: stem(0) layer1(1-3) layer2(4-7) layer3(8-13) layer4(14-16) convT(17) head convs(18-23)
+        # head out(24) pnp convs(25-27) fc(28)
+        first_group = BUCKET_FIRST_GROUP  # forward index of the LAST-executed group of buckets 0..4
         from .cabi import WreduceTask
 
-        bucket_of = lambda gi: 0 if gi >= 25 else (1 if gi >= 17 else (2 if gi >= 8 else 3))
+        bucket_of = lambda gi: next(i for i, g0 in enumerate(first_group) if gi >= g0)
         # ---- grouped halo weight gradients: a common number of 8x8 pixel patches per workgroup within a bucket, chosen so
         # that the bucket's grid has ~wgrad_blocks workgroups (2 per CU resident); longest-running tasks first
-        wg_bucket = {0: [], 1: [], 2: [], 3: []}
+        wg_bucket = {i: [] for i in range(len(first_group))}
         for gi, L, wp, flops in self._wgrad_deferred:
             wg_bucket[bucket_of(gi)].append((L, wp, flops))
         self._wgrad_tables = []
@@ -643,8 +632,8 @@ class Plan:
             run.side = True
             self.bwd_groups[first_group[bkt]].append(run)
 
-        per_bucket = {0: [], 1: [], 2: [], 3: []}
-        red_bucket = {0: [], 1: [], 2: [], 3: []}
+        per_bucket = {i: [] for i in range(len(first_group))}
+        red_bucket = {i: [] for i in range(len(first_group))}
         for gi, L in self._unpack_pending:
             bkt = bucket_of(gi)
             if L.key in self._wreduce:
@@ -706,7 +695,7 @@ class Plan:
         F32t = torch.float32
         # per-tile BN partial sums, max over layers: conv tiles need <= B*32768 floats (64-pixel tiles of the 64x64 maps at 256
         # channels); the direct stem kernel writes one [2][64] row per wave
-        n_stats = B * 32768 + 65536
+        n_stats = max(B * 32768 + 65536, 1024 * 2 * 512)  # ... and gdrn_bn_bwd_reduce writes <= 1024 rows of 2*C floats
         if e.stem_direct:
             n_stats = max(n_stats, int(lib.gdrn_stem_stats_rows(B)) * 128)
         self.stats = E(n_stats, dtype=F32t)
@@ -749,12 +738,12 @@ class Plan:
                 gw = e.grads["backbone.conv1.weight"]
                 assert gw.is_contiguous() and gw.dtype == torch.float32
                 sw_ws = e._empty(int(lib.gdrn_stem_wgrad_parts(B)) * 64 * 224, dtype=torch.float32)
-                grp.append(self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0)[0])  # the reduce; the apply is fused below
+                grp += self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0, apply=False)  # reduce + coef; the apply is fused below
 
-                def stem_wgrad(st, ctx, a=(self.img_p, g_stem, raw0, sb.mean, sb.invstd, gam, sb.sums, dgam, dbet, sw_ws, gw)):
+                def stem_wgrad(st, ctx, a=(self.img_p, g_stem, raw0, sb.ka, sb.kb, sb.kc, sw_ws, gw)):
                     # tensors bound as a default argument: _build() reuses short local names further down (late-binding closures)
-                    check(lib.gdrn_stem_wgrad(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), ptr(a[6]), ptr(a[7]), ptr(a[8]), B,
-                                              ptr(a[9]), ptr(a[10]), e.dt, st), "stem_wgrad")
+                    check(lib.gdrn_stem_wgrad(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), B, ptr(a[6]), ptr(a[7]), e.dt, st),
+                          "stem_wgrad")
 
                 stem_wgrad.meta = dict(kernel="stem_wgrad_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1:wgrad")
                 grp.append(stem_wgrad)
@@ -794,7 +783,7 @@ class Plan:
                 op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
                                     xf=dict(pend["xf"], out=x) if pend else None)
                 self.fwd.append(op)
-                xf1 = self._xf_ok(L2)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
+                xf1 = self._xf_ok(L2, 1, Ho)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
                 self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, None if xf1 else a1)
                 s1 = self.bn[pfx + ".bn1"]
                 op, cp = self._conv(L2, raw1 if xf1 else a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None,
@@ -802,7 +791,7 @@ class Plan:
                 self.fwd.append(op)
                 # block output relu(bn2(raw2) + identity): left to the next block's conv1 when that is a halo launch
                 nxt1 = e.layers.get(f"backbone.layer{li}.{b + 1}.conv1")
-                xf_out = nxt1 is not None and self._xf_ok(nxt1)
+                xf_out = nxt1 is not None and self._xf_ok(nxt1, 2, Ho)
                 if Ld is not None:
                     rawd, idn = E(B, Ho, Ho, pl), (None if xf_out else E(B, Ho, Ho, pl))
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
@@ -831,10 +820,9 @@ class Plan:
                     # the bn2-backward sums (and d_out itself is the residual-path gradient g2)
                     pre2 = (b + 1 < nb) and self._fusable(e.layers[f"backbone.layer{li}.{b + 1}.conv1"])
                     # BatchNorm-backward apply passes fused into the data-gradient conv that consumes their result (xf modes 3 / 4)
-                    xfb2 = pre2 and self._xf_ok(L2)
+                    xfb2 = pre2 and self._xf_ok(L2, 3, Ho)
                     need_dx = d_x is not None
-                    xfb1 = self._fusable(L2) and self._xf_ok(L1) and Ld is None and need_dx
-                    self.bn[pfx + ".bn2"].xf_bwd, self.bn[pfx + ".bn1"].xf_bwd = xfb2, xfb1
+                    xfb1 = self._fusable(L2) and self._xf_ok(L1, 3, Ho) and Ld is None and need_dx
                     xd2 = xd1 = None
                     if xfb2:
                         g2 = d_out
@@ -886,7 +874,7 @@ class Plan:
         h = "rot_head_net.features."
         LT = e.layers[h + "0"]
         rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
-        xf_first = (not FOLD) and (not HEAD_CONVS[0][2]) and self._xf_ok(e.layers[h + str(HEAD_CONVS[0][0])])
+        xf_first = (not FOLD) and (not HEAD_CONVS[0][2]) and self._xf_ok(e.layers[h + str(HEAD_CONVS[0][0])], 1, 16)
         if FOLD:
             self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
         else:
@@ -927,7 +915,7 @@ class Plan:
             self.tensors.update({h + f"{ci}.raw": raw, h + f"{ci}.act": act})
             nxt = HEAD_CONVS[hi + 1] if hi + 1 < len(HEAD_CONVS) else None
             # this conv's BatchNorm + ReLU is applied by the next head conv on load when no upsampling sits in between
-            xf_next = (not FOLD) and nxt is not None and not nxt[2] and self._xf_ok(e.layers[h + str(nxt[0])])
+            xf_next = (not FOLD) and nxt is not None and not nxt[2] and self._xf_ok(e.layers[h + str(nxt[0])], 1, Hh)
             if FOLD:
                 self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
             else:
@@ -941,8 +929,7 @@ class Plan:
                 # d_act is produced by the NEXT head conv's data gradient; when no upsampling sits in between, that
                 # launch masks it and reduces this BN's backward sums
                 pre = nxt is not None and not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])
-                xfb = self._xf_ok(Lc)  # this BN's backward apply inside Lc's data-gradient launch (mode 3, or 4 = with the ReLU mask)
-                self.bn[h + str(bi)].xf_bwd = xfb and pre
+                xfb = self._xf_ok(Lc, 3 if pre else 4, Hh)  # this BN's backward apply inside Lc's data-gradient launch (mode 3, or 4 = with the ReLU mask)
                 xd = None
                 if xfb:
                     ops, xd = self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre, xf=True)
@@ -1105,6 +1092,7 @@ class Plan:
         if e.dry:
             raise cabi.GdrnHipError("dry (build-only) engine: there is no CPU execution path")
         st = e._stream()
+        self.generation += 1
         if self.bn_train:
             e.bn_epoch += 1  # the kernels update the running statistics behind autograd's back
         elif self.eval_prep:
@@ -1149,7 +1137,7 @@ class Plan:
             main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
 
     def _bucket_marks(self):
-        """index of the last backward op of each gradient bucket (pnp | head | layer4+3 | rest)."""
+        """index of the last backward op of each gradient bucket (pnp | head | layer4 | layer3 | rest)."""
         if hasattr(self, "_marks"):
             return self._marks
         n_groups = len(self.bwd_groups)
@@ -1159,7 +1147,7 @@ class Plan:
         for s in sizes:
             cum += s
             ends.append(cum - 1)
-        # reversed order: fc, pnp x3 | head-out, head convs x6, convT | layer4 (3) + layer3 (6) | layer2 (4), layer1 (3), stem
-        bounds = [4, 4 + 8, 4 + 8 + 9, n_groups]
+        # reversed order: fc, pnp x3 | head-out, head convs x6, convT | layer4 (3) | layer3 (6) | layer2 (4), layer1 (3), stem
+        bounds = [n_groups - g0 for g0 in BUCKET_FIRST_GROUP]
         self._marks = {ends[b - 1]: i for i, b in enumerate(bounds)}
         return self._marks

@@ -41,6 +41,8 @@ _LR_WORD = cabi.RangerTask.lr.offset // 4
 
 
 class Ranger(Optimizer):
+    takes_grad_scale = True  # step(grad_scale=): GDRN.train_step folds the 1/world of a SUM all-reduce into the kernel
+
     def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5, weight_decay=0,
                  use_gc=True, gc_conv_only=False):
         if not 0.0 <= alpha <= 1.0:
@@ -98,10 +100,11 @@ class Ranger(Optimizer):
         return cache[gi][1:5]
 
     @torch.no_grad()
-    def step(self, closure=None, grads=None):
+    def step(self, closure=None, grads=None, grad_scale=1.0):
         """grads: optional dict param -> fp32 gradient tensor (used by the fused train step to read the
         engine's flat gradient buffer directly instead of ``p.grad``).  One multi-tensor launch per param group
-        when every tensor of the group is at the same step count (the normal case); per-tensor launches otherwise."""
+        when every tensor of the group is at the same step count (the normal case); per-tensor launches otherwise.
+        grad_scale: factor applied to every gradient inside the kernel (1/world_size after a SUM all-reduce)."""
         lib = cabi.load()
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
@@ -131,11 +134,13 @@ class Ranger(Optimizer):
                 cabi.check(
                     lib.gdrn_ranger_multi(tab.data_ptr(), stt.data_ptr(), nt, nrows, beta1, beta2, group["eps"], group["weight_decay"],
                                           step_size, 1 if n_sma > self.N_sma_threshhold else 0, 1 if step % group["k"] == 0 else 0,
-                                          self.alpha, st),
+                                          self.alpha, float(grad_scale), st),
                     "ranger_multi",
                 )
             else:
                 for (p, g), state in zip(items, states):
+                    if grad_scale != 1.0:
+                        g = g * float(grad_scale)
                     step = state["step"]
                     n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
                     gc, rows, cols = self._gc_shape(p, g)

@@ -54,14 +54,14 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *      BatchNorm(+ReLU) whose raw input was bnb_x[m][co] (channel stride bnb_cs).  The epilogue then also applies the
  *      ReLU mask -- (bnb_mask[m][co] > 0) when bnb_mask is given, else (bnb_x*bnb_scale + bnb_shift > 0) when
  *      bnb_scale/bnb_shift are given, else none -- stores the MASKED gradient and writes the two BatchNorm-backward sums
- *      of its pixel tile to bnb_rows[tile][2][Cout] (gdrn_conv3x3_stats_rows tiles, plain stores); gdrn_bn_fold_rows
- *      turns the rows into the [GDRN_BN_SUM_COPIES][2][Cout] sums gdrn_bn_bwd_apply reads: the separate reduction pass
- *      over (dy, x, mask) disappears.
+ *      of its pixel tile to bnb_rows[tile][2][Cout] (gdrn_conv3x3_stats_rows tiles, plain stores); gdrn_bn_bwd_coef
+ *      turns the rows into the BatchNorm backward's coefficients: the separate reduction pass over (dy, x, mask) disappears.
  *   xf_mode != 0 (gdrn_conv3x3_halo only): the conv's INPUT is v(x, x2) evaluated per element while the patch is staged
  *      in LDS, rounded to bf16, zero outside the image (the padding applies to v, not to x), with per-input-channel
  *      fp32 vectors [Cin] (NULL a / b = 1, NULL c2 = 0):
- *        1: v = a*x + (c + c2)                      BatchNorm(+ReLU) forward apply of the producer (a = scale, c = shift)
- *        2: v = b*x2 + (a*x + (c + c2))             ... with a residual / second normalised branch (BasicBlock output)
+ *        1: v = a*x + c                             BatchNorm(+ReLU) forward apply of the producer (a = scale, c = shift)
+ *        2: v = (a*x + c) + bf16(b*x2 + c2)         ... with a residual (b = 1, c2 = 0) or a second normalised branch (the
+ *                                                   BasicBlock downsample path, rounded as the pass that materialised it did)
  *        3: v = a*x + (b*x2 + c)                    BatchNorm backward apply: x = masked dy, x2 = the BN's raw input,
  *                                                   (a, b, c) from gdrn_bn_bwd_coef
  *        4: v = a*(x2*msc + msh > 0 ? x : 0) + (b*x2 + c)   the same with the ReLU mask recomputed from the forward affine
@@ -114,12 +114,11 @@ int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, i
  * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel
  * (gdrn_bn_bwd_apply's formula, rounded to bf16) is evaluated while the tile is staged instead of being written and re-read.
  *   canvas [N][262][272][4] bf16; g, raw [N][128][128][64] bf16 (masked upstream gradient / the conv output BatchNorm saw);
- *   mean, invstd, gamma [64]; sums [GDRN_BN_SUM_COPIES][2][64] from gdrn_bn_bwd_reduce; dgamma, dbeta [64] (nullable) are written
- *   as gdrn_bn_bwd_apply writes them.  mean == NULL: plain weight gradient with dy = g (raw .. dbeta ignored).
+ *   a, b, c [64] from gdrn_bn_bwd_coef.  a == NULL: plain weight gradient with dy = g (raw, b, c ignored).
  *   ws: gdrn_stem_wgrad_parts(N) * 64 * 224 floats of scratch; grad: fp32 OIHW [64][3][7][7], overwritten.  bf16 only. */
 int gdrn_stem_wgrad_parts(int N);
-int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* mean, const float* invstd, const float* gamma,
-                    const float* sums, float* dgamma, float* dbeta, int N, float* ws, float* grad, int dtype, void* stream);
+int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const float* a, const float* b, const float* c, int N,
+                    float* ws, float* grad, int dtype, void* stream);
 /* Skinny-M linear layer (M <= 64 rows, bf16): y[m][n] = act(sum_k x[m][k]*w[n][k] + bias[n]) with the K range split
  * over workgroups (the layer is bound by reading w once).  Replaces F.linear + LeakyReLU of Patch-PnP's fc1
  * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in
@@ -213,25 +212,24 @@ int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* runn
                         float eps, int C, float* scale, float* shift, void* stream);
 int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                   long long npix, int C, int relu, int dtype, void* stream);
-/* sums[r][0][c] += sum g, sums[r][1][c] += sum g*xhat with g = dy * (ymask > 0) (ymask NULL: g = dy), spread over
- * r < GDRN_BN_SUM_COPIES copies (same-address atomics are slow; gdrn_bn_bwd_apply adds the copies up).  ACCUMULATES with
- * atomics: the caller clears sums[GDRN_BN_SUM_COPIES*2*C] first (the engine: one fill per backward pass for all layers) */
-#define GDRN_BN_SUM_COPIES 16
-/* mask_scale/mask_shift (both or neither): the ReLU mask is recomputed as (x*mask_scale + mask_shift > 0), i.e. from
- * the forward affine of a BN->ReLU without residual, instead of reading the stored activation (one tensor pass less) */
+/* BatchNorm backward = (1) per-channel sums of g and g*xhat, g = dy * (ymask > 0) * (x*mask_scale + mask_shift > 0) (each mask
+ * optional), as partial rows rows[r][0][c] = sum g, rows[r][1][c] = sum g*xhat: one row per workgroup of gdrn_bn_bwd_reduce
+ * (gdrn_bn_bwd_reduce_rows(npix, C, dtype) <= 1024 of them, plain stores: deterministic, nothing to pre-zero), or one per pixel
+ * tile straight from the epilogue of the data-gradient conv that produced dy (gdrn_conv_params.bnb_*);
+ * (2) gdrn_bn_bwd_coef: rows -> dgamma, dbeta and the coefficients (a, b, c) of dx = a*g + (b*x + c);
+ * (3) the apply pass gdrn_bn_bwd_apply (optional g_out = g), or no pass at all when the consumer of dx is a halo conv
+ * (xf_mode 3 / 4) or the stem weight gradient (gdrn_stem_wgrad), which evaluate it while staging their operand.
+ * mask_scale/mask_shift (both or neither): the ReLU mask recomputed from the forward affine of a BN->ReLU without residual
+ * instead of reading the stored activation (one tensor pass less). */
+int gdrn_bn_bwd_reduce_rows(long long npix, int C, int dtype);
 int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                       const float* mask_scale, const float* mask_shift, long long npix, int C, float* sums, int dtype,
+                       const float* mask_scale, const float* mask_shift, long long npix, int C, float* rows, int dtype,
                        void* stream);
-/* dx = gamma*invstd*(g - sums0/n - xhat*sums1/n); optional g_out = g; dgamma = sums1, dbeta = sums0 */
-/* sums[r][*][c] = sum of rows r, r+COPIES, ... of rows[nrows][2][C] (r < GDRN_BN_SUM_COPIES): overwrites sums */
-int gdrn_bn_fold_rows(const float* rows, int nrows, int C, float* sums, void* stream);
-int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* mean, const float* invstd,
-                      const float* gamma, const float* sums, const float* mask_scale, const float* mask_shift,
-                      long long npix, int C, void* dx, void* g_out, float* dgamma, float* dbeta, int dtype, void* stream);
-/* BatchNorm-backward sums -> the per-channel coefficients of dx = a*g + (b*x + c) (what gdrn_bn_bwd_apply evaluates) for a
- * consumer that applies them itself while staging its operand (gdrn_conv3x3_halo xf_mode 3 / 4), plus dgamma = sum g*xhat,
- * dbeta = sum g (both or neither NULL).  rows: [nrows][2][C] -- the per-tile rows of a fused data-gradient epilogue
- * (bnb_rows) or the [GDRN_BN_SUM_COPIES][2][C] sums of gdrn_bn_bwd_reduce; npix = elements per channel. */
+int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const float* a, const float* b, const float* c,
+                      const float* mask_scale, const float* mask_shift, long long npix, int C, void* dx, void* g_out,
+                      int dtype, void* stream);
+/* rows [nrows][2][C] (fp64 accumulation, one launch of C/4 workgroups) -> a = gamma*invstd, b = -a*invstd*sum(g*xhat)/npix,
+ * c = -a*sum(g)/npix - b*mean; dgamma = sum g*xhat, dbeta = sum g (both or neither NULL); npix = elements per channel. */
 int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long npix, const float* gamma, const float* mean,
                      const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream);
 int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
@@ -362,9 +360,11 @@ typedef struct gdrn_ranger_task {
 int gdrn_pack_chunk(void);
 int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream);
 int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+/* grad_scale: every gradient element is multiplied by it first (1/world_size when g holds the all-reduced SUM of the ranks'
+ * gradients: the averaging pass over the 140 MB buffer disappears; 1.0 otherwise). */
 int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
                       float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha,
-                      void* stream);
+                      float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Inference post-processing on the device: get_out_coor + get_out_mask

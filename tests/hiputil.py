@@ -80,7 +80,7 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
               out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None):
     """bnb (halo only): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
-    the second return value is then the [16][2][Cout] sums buffer.
+    the second return value is then the [tiles][2][Cout] rows buffer.
     xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging."""
     lib = cabi.load()
     if halo:  # the halo kernel takes the fragment-major permutation of the same operand
@@ -108,18 +108,15 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     if bnb is not None:
         nrows = lib.gdrn_conv3x3_stats_rows(C.byref(cp))
         rows_t = torch.full((nrows, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
-        sums = torch.full((16, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
         cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(bnb["x"]), ptr(bnb.get("mask")), bnb["x"].shape[-1]
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
         cp.bnb_rows = ptr(rows_t)
-        stats = sums
+        stats = rows_t  # per-tile rows [nrows][2][Cout]: callers sum over dim 0
     if xf is not None:
         cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
         cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
         cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
     check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
-    if bnb is not None:
-        check(lib.gdrn_bn_fold_rows(ptr(rows_t), nrows, Cout, ptr(sums), stream()), "bn_fold_rows")
     torch.cuda.synchronize()
     return y, stats
 

@@ -303,12 +303,14 @@ def test_full_size_properties_bs64():
         assert abs(L[k].item() - L2[k].item()) <= 2e-2 * max(abs(L[k].item()), 1e-3), k
 
 
-def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch, capsys):
+def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
     """bf16 engine with the BatchNorm apply passes evaluated inside the consumer halo convs (GDRN_FUSE_XF=1, the default)
-    against the same engine with separate gdrn_bn_apply / gdrn_bn_bwd_apply launches: the fused arithmetic is the separate
-    kernels' arithmetic, so layer1 (no downsample branch) is bit-identical in the forward pass; further down the fused path
-    skips the bf16 rounding of the normalised downsample branch (3 places) and the sums take another summation order, which
-    the random-init graph amplifies -- checked stage by stage against a loose bound and reported."""
+    against the same engine with separate gdrn_bn_apply / gdrn_bn_bwd_apply launches.  The fused transforms evaluate the
+    separate kernels' arithmetic (same fma association, same bf16 roundings), the statistics and BatchNorm-backward sums are
+    per-tile rows added up in a fixed order, so EVERY activation and every gradient along the chain is bit-identical --
+    any mis-wired tensor or coefficient vector in the fused plan shows up as a difference at its stage.  Parameter
+    gradients: bit-identical for the halo layers (workspace partials), 1e-5 for the layers whose weight gradient
+    accumulates with fp32 atomics (stride-2 / 1x1 / Patch-PnP / fc)."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     B = 4
@@ -328,25 +330,22 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch, capsys):
         n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith("conv3x3_halo") and not op.meta["kernel"].endswith(",0>"))
         assert n_xf == (63 if fx == "1" else 0), n_xf
         res[fx] = (losses.cpu(), {k: v.float().cpu().clone() for k, v in plan.tensors.items()}, {n: g.cpu().clone() for n, g in eng.grads.items()},
-                   plan.head_out.cpu().clone())
-    l0, t0, g0, h0 = res["0"]
-    l1, t1, g1, h1 = res["1"]
-    for k in t0:
-        if k.startswith("backbone.layer1.") and k.split(".")[-1] in ("raw1", "a1", "raw2", "out"):
-            assert torch.equal(t0[k], t1[k]), k
-    report = []
-    for k in t0:
-        assert torch.isfinite(t1[k]).all(), k
-        r = rel(t1[k], t0[k])
-        report.append((r, k))
-        assert r < (0.08 if ".d_" in k else 0.03), (k, r)
-    assert rel(h1, h0) < 0.03
-    worst_g = max((rel(g1[n], g0[n]), n) for n in g0 if g0[n].numel() > 4096)
-    with capsys.disabled():
-        print("\nfused vs separate BN applies: worst activation %.3e (%s), worst gradient tensor %.3e (%s), losses %s vs %s"
-              % (max(report)[0], max(report)[1], worst_g[0], worst_g[1], l1.tolist(), l0.tolist()))
-    assert worst_g[0] < 0.15
-    assert ((l1 - l0).abs() / (l0.abs() + 1e-3))[:5].max() < 0.03
+                   plan.head_out.cpu().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+    l0, t0, g0, h0, r0 = res["0"]
+    l1, t1, g1, h1, r1 = res["1"]
+    bad = [(k, rel(t1[k], t0[k])) for k in t0 if not torch.equal(t0[k], t1[k])]
+    assert not bad, bad[:12]
+    assert torch.equal(h0, h1) and torch.equal(l0, l1)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    halo = lambda n: n.endswith("weight") and g0[n].dim() == 4 and g0[n].shape[2] == 3 and ("layer" in n or "rot_head" in n) and n not in (
+        "backbone.layer2.0.conv1.weight", "backbone.layer3.0.conv1.weight", "backbone.layer4.0.conv1.weight", "rot_head_net.features.0.weight")
+    for n in g0:
+        assert torch.isfinite(g1[n]).all(), n
+        if halo(n) or "bn" in n or n.split(".")[-2] in ("1", "4", "7", "11", "14", "18", "21") and "rot_head" in n:
+            assert torch.equal(g0[n], g1[n]), (n, rel(g1[n], g0[n]))
+        else:
+            assert rel(g1[n], g0[n]) < 1e-5, (n, rel(g1[n], g0[n]))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -294,9 +294,9 @@ def test_conv3x3_halo_operand_transform(H, case, mode):
     V = lambda t: t.view(1, -1, 1, 1)
     relu = mode in (1, 2)
     if mode == 1:
-        v = x * V(a) + V(c + c2)
+        v = x * V(a) + V(c)
     elif mode == 2:
-        v = x2 * V(b) + (x * V(a) + V(c + c2))
+        v = (x * V(a) + V(c)) + H.rounded(x2 * V(b) + V(c2), dt)
     elif mode == 3:
         v = V(a) * x + (V(b) * x2 + V(c))
     else:
@@ -308,7 +308,7 @@ def test_conv3x3_halo_operand_transform(H, case, mode):
     d = lambda t: t.to(dev).float().contiguous()
     out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
     xf = dict(mode=mode, relu=relu, a=d(a), c=d(c), out=out)
-    if mode in (1, 2):
+    if mode == 2:
         xf["c2"] = d(c2)
     if mode >= 2:
         xf.update(x2=H.nhwc(x2, dt), b=d(b))
@@ -367,9 +367,9 @@ def test_bn_bwd_coef(H, nrows, C_):
     gamma, mean = torch.rand(C_) + 0.5, H.randn(61, C_) * 0.3
     invstd = torch.rand(C_, generator=torch.Generator().manual_seed(62)) + 0.5
     npix = 4096
-    d = lambda t: t.to(dev).float().contiguous()
+    rows_d, gamma_d, mean_d, invstd_d = (t.to(dev).float().contiguous() for t in (rows, gamma, mean, invstd))  # alive across the launch
     o = [torch.full((C_,), float("nan"), device=dev) for _ in range(5)]
-    check(lib.gdrn_bn_bwd_coef(ptr(d(rows)), nrows, C_, npix, ptr(d(gamma)), ptr(d(mean)), ptr(d(invstd)), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]),
+    check(lib.gdrn_bn_bwd_coef(ptr(rows_d), nrows, C_, npix, ptr(gamma_d), ptr(mean_d), ptr(invstd_d), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]),
                                ptr(o[4]), H.stream()), "bn_bwd_coef")
     torch.cuda.synchronize()
     s = rows.double().sum(0)
@@ -455,13 +455,18 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
     check(lib.gdrn_bn_apply(ptr(xd), ptr(scale), ptr(shift), ptr(resd), ptr(y), npix, C_, 1, dt, st), "bn_apply")
     assert H.rel(H.nchw(y), yref) < TOL[dt]
     assert H.rel(rmd, rm) < 1e-5 and H.rel(rvd, rv) < 1e-5 and int(nbt) == 1
-    sums = torch.zeros(16 * 2 * C_, device=dev)  # GDRN_BN_SUM_COPIES
+    nrows = lib.gdrn_bn_bwd_reduce_rows(npix, C_, dt)
+    assert 1 <= nrows <= 1024
+    rows = torch.full((nrows, 2, C_), float("nan"), device=dev)  # every row is written (no pre-zeroing, no atomics)
     dx, gout = torch.empty_like(xd), torch.empty_like(xd)
-    dg, db = mk(), mk()
+    dg, db, ka, kb, kc = mk(), mk(), mk(), mk(), mk()
     yd = H.nhwc(yref.detach(), dt)  # mask source: the stored activation
-    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), None, None, npix, C_, ptr(sums), dt, st), "bn_bwd_reduce")
-    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), None, None, npix, C_, ptr(dx),
-                                ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), None, None, npix, C_, ptr(rows), dt, st), "bn_bwd_reduce")
+    check(lib.gdrn_bn_bwd_coef(ptr(rows), nrows, C_, npix, ptr(gam_d), ptr(mean), ptr(invstd), ptr(ka), ptr(kb), ptr(kc), ptr(dg), ptr(db), st), "bn_bwd_coef")
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), ptr(yd), ptr(xd), ptr(ka), ptr(kb), ptr(kc), None, None, npix, C_, ptr(dx), ptr(gout), dt, st), "bn_bwd_apply")
+    rows2 = torch.full((nrows, 2, C_), float("nan"), device=dev)
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), ptr(yd), ptr(xd), ptr(mean), ptr(invstd), None, None, npix, C_, ptr(rows2), dt, st), "bn_bwd_reduce")
+    assert torch.equal(rows, rows2)  # deterministic
     tol = 2e-4 if dt == F32 else 1e-2
     assert H.rel(H.nchw(dx), x.grad) < tol
     assert H.rel(dg, gam.grad) < tol and H.rel(db, bet.grad) < tol
@@ -494,12 +499,15 @@ def test_batchnorm_bwd_affine_mask(H, dt, C_, B, Hh):
     st = H.stream()
     check(lib.gdrn_bn_finalize(ptr(part), 1, C_, float(npix), ptr(gam_d), ptr(bet_d), None, None, None, 0.1, 1e-5, ptr(mean),
                                ptr(invstd), ptr(scale), ptr(shift), None, st), "bn_finalize")
-    sums = torch.zeros(16 * 2 * C_, device=dev)  # GDRN_BN_SUM_COPIES
+    nrows = lib.gdrn_bn_bwd_reduce_rows(npix, C_, dt)
+    rows = torch.full((nrows, 2, C_), float("nan"), device=dev)
+    ka, kb, kc = mk(), mk(), mk()
     dx, gout = torch.empty_like(xd), torch.empty_like(xd)
-    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), None, ptr(xd), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), npix, C_, ptr(sums), dt, st),
+    check(lib.gdrn_bn_bwd_reduce(ptr(dyd), None, ptr(xd), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), npix, C_, ptr(rows), dt, st),
           "bn_bwd_reduce")
-    check(lib.gdrn_bn_bwd_apply(ptr(dyd), None, ptr(xd), ptr(mean), ptr(invstd), ptr(gam_d), ptr(sums), ptr(scale), ptr(shift), npix, C_,
-                                ptr(dx), ptr(gout), ptr(dg), ptr(db), dt, st), "bn_bwd_apply")
+    check(lib.gdrn_bn_bwd_coef(ptr(rows), nrows, C_, npix, ptr(gam_d), ptr(mean), ptr(invstd), ptr(ka), ptr(kb), ptr(kc), ptr(dg), ptr(db), st), "bn_bwd_coef")
+    check(lib.gdrn_bn_bwd_apply(ptr(dyd), None, ptr(xd), ptr(ka), ptr(kb), ptr(kc), ptr(scale), ptr(shift), npix, C_, ptr(dx), ptr(gout), dt, st),
+          "bn_bwd_apply")
     torch.cuda.synchronize()
     tol = 2e-4 if dt == F32 else 1e-2
     assert H.rel(H.nchw(dx), x.grad) < tol
@@ -774,9 +782,9 @@ def test_stem_wgrad_fused_bn_backward(H, B, fused):
         b = -a * invstd * (s2 / npix)
         c = -a * (s1 / npix) - b * mean
         dy = H.rounded(a[None, :, None, None] * g + (b[None, :, None, None] * raw + c[None, :, None, None]), dt)
-        sums = torch.zeros(16, 2, 64)
-        sums[3, 0], sums[5, 1] = s1 * 0.25, s2 * 0.5  # spread over the copies: the kernel adds them up
-        sums[9, 0], sums[0, 1] = s1 * 0.75, s2 * 0.5
+        rows = torch.zeros(16, 2, 64)
+        rows[3, 0], rows[5, 1] = s1 * 0.25, s2 * 0.5  # spread over partial rows: gdrn_bn_bwd_coef adds them up
+        rows[9, 0], rows[0, 1] = s1 * 0.75, s2 * 0.5
     else:
         dy = g
     x = H.rounded(img, dt).requires_grad_(False)
@@ -788,13 +796,14 @@ def test_stem_wgrad_fused_bn_backward(H, B, fused):
     dgam = torch.full((64,), float("nan"), dtype=torch.float32, device=dev)
     dbet = torch.full((64,), float("nan"), dtype=torch.float32, device=dev)
     if fused:
-        md, isd, gmd, sd = mean.to(dev), invstd.to(dev), gamma.to(dev), sums.to(dev).contiguous()
-        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), ptr(rawd), ptr(md), ptr(isd), ptr(gmd), ptr(sd), ptr(dgam), ptr(dbet), B, ptr(ws), ptr(grad),
-                                  dt, H.stream()), "stem_wgrad")
+        md, isd, gmd, sd = mean.to(dev), invstd.to(dev), gamma.to(dev), rows.to(dev).contiguous()
+        ka, kb, kc = (torch.full((64,), float("nan"), dtype=torch.float32, device=dev) for _ in range(3))
+        check(lib.gdrn_bn_bwd_coef(ptr(sd), 16, 64, npix, ptr(gmd), ptr(md), ptr(isd), ptr(ka), ptr(kb), ptr(kc), ptr(dgam), ptr(dbet), H.stream()), "bn_bwd_coef")
+        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), ptr(rawd), ptr(ka), ptr(kb), ptr(kc), B, ptr(ws), ptr(grad), dt, H.stream()), "stem_wgrad")
     else:
-        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, None, None, None, None, None, None, B, ptr(ws), ptr(grad), dt, H.stream()), "stem_wgrad")
+        check(lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, None, None, None, B, ptr(ws), ptr(grad), dt, H.stream()), "stem_wgrad")
     torch.cuda.synchronize()
     assert H.rel(grad.cpu(), w.grad) < (4e-3 if fused else 1e-4)  # fused: dy is re-rounded to bf16 from fp32 constants
     if fused:
         assert H.rel(dbet.cpu(), s1) < 1e-5 and H.rel(dgam.cpu(), s2) < 1e-5
-    assert lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, ptr(dgam), None, None, None, None, None, B, ptr(ws), ptr(grad), dt, H.stream()) == -1
+    assert lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, ptr(dgam), None, None, B, ptr(ws), ptr(grad), dt, H.stream()) == -1
