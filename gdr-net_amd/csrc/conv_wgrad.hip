@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
     const char* dyg = reinterpret_cast<const char*>(p.dy);
     const char* xg = reinterpret_cast<const char*>(p.x);
     const int HW = p.Ho * p.Wo;
+    // every feature map of the path has power-of-two sides: pixel -> (n, oy, ox) with shifts instead of two integer divisions
+    // per gathered row and stage (the PMC pass of round 1 counted 11 VALU per MFMA in this kernel, most of them this index math)
+    const bool pow2 = (p.Wo & (p.Wo - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int lgW = 31 - __builtin_clz(p.Wo), lgHW = 31 - __builtin_clz(HW);
 
     uint4 ra[LDA], rb[LDB];
     auto load_stage = [&](int s) {
@@ -88,9 +92,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
             const int m = m0 + rowB + RSB * i;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (m < p.M) {
-                const int n = m / HW;
-                const int rem = m - n * HW;
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                int n, oy, ox;
+                if (pow2) {
+                    n = m >> lgHW;
+                    const int rem = m & (HW - 1);
+                    oy = rem >> lgW;
+                    ox = rem & (p.Wo - 1);
+                } else {
+                    n = m / HW;
+                    const int rem = m - n * HW;
+                    oy = rem / p.Wo;
+                    ox = rem - oy * p.Wo;
+                }
                 const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
                 if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
                     v = *reinterpret_cast<const uint4*>(xg + ((size_t)((n * p.Hi + iy) * p.Wi + ix) * p.x_cs + ci0) * ESZ + segB * 16);

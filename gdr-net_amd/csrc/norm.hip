@@ -46,6 +46,14 @@ __global__ __launch_bounds__(256) void bn_finalize_rows_kernel(const float* __re
     __shared__ double red[4][8];
     double tot[8];
     const int c4 = blockIdx.x * 4;
+    // the per-channel parameters are fetched before the reduction, not after it (a second dependent memory round trip in a
+    // kernel that is nothing but latency)
+    float k_g = 0.f, k_b = 0.f, k_rm = 0.f, k_rv = 0.f;
+    if (threadIdx.x < 4) {
+        k_g = gamma[c4 + threadIdx.x];
+        k_b = beta[c4 + threadIdx.x];
+        if (running_mean != nullptr) { k_rm = running_mean[c4 + threadIdx.x]; k_rv = running_var[c4 + threadIdx.x]; }
+    }
     rows_total4(partial, rows, C, c4, tot, red);
     if (threadIdx.x < 4) {
         const int ch = c4 + threadIdx.x;
@@ -56,13 +64,13 @@ __global__ __launch_bounds__(256) void bn_finalize_rows_kernel(const float* __re
         const double is = 1.0 / sqrt(var + (double)eps);
         mean[ch] = (float)m;
         invstd[ch] = (float)is;
-        const float sc = gamma[ch] * (float)is;
+        const float sc = k_g * (float)is;
         scale[ch] = sc;
-        shift[ch] = beta[ch] - (float)m * sc;
+        shift[ch] = k_b - (float)m * sc;
         if (running_mean != nullptr) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
-            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+            running_mean[ch] = (1.f - momentum) * k_rm + momentum * (float)m;
+            running_var[ch] = (1.f - momentum) * k_rv + momentum * (float)unb;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
@@ -77,6 +85,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
     __shared__ double red[4][8];
     double tot[8];
     const int c4 = blockIdx.x * 4;
+    float k_g = 0.f, k_mu = 0.f, k_is = 0.f;  // fetched before the reduction (see bn_finalize_rows_kernel)
+    if (threadIdx.x < 4) { k_g = gamma[c4 + threadIdx.x]; k_mu = mean[c4 + threadIdx.x]; k_is = invstd[c4 + threadIdx.x]; }
     rows_total4(rows, nrows, C, c4, tot, red);
     if (threadIdx.x < 4) {
         const int ch = c4 + threadIdx.x;
@@ -84,10 +94,10 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
         if (dgamma != nullptr) { dbeta[ch] = m1; dgamma[ch] = m2; }
         m1 *= inv_n;
         m2 *= inv_n;
-        const float is = invstd[ch], a = gamma[ch] * is, b = -a * is * m2;
+        const float a = k_g * k_is, b = -a * k_is * m2;
         ka[ch] = a;
         kb[ch] = b;
-        kc[ch] = -a * m1 - b * mean[ch];
+        kc[ch] = -a * m1 - b * k_mu;
     }
 }
 
@@ -145,20 +155,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ msh, long long npix, int C,
                                                             float* __restrict__ rows, int rows_per_block) {
     constexpr int V = Vec16<T>::VEC;
-    __shared__ float acc[2 * 512];
     const int tpr = C / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
     // per-channel constants through LDS: one coalesced load round per workgroup instead of 4*V dependent scalar loads
     // per thread (those latency chains cost ~10 us per launch)
     __shared__ float kst[4][512];
+    __shared__ float part[4][2 * 512];  // per-wave partial sums, added up in wave order: no float atomics, bit-reproducible
     for (int c = threadIdx.x; c < C; c += 256) {
-        acc[c] = 0.f;
-        acc[C + c] = 0.f;
         kst[0][c] = mean[c];
         kst[1][c] = invstd[c];
         kst[2][c] = msc ? msc[c] : 0.f;
         kst[3][c] = msc ? msh[c] : 1.f;
     }
+    for (int i = threadIdx.x; i < 4 * 2 * 512; i += 256) (&part[0][0])[i] = 0.f;
     __syncthreads();
     float s1[V], s2[V], mu[V], is[V], ksc[V], ksh[V];
 #pragma unroll
@@ -184,8 +193,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             }
         }
     }
-    // lanes of a wave that share a channel vector (lane % tpr) are combined with shuffles; one LDS atomic per wave/channel
-    const int lane = threadIdx.x & 63;
+    // lanes of a wave that share a channel vector (lane % tpr) are combined with shuffles (fixed tree); every (wave, channel)
+    // slot of `part` then has exactly one writer
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int o = tpr; o < 64; o <<= 1) {
 #pragma unroll
         for (int j = 0; j < V; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
@@ -193,13 +203,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     if (rl < rpp && (tpr >= 64 || lane < tpr)) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            atomicAdd(&acc[cv * V + j], s1[j]);
-            atomicAdd(&acc[C + cv * V + j], s2[j]);
+            part[wave][cv * V + j] = s1[j];
+            part[wave][C + cv * V + j] = s2[j];
         }
     }
     __syncthreads();
     float* dst = rows + (size_t)blockIdx.x * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = acc[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
 }
 
 template <typename T>
@@ -430,10 +440,10 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
     constexpr int V = Vec16<T>::VEC;
     __shared__ double sg[2 * 128];
     __shared__ float kgb[2][512];
+    __shared__ float pp[2][256 * V];  // per-thread partial sums [row lane][channel]: added up in a fixed order (no atomics -> reproducible)
     const int n = blockIdx.x, cpg = C / G, c0 = blockIdx.y * CS, g0 = c0 / cpg, GS = CS / cpg;
     const int tpr = CS / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    for (int i = threadIdx.x; i < 2 * GS; i += 256) sg[i] = 0.0;
     for (int i = threadIdx.x; i < CS; i += 256) { kgb[0][i] = gamma[c0 + i]; kgb[1][i] = beta[c0 + i]; }
     __syncthreads();
     const T* xb = x + (size_t)n * HW * C + c0;
@@ -446,11 +456,17 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
     }
+    if (rl < rpp) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int gi = (cv * V + j) / cpg;
-        atomicAdd(&sg[gi], (double)s1[j]);
-        atomicAdd(&sg[GS + gi], (double)s2[j]);
+        for (int j = 0; j < V; ++j) { pp[0][rl * CS + cv * V + j] = s1[j]; pp[1][rl * CS + cv * V + j] = s2[j]; }
+    }
+    __syncthreads();
+    for (int gi = threadIdx.x; gi < 2 * GS; gi += 256) {  // group sums: channels of the group x row lanes, fixed order, fp64
+        const int st = gi / GS, gq = gi - st * GS;
+        double t = 0.0;
+        for (int k = 0; k < cpg; ++k)
+            for (int r = 0; r < rpp; ++r) t += (double)pp[st][r * CS + gq * cpg + k];
+        sg[gi] = t;
     }
     __syncthreads();
     const double cnt = (double)HW * cpg;
@@ -490,13 +506,12 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
     __shared__ float sg[2 * 128];   // per group: sum g*gamma, sum g*gamma*xhat
     __shared__ float sc[2 * 512];   // per channel: sum g*xhat, sum g
     __shared__ float kst[3][512];   // per channel: group mean, group rstd, gamma
+    __shared__ float pp[2][256 * V];  // per-thread partial sums [row lane][channel], added up in a fixed order: the gradient that
+                                      // flows on to the geometric head and the backbone is bit-reproducible (no float atomics)
     const int n = blockIdx.x, cpg = C / G, c0 = blockIdx.y * CS, g0 = c0 / cpg, GS = CS / cpg;
     const int tpr = CS / V, rpp = 256 / tpr;
     const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    for (int i = threadIdx.x; i < 2 * GS; i += 256) sg[i] = 0.f;
     for (int i = threadIdx.x; i < CS; i += 256) {
-        sc[i] = 0.f;
-        sc[CS + i] = 0.f;
         const int gi = g0 + i / cpg;
         kst[0][i] = mean_rstd[((size_t)n * G + gi) * 2 + 0];
         kst[1][i] = mean_rstd[((size_t)n * G + gi) * 2 + 1];
@@ -526,13 +541,23 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
             a2[j] += gg * (xv[j] - mu[j]) * rs[j];
         }
     }
+    if (rl < rpp) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int c = cv * V + j, gi = c / cpg;
-        atomicAdd(&sc[c], a2[j]);
-        atomicAdd(&sc[CS + c], a1[j]);
-        atomicAdd(&sg[gi], a1[j] * gm[j]);
-        atomicAdd(&sg[GS + gi], a2[j] * gm[j]);
+        for (int j = 0; j < V; ++j) { pp[0][rl * CS + cv * V + j] = a2[j]; pp[1][rl * CS + cv * V + j] = a1[j]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * CS; i += 256) {  // per-channel totals over the row lanes
+        const int st = i / CS, c = i - st * CS;
+        float t = 0.f;
+        for (int r = 0; r < rpp; ++r) t += pp[st][r * CS + c];
+        sc[i] = t;
+    }
+    __syncthreads();
+    for (int gi = threadIdx.x; gi < 2 * GS; gi += 256) {  // per-group: sum_c gamma_c * (sum g | sum g*xhat)
+        const int st = gi / GS, gq = gi - st * GS;
+        float t = 0.f;
+        for (int k = 0; k < cpg; ++k) t += sc[(st == 0 ? CS : 0) + gq * cpg + k] * kst[2][gq * cpg + k];
+        sg[gi] = t;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < CS; c += 256) {

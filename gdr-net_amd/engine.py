@@ -23,7 +23,14 @@ from .cabi import BF16, F32, ConvParams, PoseParams, WgradParams, check, ptr
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
 HEAD_CONVS = ((3, 4, False), (6, 7, False), (10, 11, True), (13, 14, False), (17, 18, True), (20, 21, False))
-BUCKET_FIRST_GROUP = (25, 17, 14, 8, 0)  # lowest forward-order backward-group index of gradient buckets pnp | head | layer4 | layer3 | rest
+# lowest forward-order backward-group index of the gradient buckets, and the last parameter (forward order) of each bucket but the
+# last.  Data-parallel runs exchange five buckets pnp | head | layer4 | layer3 | rest (the 52 MB layer4 all-reduce starts nine blocks
+# before the end of backward, the exposed tail is 5 MB); one GPU keeps layer4 + layer3 together: the grouped weight-gradient launch of
+# a bucket wants ~1000 workgroups, and splitting it costs 0.13 ms per step for nothing when there is no exchange to overlap.
+BUCKET_LAYOUTS = {
+    5: ((25, 17, 14, 8, 0), ("rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer3.5.bn2.bias", "backbone.layer2.3.bn2.bias")),
+    4: ((25, 17, 8, 0), ("rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer2.3.bn2.bias")),
+}
 LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_PM_R", "loss_centroid", "loss_z")
 
 
@@ -66,6 +73,12 @@ class Engine:
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
+        nb = _os.environ.get("GDRN_BUCKETS")
+        if nb is None:
+            import torch.distributed as _dist
+
+            nb = 5 if (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) else 4
+        self.bucket_first_group, self.bucket_marks = BUCKET_LAYOUTS[int(nb)]
         self.layers = OrderedDict()
         self._versions = {}
         self.bn_fold = {}  # bn key -> NS(scale, shift, layer): eval-mode BatchNorm folded into the preceding conv
@@ -105,7 +118,7 @@ class Engine:
         """Flat-gradient slices in the order backward completes them: pnp (36 MB fp32), head (19), layer4 (52), layer3 (27),
         rest = layer2 + layer1 + stem (5.4): the big layer4 exchange starts nine blocks before the end of backward and the
         exposed tail is the smallest bucket."""
-        marks = ["rot_head_net.features.23.bias", "backbone.layer4.2.bn2.bias", "backbone.layer3.5.bn2.bias", "backbone.layer2.3.bn2.bias"]
+        marks = self.bucket_marks
         cuts = [0]
         for m in marks:
             cuts.append(self.grad_offsets[m])
@@ -588,7 +601,7 @@ class Plan:
         assert ng == 29, ng
         # backward groups in forward order: stem(0) layer1(1-3) layer2(4-7) layer3(8-13) layer4(14-16) convT(17) head convs(18-23)
         # head out(24) pnp convs(25-27) fc(28)
-        first_group = BUCKET_FIRST_GROUP  # forward index of the LAST-executed group of buckets 0..4
+        first_group = e.bucket_first_group  # forward index of the LAST-executed group of each bucket
         from .cabi import WreduceTask
 
         bucket_of = lambda gi: next(i for i, g0 in enumerate(first_group) if gi >= g0)
@@ -1148,6 +1161,6 @@ class Plan:
             cum += s
             ends.append(cum - 1)
         # reversed order: fc, pnp x3 | head-out, head convs x6, convT | layer4 (3) | layer3 (6) | layer2 (4), layer1 (3), stem
-        bounds = [n_groups - g0 for g0 in BUCKET_FIRST_GROUP]
+        bounds = [n_groups - g0 for g0 in self.e.bucket_first_group]
         self._marks = {ends[b - 1]: i for i, b in enumerate(bounds)}
         return self._marks

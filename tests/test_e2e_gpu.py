@@ -335,7 +335,8 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
     l1, t1, g1, h1, r1 = res["1"]
     bad = [(k, rel(t1[k], t0[k])) for k in t0 if not torch.equal(t0[k], t1[k])]
     assert not bad, bad[:12]
-    assert torch.equal(h0, h1) and torch.equal(l0, l1)
+    assert torch.equal(h0[:, :69], h1[:, :69])  # (columns 69..71 of the 72-wide rows are never written)
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=1e-9)  # the three pose losses are accumulated with float atomics
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
     halo = lambda n: n.endswith("weight") and g0[n].dim() == 4 and g0[n].shape[2] == 3 and ("layer" in n or "rot_head" in n) and n not in (
@@ -407,6 +408,7 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GDRN_BUCKETS"] = "5"  # the data-parallel bucket layout (a one-rank group would pick the single-GPU one)
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
@@ -427,7 +429,13 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
             model.train_step(batch["roi_img"], optimizer=None, **kw)
             torch.cuda.synchronize()
             if attached:
-                assert calls == [0, 1, 2, 3]
+                assert calls == [0, 1, 2, 3, 4]  # pnp | head | layer4 | layer3 | rest
+                # overlap: the collective of bucket 0 (Patch-PnP) is enqueued on the side stream while most of the backward is
+                # still to run -- its start event precedes the last bucket's by (nearly) the whole backbone + head backward
+                assert len(red.started) == 5
+                lead_ms = red.started[0].elapsed_time(red.started[4])
+                assert lead_ms > 0.5, lead_ms
+                assert red.grad_scale == 1.0  # one rank: nothing deferred
             eng = model.engine()
             grads[attached] = eng.grad_flat.clone()
         a, b = grads[False], grads[True]
@@ -437,6 +445,7 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
             ref = a[lo:hi]
             assert float((ref - b[lo:hi]).abs().max() / (ref.abs().max() + 1e-12)) < 2e-3
     finally:
+        os.environ.pop("GDRN_BUCKETS", None)
         if created:
             dist.destroy_process_group()
 
