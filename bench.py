@@ -12,7 +12,10 @@ currently the halo-tiled 3x3 kernel, 8x16 pixels x 128 channels) -- every launch
 events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(durations - event overhead) against the
 2.5 PFLOP/s dense bf16 MFMA peak.
 `cpu_baseline`: the CPU oracle (a port of the reference path on stock PyTorch CPU kernels) timed on
-this box's host cores on a bounded sample (bs=4, fwd+bwd, 32 threads).
+this box's host cores per SURVEY.md section 8(d): B = 4 and B = 64, forward-only and forward + backward + Ranger, median of 5
+after 2 warm-ups, core count and CPU model stated (about 50 s of CPU work).
+`also`: the step without the optimizer, eval-mode inference, a sustained (>= 2 s timed) run of the same step, the fp32 parity
+mode (the mode the 1e-4 pose bound belongs to) with its own MFMA roofline fraction, the RoI cropper.
 """
 import argparse
 import json
@@ -39,48 +42,93 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra no-optimizer / inference loops")
     ap.add_argument("--fwd-only", action="store_true", help="inference throughput (eval BN, test-mode pose decode)")
+    ap.add_argument("--dist-force", action="store_true",
+                    help="run the data-parallel code path (RCCL process group, parameter broadcast, bucketed side-stream all-reduce) even with one rank")
+    ap.add_argument("--comm-dtype", default=os.environ.get("GDRN_COMM_DTYPE", "fp32"), choices=["fp32", "bf16"], help="wire format of the gradient buckets")
     return ap.parse_args()
 
 
-def cpu_baseline(bs=16, iters=4):
-    """Oracle fwd+bwd on the host cores (reported baseline, not a target)."""
+def kernel_source_hash():
+    """sha256 over the kernel sources + the C-ABI header: identifies the build a PMC traffic summary belongs to."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gdr-net_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/gdrn_hip.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline():
+    """the CPU restatement of the reference path (oracle/, stock PyTorch CPU kernels, fp32) on this box's host
+    cores, same synthetic batch, B = 4 and B = 64, forward-only and the full training step (forward + 8 losses + backward + Ranger,
+    oracle/ranger_oracle.py), median of 5 timed iterations after 2 warm-ups.  A reported baseline, not a target."""
+    import statistics
+
     import torch
 
     from gdrnet_amd import synth
     from oracle import gdrn_oracle as O
+    from oracle import ranger_oracle as R
 
     cores = min(os.cpu_count() or 1, 32)  # stock PyTorch CPU conv kernels stop scaling (and regress) beyond ~32 threads
     torch.set_num_threads(cores)
-    sd = synth.make_state_dict(0)
-    for v in sd.values():
-        if v.is_floating_point():
-            v.requires_grad_(True)
-    batch = synth.make_batch(bs, seed=1)
 
-    def step():
-        out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})
-        sum(out["loss_dict"].values()).backward()
-        for v in sd.values():
-            v.grad = None
+    def med(fn, warm=2, n=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
+    res = {}
+    for bs in (4, 64):
+        sd = synth.make_state_dict(0)
+        names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+        for k in names:
+            sd[k].requires_grad_(True)
+        batch = synth.make_batch(bs, seed=1)
+        state = [dict() for _ in names]
 
-    def infer():
-        with torch.no_grad():
-            O.gdrn_forward(sd, batch, do_loss=False, training=False)
+        def train_step(opt=True):
+            out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})
+            sum(out["loss_dict"].values()).backward()
+            if opt:
+                R.ranger_step([sd[k] for k in names], [sd[k].grad for k in names], state, lr=1e-4)
+            for k in names:
+                sd[k].grad = None
 
-    infer()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        infer()
-    dti = (time.perf_counter() - t0) / iters
-    return {"value": round(bs / dt, 3), "unit": "RoI/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU fp32) fwd+bwd, bs={bs}, {iters} timed steps after 1 warm-up, no optimizer step",
-            "inference_fwd_roi_s": round(bs / dti, 3)}
+        def infer():
+            with torch.no_grad():
+                O.gdrn_forward(sd, batch, do_loss=False, training=False)
+
+        t_train = med(train_step)
+        t_noopt = med(lambda: train_step(False), warm=1, n=3) if bs == 4 else None
+        t_inf = med(infer)
+        res[bs] = (t_train, t_noopt, t_inf)
+    t64, _, i64 = res[64]
+    t4, n4, i4 = res[4]
+    return {"value": round(64 / t64, 3), "unit": "RoI/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+            "sample": "oracle/ (CPU restatement of the reference path, torch CPU fp32): fwd + 8 losses + bwd + Ranger step at bs=64, median of 5 timed "
+                      "steps after 2 warm-ups, %d threads" % cores,
+            "train_step_bs4_roi_s": round(4 / t4, 3), "fwd_bwd_without_optimizer_bs4_roi_s": round(4 / n4, 3),
+            "inference_fwd_bs64_roi_s": round(64 / i64, 3), "inference_fwd_bs4_roi_s": round(4 / i4, 3)}
 
 
 def measure_roofline(model, plan, kctx, dtype):
@@ -135,16 +183,23 @@ def measure_roofline(model, plan, kctx, dtype):
     achieved = flops / (tot_ms * 1e-3) / 1e12
     peak = (PEAK_BF16 if dtype == "bf16" else PEAK_F32) / 1e12
     # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs; FETCH_SIZE doubled
-    # as MI355X_MICROARCH.md prescribes for gfx950) cannot be collected from inside this process -- read the committed summary
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_bs64_bf16.json")
+    # as MI355X_MICROARCH.md prescribes for gfx950) cannot be collected from inside this process.  The committed summary
+    # (tools/pmc_traffic.py) carries the hash of the kernel sources it was measured on: any other build reports null
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_bs64_bf16.json")
     if dtype == "bf16" and plan.B == 64 and os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get(dom, {}).get("traffic_bytes_per_launch")
-        traffic = round(traffic) if traffic else None
+            tj = json.load(f)
+        if tj.get("__kernel_source_sha256_16__") == kernel_source_hash():
+            traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
+            traffic = round(traffic) if traffic else None
+            traffic_src = "profiles/r02_hbm_traffic_bs64_bf16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)"
+        else:
+            traffic_src = "null: the committed PMC summary belongs to another build of the kernels"
     return {"bound": "mfma", "kernel": dom, "launches_per_step": len(ev), "avg_launch_us": round(tot_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_launch": round(flops / max(len(ev), 1) / 1e9, 3), "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "event_overhead_us": round(ovh_ms * 1e3, 2)}
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "event_overhead_us": round(ovh_ms * 1e3, 2)}
 
 
 def roi_cropper_extras(B, dev, timed):
@@ -186,9 +241,14 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    if world > 1:
+    use_dist = world > 1 or args.dist_force
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29541"))
+        if world > 1:
+            os.environ.setdefault("GDRN_BUCKETS", "5")  # (the engine picks this itself once the group exists; explicit for clarity)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
 
     cfg = lm13_cfg(device=dev)
     cfg.MODEL.CDPN.HIP_DTYPE = args.dtype
@@ -199,10 +259,10 @@ def main():
     batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     kw = synth.model_kwargs(batch, do_loss=not args.fwd_only)
     kw.pop("do_loss")
-    if world > 1:
+    if use_dist:
         gdist.broadcast_parameters(model)
         model.train()
-        gdist.attach(model)
+        gdist.attach(model, force=args.dist_force, comm_dtype=args.comm_dtype)
 
     if args.fwd_only:
         model.eval()
@@ -219,14 +279,14 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -261,7 +321,31 @@ def main():
         also = {"fwd_bwd_without_optimizer_roi_s": round(B / t_noopt, 1), "fwd_bwd_without_optimizer_ms": round(t_noopt * 1e3, 3),
                 "inference_fwd_roi_s": round(B / t_inf, 1), "inference_fwd_ms": round(t_inf * 1e3, 3),
                 "inference_fwd_tflops": round(B / t_inf * 22.823e9 / 1e12, 1)}
+        # sustained figure: the same full step for >= 2 s of timed GPU work (the driver's 20 steps are 0.18 s: DVFS has not settled)
+        n_sus = max(50, int(2.2 / max(dt / args.steps, 1e-4)))
+        t_sus = timed(step, n_sus)
+        also["sustained"] = {"steps": n_sus, "seconds": round(t_sus * n_sus, 2), "ms_per_step": round(t_sus * 1e3, 3), "roi_s": round(B / t_sus, 1)}
         also.update(roi_cropper_extras(B, dev, timed))
+        if args.dtype == "bf16":
+            # the parity (fp32) mode -- the mode the 1e-4 pose bound is claimed for: generic fp32-MFMA kernels, no halo kernel
+            cfg32 = lm13_cfg(device=dev)
+            cfg32.MODEL.CDPN.HIP_DTYPE = "fp32"
+            m32, o32 = GDRN.build_model_optimizer(cfg32)
+            m32.load_state_dict(synth.make_state_dict(0))
+            m32.train()
+            t32 = timed(lambda: m32.train_step(batch["roi_img"], optimizer=o32, **kw), 5)
+            also["fp32_parity_mode"] = {"roi_s": round(B / t32, 1), "ms_per_step": round(t32 * 1e3, 3),
+                                        "whole_step_tflops": round(B / t32 * FLOP_PER_ROI_TRAIN / 1e12, 2),
+                                        "frac_of_fp32_mfma_peak": round(B / t32 * FLOP_PER_ROI_TRAIN / PEAK_F32, 4)}
+            if not args.no_roofline:
+                eng32 = m32.engine()
+                _, plan32, kctx32 = m32._prepare(batch["roi_img"], True, {k: kw.get(k) for k in (
+                    "gt_xyz", "gt_mask_trunc", "gt_mask_visib", "gt_region", "gt_ego_rot", "gt_points", "sym_infos", "gt_trans", "gt_trans_ratio",
+                    "roi_coord_2d", "roi_cams", "roi_centers", "roi_whs", "roi_extents", "resize_ratios")})
+                r32 = measure_roofline(m32, plan32, kctx32, "fp32")
+                also["fp32_parity_mode"]["roofline"] = {k: r32[k] for k in ("kernel", "launches_per_step", "avg_launch_us", "achieved", "peak", "frac")}
+            del m32, o32
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -290,7 +374,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

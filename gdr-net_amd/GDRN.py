@@ -278,8 +278,7 @@ class GDRN(nn.Module):
             if dev.type != "cuda":
                 raise cabi.GdrnHipError("GDRN runs on the HIP engine only: move the model to an MI355X (`model.to('cuda')`)")
             r, p = self.cfg.MODEL.CDPN.ROT_HEAD, self.cfg.MODEL.CDPN.PNP_NET
-            self._eng = Engine(params, dict(self.named_buffers()), dtype=self.hip_dtype, num_regions=r.NUM_REGIONS,
-                               wgrad_variant=int(os.environ.get("GDRN_WGRAD_VARIANT", "0")))
+            self._eng = Engine(params, dict(self.named_buffers()), dtype=self.hip_dtype, num_regions=r.NUM_REGIONS)
             self._eng_key = key
             lw = [r.XYZ_LW, r.XYZ_LW, r.XYZ_LW, r.MASK_LW, r.REGION_LW, p.PM_LW, p.CENTROID_LW, p.Z_LW]
             self._loss_w = torch.tensor(lw, dtype=torch.float32, device=dev)

@@ -90,6 +90,7 @@ def to_device_table(structs, device):
 # name -> argtypes (all return int status, except the two tile queries which return ints too)
 _SIGS = {
     "gdrn_version": [],
+    "gdrn_workspace_bytes": [I, P],
     "gdrn_device_info": [I, C.c_char_p, C.POINTER(I), C.c_char_p],
     "gdrn_conv_gemm": [C.POINTER(ConvParams), P],
     "gdrn_correspondences": [P, P, P, P, LL, I, P, P, P, F, I, I, P, P, P, P, P, P],
@@ -172,7 +173,7 @@ def load():
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = I
+        fn.restype = LL if name == "gdrn_workspace_bytes" else I
     _lib = lib
     return lib
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
 #pragma unroll
             for (int ks = 0; ks < BKM / 32; ++ks) {
                 bf16x8_t fa[FA], fb[FB];
-                if (p.variant == 0) {
+                {
                     // ds_read_b64_tr_b16: lane q of a 16-lane group supplies the address of 4 contiguous
                     // bf16 of row (q>>2), columns (q&3)*4.. of a [4 m][16 ch] block and receives
                     // channel q for those 4 rows.  Lane group g takes reduction rows {4g..4g+3} with the
@@ -160,27 +160,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
                         bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0));
                         bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 16 * PB));
                         fb[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
-                } else {
-                    // reference variant: 8 scalar 16-bit LDS reads per fragment (slow, layout-obvious)
-                    const int mrow = ks * 32 + g * 8;  // this lane group's 8 reduction rows
-#pragma unroll
-                    for (int a = 0; a < FA; ++a) {
-                        unsigned short e[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            e[k] = *reinterpret_cast<const unsigned short*>(tA + (mrow + k) * PA + (wa * WCO + a * 16 + r16) * 2);
-                        uint4 u = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-                        fa[a] = __builtin_bit_cast(bf16x8_t, u);
-                    }
-#pragma unroll
-                    for (int b = 0; b < FB; ++b) {
-                        unsigned short e[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            e[k] = *reinterpret_cast<const unsigned short*>(tB + (mrow + k) * PB + (wb * WCI + b * 16 + r16) * 2);
-                        uint4 u = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-                        fb[b] = __builtin_bit_cast(bf16x8_t, u);
                     }
                 }
 #pragma unroll

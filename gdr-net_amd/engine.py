@@ -41,7 +41,7 @@ def _ru(a, b):
 class Engine:
     """Owns the packed (kernel-layout) weight copies and the per-batch-size plans for one GDRN module."""
 
-    def __init__(self, params, buffers, dtype="bf16", num_regions=64, wgrad_variant=0, dry=False):
+    def __init__(self, params, buffers, dtype="bf16", num_regions=64, dry=False):
         """params / buffers: dict name -> tensor with the reference's state_dict names.
         dry: build-only engine on host tensors for inspecting the launch lists without a GPU (tests); it cannot run."""
         self.lib = cabi.load()
@@ -55,23 +55,20 @@ class Engine:
         if self.dev.type != "cuda" and not self.dry:
             raise cabi.GdrnHipError("the HIP engine needs parameters on a GPU device (no CPU fallback)")
         self.nreg = num_regions
-        self.wgrad_variant = wgrad_variant
         import os as _os
 
-        self.use_halo = _os.environ.get("GDRN_HALO", "1") != "0"  # A/B switch: generic gather kernel for every conv
+        self.use_halo = self.dt == BF16  # 3x3 stride-1 convs on the halo-tiled kernel (bf16); the fp32 parity mode keeps the generic one
         self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "0") == "1"  # bucket-end work on a 2nd stream (measured: no gain on one GPU)
         self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
         self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
         self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
-        self.fuse_bnb = _os.environ.get("GDRN_FUSE_BNB", "1") != "0"  # A/B switch: BN-backward sums in the dgrad epilogue
         # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
-        self.fuse_xf = self.dt == BF16 and self.use_halo and self.fuse_bnb and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
+        self.fuse_xf = self.use_halo and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
-        self.wgrad_ws = _os.environ.get("GDRN_WGRAD_WS", "1") != "0"  # A/B switch: grouped + workspace partials vs per-layer atomics
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
         nb = _os.environ.get("GDRN_BUCKETS")
         if nb is None:
@@ -451,12 +448,12 @@ class Plan:
         wp.Hi, wp.Wi, wp.Cin, wp.x_cs = Hi, Wi, cin, x_cs
         wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Ho, Wo, cout, dy_cs
         wp.KH, wp.KW, wp.stride, wp.pad = KH or L.KH, KW or L.KW, stride, pad
-        wp.M, wp.dtype, wp.splits, wp.variant = self.B * Ho * Wo, e.dt, 0, e.wgrad_variant
+        wp.M, wp.dtype, wp.splits, wp.variant = self.B * Ho * Wo, e.dt, 0, 0
         self.keep.append(wp)
         ref = C.byref(wp)
         use_halo = e.use_halo and L.kind == "conv" and bool(e.lib.gdrn_conv3x3_wgrad_ok(ref))
         fn = e.lib.gdrn_conv3x3_wgrad if use_halo else e.lib.gdrn_conv_wgrad
-        if use_halo and e.wgrad_ws:
+        if use_halo:
             # deferred: one grouped launch per gradient bucket (see _finish_unpack) -- weight gradients are off the
             # critical path, and a grid over many layers fills the chip with far fewer pixel-range splits per layer
             self._wgrad_deferred.append((len(self.bwd_groups), L, wp, 2.0 * self.B * Ho * Wo * L.O * L.I * L.KK))
@@ -546,7 +543,7 @@ class Plan:
     def _fusable(self, L):
         """can the data gradient of layer L run on the halo kernel (and so carry a fused BN-backward reduction)?"""
         e = self.e
-        return e.fuse_bnb and e.use_halo and e.dt == BF16 and L.kind == "conv" and L.wfF is not None
+        return e.use_halo and L.kind == "conv" and L.wfF is not None
 
     def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False, apply=True):
         """BatchNorm(+ReLU) backward: [reduce -> coef ->] apply.  prereduced: dy arrives masked and the producing data-gradient

@@ -31,6 +31,19 @@ enum { GDRN_F32 = 0, GDRN_BF16 = 1 };
 enum { GDRN_E_ARG = -1, GDRN_E_SHAPE = -2, GDRN_E_LAUNCH = -3 };
 
 int gdrn_version(void);
+/* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
+ * memory, no initialisation needed unless stated): `op` selects the buffer, `params` points at the arguments that determine its
+ * size.  < 0: GDRN_E_*.  (the Python engine sizes its plan buffers with the same rules.) */
+enum {
+    GDRN_WS_CONV_STATS = 0,     /* const gdrn_conv_params*  -> p->stats of gdrn_conv_gemm */
+    GDRN_WS_CONV3X3_STATS = 1,  /* const gdrn_conv_params*  -> p->stats / p->bnb_rows of gdrn_conv3x3_halo */
+    GDRN_WS_CONV3X3_WGRAD = 2,  /* const gdrn_wgrad_params* -> p->ws of gdrn_conv3x3_wgrad / one task of gdrn_conv3x3_wgrad_multi */
+    GDRN_WS_STEM_WGRAD = 3,     /* const int* N             -> ws of gdrn_stem_wgrad */
+    GDRN_WS_STEM_STATS = 4,     /* const int* N             -> stats of gdrn_stem_conv */
+    GDRN_WS_LINEAR_SPLITK = 5,  /* const int[2] {M, N}      -> ws of gdrn_linear_splitk */
+    GDRN_WS_BN_BWD_ROWS = 6     /* const long long[3] {npix, C, dtype} -> rows of gdrn_bn_bwd_reduce */
+};
+long long gdrn_workspace_bytes(int op, const void* params);
 /* fills name (<=255 chars), compute units and the gcn arch string of device `dev`. */
 int gdrn_device_info(int dev, char* name, int* cus, char* arch);
 
@@ -140,8 +153,8 @@ int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
 
 /* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
- *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather).  variant: 0 = LDS transpose-read (bf16),
- *   1 = scalar LDS reads (bf16 reference variant).  splits <= 0: automatic pixel-range split.
+ *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather; bf16 fragments through the LDS transpose read).  variant: reserved, 0.
+ *   splits <= 0: automatic pixel-range split.
  * ws (gdrn_conv3x3_wgrad only, else NULL): per-split partial tiles go here (plain stores) instead of atomics on dw.
  * Replaces the autograd weight-gradients of the same layers (engine.py:279). */
 typedef struct gdrn_wgrad_params {

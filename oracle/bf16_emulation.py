@@ -1,0 +1,104 @@
+"""ORACLE -- test infrastructure, NOT product code (see gdrn_oracle.py for the rules).
+
+The CPU oracle's train-mode forward pass with the bf16 STORAGE points of the throughput mode: every tensor the HIP engine
+keeps in HBM as bf16 is rounded to bf16 here at the same place, everything the engine keeps in fp32 (MFMA accumulators, the
+BatchNorm statistics reduced in the conv epilogue, scale / shift vectors, the 69-channel head output, the Patch-PnP output,
+pose decode and losses) stays fp32.  The arithmetic between the rounding points is the reference's
+(``gdrn_oracle.py`` cites the reference lines); the rounding points are the engine's (``gdr-net_amd/engine.py::Plan._build``):
+
+  image canvas, packed conv / linear weights ............ bf16 (gdrn_pack_image, gdrn_pack_multi)
+  raw conv / conv-transpose outputs ...................... bf16, BatchNorm statistics from the fp32 accumulators
+  BatchNorm(+residual)+ReLU outputs, max-pool, upsample .. bf16, evaluated as fma(x, scale, shift) (+ identity) in fp32
+  normalised downsample branch ........................... bf16 before it is added (bn_apply pass / xf mode 2)
+  1x1 head conv output (mask, xyz, region logits) ........ fp32
+  Patch-PnP input (xyz * extent, coord2d, softmax) ....... bf16; GroupNorm statistics from the stored bf16 tensor
+  fc1 / fc2 activations .................................. bf16; fc_r / fc_t output fp32
+
+What this answers: the bf16 engine differs from the fp32 reference by 0.3 relative in the dense maps of the random-init
+network (BatchNorm with batch statistics turns a 2^-9 storage rounding of x into a 2^-9 * |mean|/std error of xhat, layer after
+layer); against THIS restatement it differs only by summation order, i.e. the deviation is the declared storage precision and
+nothing else.  Used by tests/test_e2e_gpu.py::test_bf16_engine_equals_the_oracle_with_bf16_storage.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import gdrn_oracle as O
+
+
+def r(x):
+    """value after a round trip through bf16 storage (round-to-nearest-even, as v_cvt_pk_bf16_f32)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _fma(x, a, c):
+    """fp32 fma(x, a, c) per channel: exact product in fp64, one rounding."""
+    return (x.double() * a.double().view(1, -1, 1, 1) + c.double().view(1, -1, 1, 1)).float()
+
+
+def _bn_train(acc, sd, prefix, eps=1e-5):
+    """scale / shift of a train-mode BatchNorm as gdrn_bn_finalize computes them: fp64 statistics of the fp32 conv accumulators,
+    mean and invstd rounded to fp32, scale = gamma * invstd, shift = beta - mean * scale in fp32."""
+    a = acc.double()
+    m = a.mean((0, 2, 3))
+    var = (a * a).mean((0, 2, 3)) - m * m
+    inv = (1.0 / torch.sqrt(var.clamp_min(0) + eps)).float()
+    sc = sd[prefix + ".weight"].float() * inv
+    sh = sd[prefix + ".bias"].float() - m.float() * sc
+    return sc, sh
+
+
+def _conv(x, sd, name, stride, pad):
+    return F.conv2d(x, r(sd[name].float()), None, stride, pad)
+
+
+def forward_train(sd, batch, sym=False):
+    """gdrn_oracle.gdrn_forward(do_loss=True, training=True) with bf16 storage; returns the same dict (maps fp32 [B,69,64,64])."""
+    p = "backbone."
+    acc = _conv(r(batch["roi_img"].float()), sd, p + "conv1.weight", 2, 3)
+    sc, sh = _bn_train(acc, sd, p + "bn1")
+    x = r(F.max_pool2d(F.relu(_fma(r(acc), sc, sh)), 3, 2, 1))
+    for li, nb in enumerate(O.RESNET34_LAYERS, start=1):
+        for b in range(nb):
+            q = f"backbone.layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            a1 = _conv(x, sd, q + ".conv1.weight", stride, 1)
+            sc, sh = _bn_train(a1, sd, q + ".bn1")
+            h = r(F.relu(_fma(r(a1), sc, sh)))
+            a2 = _conv(h, sd, q + ".conv2.weight", 1, 1)
+            sc2, sh2 = _bn_train(a2, sd, q + ".bn2")
+            if (q + ".downsample.0.weight") in sd:
+                ad = _conv(x, sd, q + ".downsample.0.weight", stride, 0)
+                scd, shd = _bn_train(ad, sd, q + ".downsample.1")
+                idn = r(_fma(r(ad), scd, shd))
+            else:
+                idn = x
+            x = r(F.relu(_fma(r(a2), sc2, sh2) + idn))
+    h_ = "rot_head_net.features."
+    acc = F.conv_transpose2d(x, r(sd[h_ + "0.weight"].float()), None, stride=2, padding=1, output_padding=1)
+    sc, sh = _bn_train(acc, sd, h_ + "1")
+    x = r(F.relu(_fma(r(acc), sc, sh)))
+    for conv_i, bn_i in ((3, 4), (6, 7), (10, 11), (13, 14), (17, 18), (20, 21)):
+        if conv_i in (10, 17):
+            x = r(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True))
+        acc = _conv(x, sd, h_ + f"{conv_i}.weight", 1, 1)
+        sc, sh = _bn_train(acc, sd, h_ + f"{bn_i}")
+        x = r(F.relu(_fma(r(acc), sc, sh)))
+    maps = F.conv2d(x, r(sd[h_ + "23.weight"].float()), sd[h_ + "23.bias"].float(), 1, 0)  # fp32 output
+    mask, cx, cy, cz, region = maps[:, :1], maps[:, 1:2], maps[:, 2:3], maps[:, 3:4], maps[:, 4:]
+    bs = maps.shape[0]
+    xyz = (torch.cat([cx, cy, cz], 1) - 0.5) * batch["roi_extent"].float().view(bs, 3, 1, 1)
+    x = r(torch.cat([xyz, batch["roi_coord_2d"].float(), F.softmax(region[:, 1:], dim=1)], 1))
+    q = "pnp_net.features."
+    for conv_i, gn_i in ((0, 1), (3, 4), (6, 7)):
+        x = r(F.conv2d(x, r(sd[q + f"{conv_i}.weight"].float()), None, 2, 1))
+        x = r(F.relu(F.group_norm(x, 32, sd[q + f"{gn_i}.weight"].float(), sd[q + f"{gn_i}.bias"].float(), 1e-5)))
+    x = x.reshape(bs, 128 * 8 * 8)
+    x = r(F.leaky_relu(F.linear(x, r(sd["pnp_net.fc1.weight"].float()), sd["pnp_net.fc1.bias"].float()), 0.1))
+    x = r(F.leaky_relu(F.linear(x, r(sd["pnp_net.fc2.weight"].float()), sd["pnp_net.fc2.bias"].float()), 0.1))
+    rot6d = F.linear(x, r(sd["pnp_net.fc_r.weight"].float()), sd["pnp_net.fc_r.bias"].float())
+    t_ = F.linear(x, r(sd["pnp_net.fc_t.weight"].float()), sd["pnp_net.fc_t.bias"].float())
+    rot_m = O.ortho6d_to_mat_batch(rot6d)
+    rot, trans = O.pose_decode_train(rot_m, t_, batch["roi_cam"], batch["roi_center"], batch["resize_ratio"], batch["roi_wh"])
+    out = dict(maps=maps, rot6d=rot6d, t_=t_, rot=rot, trans=trans)
+    out["loss_dict"] = O.gdrn_loss(mask, cx, cy, cz, region, rot, t_, batch, sym=sym)
+    return out

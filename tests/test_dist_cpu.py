@@ -35,6 +35,16 @@ def _worker(rank, world, port, q):
         red.wait()
         expect = torch.arange(n, dtype=torch.float32) * (sum(r + 1 for r in range(world)) / world)
         assert torch.allclose(flat, expect), (rank, (flat - expect).abs().max())
+        # bf16 on the wire, fp32 master buffer, 1/world deferred to the consumer (the fused optimizer's grad_scale)
+        flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        red2 = GradReducer(flat2, bounds, average=True, comm_dtype="bf16", defer_scale=True)
+        for i in range(len(bounds)):
+            red2.on_bucket(i)
+        red2.wait()
+        assert red2.grad_scale == 1.0 / world
+        assert torch.allclose(flat2 * red2.grad_scale, expect, rtol=1e-2), (rank, (flat2 * red2.grad_scale - expect).abs().max())
+        red2.finish()
+        assert torch.allclose(flat2, expect, rtol=1e-2)
 
         # initial broadcast of parameters and buffers from rank 0
         torch.manual_seed(rank)
@@ -55,6 +65,79 @@ def _worker(rank, world, port, q):
         q.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_autograd(rank, world, port, q):
+    """loss.backward() through GDRN's single autograd node with a reducer attached: the gradients autograd accumulates into
+    .grad must be the all-reduced MEAN (the node waits for the bucket exchanges and applies the deferred 1/world before it hands
+    its views to AccumulateGrad) -- the path the reference trainer takes (loss.backward(); optimizer.step(), engine.py:279).
+    The HIP engine is replaced by a stub plan with the same interface (no GPU in this test)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace as NS
+
+    from gdrnet_amd import GDRN as G
+    from gdrnet_amd.dist import GradReducer
+
+    try:
+        for comm in ("fp32", "bf16"):
+            params = {"a.weight": torch.nn.Parameter(torch.zeros(6, 5)), "b.bias": torch.nn.Parameter(torch.zeros(7))}
+            names = list(params)
+            flat = torch.zeros(40)
+            offs = {"b.bias": 0, "a.weight": 8}  # backward-completion order: b first
+            grads = {n: flat[offs[n]: offs[n] + params[n].numel()].view(params[n].shape) for n in names}
+            eng = NS(grads=grads, param_names=names, grad_flat=flat, P=params)
+            bounds = [(0, 8), (8, 40)]
+            red = GradReducer(flat, bounds, average=True, comm_dtype=comm, defer_scale=True)
+            model = NS(_on_bucket=red.on_bucket, _reducer=red)
+            plan = NS(e=eng, has_backward=True, generation=0, losses=torch.ones(8), gw=torch.zeros(8))
+
+            def run_forward(kctx):
+                plan.generation += 1
+
+            def run_backward(kctx, on_bucket=None):
+                # "kernels": rank-dependent gradients scaled by the incoming loss gradient, bucket by bucket
+                flat[0:8] = (rank + 1) * plan.gw.sum()
+                on_bucket(0)
+                flat[8:40] = torch.arange(32, dtype=torch.float32) * (rank + 1)
+                on_bucket(1)
+
+            plan.run_forward, plan.run_backward = run_forward, run_backward
+            losses = G._PathFn.apply(model, plan, {}, *[params[n] for n in names])
+            losses.sum().backward()
+            mean_scale = sum(r + 1 for r in range(world)) / world
+            assert torch.allclose(params["b.bias"].grad, torch.full((7,), 8.0 * mean_scale), rtol=1e-2 if comm == "bf16" else 1e-6)
+            exp = (torch.arange(32, dtype=torch.float32) * mean_scale)[:30].view(6, 5)
+            assert torch.allclose(params["a.weight"].grad, exp, rtol=1e-2 if comm == "bf16" else 1e-6), (comm, params["a.weight"].grad, exp)
+            # a second forward before the backward of the first is refused (one set of activations per plan)
+            l1 = G._PathFn.apply(model, plan, {}, *[params[n] for n in names])
+            G._PathFn.apply(model, plan, {}, *[params[n] for n in names])
+            try:
+                l1.sum().backward()
+                raise AssertionError("stale backward was not refused")
+            except Exception as e:  # GdrnHipError
+                assert "overwritten" in str(e), e
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_autograd_path_waits_for_the_reducer_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_autograd, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
 def test_grad_reducer_two_ranks_gloo():

@@ -560,3 +560,318 @@ def test_other_baseline_configs_full_size(cfgname, B, classes, cam, sym):
     eye = torch.eye(3, dtype=torch.float64, device=DEV).expand(B, 3, 3)
     assert (R @ R.transpose(1, 2) - eye).abs().max() < 1e-5
     assert torch.isfinite(eng.grad_flat).all() and float(eng.grad_flat.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ round-2 parity additions
+def _oracle_step(cpu_batch, sym):
+    from oracle import gdrn_oracle as O
+
+    sd = synth.make_state_dict(0)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    bufs = {}
+    ref = O.gdrn_forward(sd, cpu_batch, do_loss=True, training=True, bufs=bufs, sym=sym)
+    sum(ref["loss_dict"].values()).backward()
+    ref["bufs"] = bufs
+    return sd, ref
+
+
+@pytest.mark.parametrize("cfgname,B,classes,cam,sym", [("lm13", 64, 13, "lm", False), ("lmo", 32, 8, "lm", False), ("ycbv", 64, 21, "ycbv", True)])
+def test_fp32_vs_oracle_at_baseline_sizes(cfgname, B, classes, cam, sym):
+    """BASELINE.json configs[1] / [3] / [4] at their FULL batch sizes, fp32 (parity) mode, against one CPU-oracle train step on the
+    same seeded batch: the 8 losses (2e-4), the pose outputs at the north-star bound (1e-4 relative L2: rot6d, t_, R, t), the
+    BatchNorm running statistics, and FULL weight-gradient tensors of the two largest 3x3 layers plus a sample of the others
+    (1e-2; BatchNorm-affine gradients 6e-2, see test_fp32_train_step_vs_reference)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.cfg import lmo_cfg
+
+    cfgfn = {"lm13": lm13_cfg, "lmo": lmo_cfg, "ycbv": ycbv_cfg}[cfgname]
+    cpu_batch = synth.make_batch(B, seed=3, num_classes=classes, cam=cam, with_sym=sym)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd, ref = _oracle_step(cpu_batch, sym)
+    model, _ = build("fp32", cfgfn)
+    model.train()
+    batch = to_dev(cpu_batch)
+    _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    for k, v in ref["loss_dict"].items():
+        assert abs(loss_dict[k].item() - v.item()) <= 2e-4 * max(abs(v.item()), 1e-3), (k, loss_dict[k].item(), v.item())
+    plan = model.engine().plan(B, True, True)
+    fc = plan.fc_out.cpu()
+    errs = {"rot6d": rel(fc[:, :6], ref["rot6d"]), "t_": rel(fc[:, 6:9], ref["t_"]), "rot": rel(plan.rot, ref["rot"]), "trans": rel(plan.trans, ref["trans"])}
+    print(f"fp32 {cfgname} bs={B} pose rel-err vs oracle:", {k: "%.2e" % v for k, v in errs.items()})
+    assert max(errs.values()) < 1e-4, errs
+    sum(loss_dict.values()).backward()
+    params = dict(model.named_parameters())
+    full = ("rot_head_net.features.20.weight", "backbone.layer4.2.conv2.weight", "rot_head_net.features.17.weight", "backbone.layer1.0.conv1.weight",
+            "backbone.layer3.0.conv1.weight", "backbone.layer2.0.downsample.0.weight", "rot_head_net.features.0.weight", "rot_head_net.features.23.weight",
+            "pnp_net.features.0.weight", "pnp_net.fc1.weight", "pnp_net.fc_r.weight", "backbone.conv1.weight")
+    ge = {n: rel(params[n].grad, sd[n].grad) for n in full}
+    print(f"fp32 {cfgname} bs={B} full weight-gradient rel-err vs oracle:", {k.replace("backbone.", "").replace("rot_head_net.", "head."): "%.1e" % v for k, v in ge.items()})
+    # gradients w.r.t. weights further from the losses carry more of the fp32 summation-order noise of the two implementations
+    # (the reference's own fp32 run differs from its fp64 run by 2e-2 at conv1, SURVEY.md section 7): measured 5e-4 (1x1 head conv)
+    # -> 5e-3 (head 3x3) -> 1.3e-2 (layer4) -> 1.6e-2 (stem) at all three sizes
+    assert ge["rot_head_net.features.20.weight"] < 1e-2 and ge["rot_head_net.features.23.weight"] < 2e-3, ge
+    assert max(ge.values()) < 2.5e-2, ge
+    msd = model.state_dict()
+    for k in ("backbone.bn1.running_mean", "backbone.layer4.2.bn2.running_var", "rot_head_net.features.21.running_var"):
+        assert rel(msd[k], ref["bufs"][k]) < 1e-4, k
+
+
+def test_fp32_pose_parity_over_seeds():
+    """configs[0] (bs=4), fp32 mode, pose outputs against the CPU oracle on five differently seeded batches: every one within the
+    1e-4 north-star bound (the single golden batch of test_fp32_train_step_vs_reference sits at 9e-5)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import gdrn_oracle as O
+
+    B = 4
+    model, _ = build("fp32")
+    model.train()
+    worst = {}
+    for seed in (1, 2, 3, 4, 5):
+        cpu_batch = synth.make_batch(B, seed=seed)
+        with torch.no_grad():
+            ref = O.gdrn_forward(synth.make_state_dict(0), cpu_batch, do_loss=True, training=True, bufs={})
+        model.load_state_dict(synth.make_state_dict(0))
+        batch = to_dev(cpu_batch)
+        with torch.no_grad():
+            model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+        plan = model.engine().plan(B, True, True)
+        fc = plan.fc_out.cpu()
+        errs = {"rot6d": rel(fc[:, :6], ref["rot6d"]), "t_": rel(fc[:, 6:9], ref["t_"]), "rot": rel(plan.rot, ref["rot"]), "trans": rel(plan.trans, ref["trans"])}
+        print(f"fp32 bs=4 seed {seed} pose rel-err vs oracle:", {k: "%.2e" % v for k, v in errs.items()})
+        worst[seed] = max(errs.values())
+    print("fp32 bs=4 worst pose rel-err over seeds: %.2e" % max(worst.values()))
+    assert max(worst.values()) < 1e-4, worst
+
+
+def test_loss_kernels_replay_reference_golden_g4(golden_dir):
+    """golden G4 = the reference's own gdrn_loss on fixed maps / poses (tests/golden/make_golden.py), incl. the all-zero visible
+    mask (clamp(min=1), GDRN.py:349) and the symmetric point-matching loss (pm_loss.py:91-92, pose_utils.py:457-482): the HIP
+    loss kernels (gdrn_map_loss_fwd / finalize, gdrn_pose_loss) reproduce all 8 values of the four cases."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd import GDRN as G
+    from gdrnet_amd.cabi import PoseParams
+    from oracle import gdrn_oracle as O
+
+    lib = cabi.load()
+    g = np.load(os.path.join(golden_dir, "g4_loss.npz"))
+    B, HW, nreg, hs = 4, 4096, 64, 72
+    batch = synth.make_batch(B, seed=7, num_classes=21, cam="ycbv", with_sym=True)
+    mk = lambda name, shape, s=1.0: torch.from_numpy((synth.hash_normal(11, name, shape) * s).astype(np.float32))
+    maps = torch.cat([mk("m", (B, 1, 64, 64)), mk("x", (B, 1, 64, 64)), mk("y", (B, 1, 64, 64)), mk("z", (B, 1, 64, 64)), mk("r", (B, 65, 64, 64), 2.0)], 1)
+    rot6d = mk("r6", (B, 6))
+    t_ = mk("t", (B, 3), 0.3) + torch.tensor([0.0, 0.0, 1.0])
+    d = lambda t: t.to(DEV).float().contiguous()
+    head = torch.zeros(B * HW, hs, device=DEV)
+    head[:, :69] = maps.permute(0, 2, 3, 1).reshape(B * HW, 69).to(DEV)
+    fc = torch.zeros(B, 64)
+    fc[:, :6], fc[:, 6:9] = rot6d, t_
+    keep = dict(fc=d(fc), cams=d(batch["roi_cam"]), ctr=d(batch["roi_center"]), wh=d(batch["roi_wh"]), rat=d(batch["resize_ratio"]), ext=d(batch["roi_extent"]),
+                grot=d(batch["ego_rot"]), gtr=d(batch["roi_trans_ratio"]), gt=d(batch["trans"]), pts=d(batch["roi_points"]), gxyz=d(batch["roi_xyz"]),
+                mt=d(batch["roi_mask_trunc"]), greg=batch["roi_region"].to(DEV).contiguous())
+    sym, cnt, K = G.GDRN._pack_sym(None, batch["sym_info"], B, DEV)
+    assert K == 2
+    st = torch.cuda.current_stream().cuda_stream
+    for case in ("normal", "zero_visib"):
+        mv = d(batch["roi_mask_visib"]) if case == "normal" else torch.zeros(B, 64, 64, device=DEV)
+        for tag, use_sym in (("nosym", False), ("sym", True)):
+            acc = torch.zeros(8, dtype=torch.float64, device=DEV)
+            losses = torch.full((8,), float("nan"), device=DEV)
+            check(lib.gdrn_map_loss_fwd(ptr(head), hs, ptr(keep["gxyz"]), ptr(mv), ptr(keep["mt"]), ptr(keep["greg"]), B, HW, nreg, ptr(acc), st), "map_loss_fwd")
+            check(lib.gdrn_map_loss_finalize(ptr(acc), B, HW, ptr(losses), st), "map_loss_finalize")
+            rot, trans = torch.zeros(B, 9, device=DEV), torch.zeros(B, 3, device=DEV)
+            dfc, vis = torch.zeros(3, B, 64, device=DEV), torch.zeros(B, 2, device=DEV)
+            pp = PoseParams()
+            pp.fc, pp.fs, pp.cams, pp.centers, pp.whs, pp.ratios, pp.extents = ptr(keep["fc"]), 64, ptr(keep["cams"]), ptr(keep["ctr"]), ptr(keep["wh"]), ptr(keep["rat"]), ptr(keep["ext"])
+            pp.gt_rot, pp.gt_trans, pp.gt_trans_ratio, pp.points, pp.npts = ptr(keep["grot"]), ptr(keep["gt"]), ptr(keep["gtr"]), ptr(keep["pts"]), int(keep["pts"].shape[1])
+            if use_sym:
+                pp.sym, pp.sym_count, pp.Kmax = ptr(sym), ptr(cnt), K
+            pp.N, pp.train, pp.rot, pp.trans, pp.losses, pp.dfc, pp.vis = B, 1, ptr(rot), ptr(trans), losses.data_ptr() + 20, ptr(dfc), ptr(vis)
+            check(lib.gdrn_pose_loss(C.byref(pp), st), "pose_loss")
+            torch.cuda.synchronize()
+            from gdrnet_amd.engine import LOSS_NAMES
+
+            got = dict(zip(LOSS_NAMES, losses.cpu().numpy()))
+            names = list(g[f"{case}/{tag}/names"])
+            np.testing.assert_allclose(np.array([got[k] for k in names]), g[f"{case}/{tag}/values"], rtol=2e-5, atol=1e-7, err_msg=f"{case}/{tag}")
+            if case == "zero_visib":
+                assert got["loss_coor_x"] == 0.0 and got["loss_coor_y"] == 0.0 and got["loss_coor_z"] == 0.0
+
+
+def _conditioned_state_dict():
+    """synth weights with the last BatchNorm of every residual block scaled by 0.1 (the usual zero-gamma residual init): the
+    random-init BatchNorm-ReLU chain multiplies every perturbation by ~1.2 per layer (x700-1600 over the 43 BatchNorms of this graph:
+    fp32 rounding -> 1e-4 at the pose, test_fp32_*), which makes any bf16-vs-fp32 comparison a measurement of that chaos; with
+    near-identity blocks the amplification drops to ~x80 (fp32 vs fp64: 5e-6) and what is left is the arithmetic's own error."""
+    sd = synth.make_state_dict(0)
+    for k in sd:
+        if k.startswith("backbone.layer") and k.endswith("bn2.weight"):
+            sd[k] = sd[k] * 0.1
+    return sd
+
+
+def test_bf16_parity_on_a_conditioned_network():
+    """Throughput (bf16) mode on a conditioned network (see _conditioned_state_dict), three figures:
+    (1) train mode, engine vs oracle/bf16_emulation.py (the reference's arithmetic with the engine's bf16 storage points): only the
+        summation order differs -> implementation fidelity;
+    (2) train mode, engine vs the plain fp32 oracle -> what bf16 storage of ~100 chained tensors costs on this graph;
+    (3) eval mode (folded BatchNorm on converged running statistics, test-mode pose decode -- what cfg.TEST.AMP_TEST maps to,
+        INTEGRATION.md) vs the fp32 oracle, incl. the per-RoI rotation error in degrees.
+    Bounds: about 2x the measured values (printed)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd import GDRN as G
+    from oracle import bf16_emulation as E
+    from oracle import gdrn_oracle as O
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = _conditioned_state_dict()
+
+    def mk(dtype, state):
+        cfg = lm13_cfg(device=DEV)
+        cfg.MODEL.CDPN.HIP_DTYPE = dtype
+        m, _ = G.build_model_optimizer(cfg)
+        m.load_state_dict(state)
+        return m
+
+    # ---- train mode
+    B = 16
+    cpu_batch = synth.make_batch(B, seed=41)
+    with torch.no_grad():
+        ref_st = E.forward_train(sd, cpu_batch)
+        ref32 = O.gdrn_forward(sd, cpu_batch, do_loss=True, training=True, bufs={})
+    m = mk("bf16", sd)
+    m.train()
+    batch = to_dev(cpu_batch)
+    with torch.no_grad():
+        _, loss_dict = m(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    plan = m.engine().plan(B, True, True)
+    maps = plan.head_out[:, :69].view(B, 64, 64, 69).permute(0, 3, 1, 2).cpu()
+    fc = plan.fc_out.cpu()
+    maps32 = torch.cat([ref32["mask"], ref32["coor_x"], ref32["coor_y"], ref32["coor_z"], ref32["region"]], 1)
+    e_st = {"maps": rel(maps, ref_st["maps"]), "rot6d": rel(fc[:, :6], ref_st["rot6d"]), "t_": rel(fc[:, 6:9], ref_st["t_"]), "rot": rel(plan.rot, ref_st["rot"]),
+            "trans": rel(plan.trans, ref_st["trans"])}
+    e_32 = {"maps": rel(maps, maps32), "rot6d": rel(fc[:, :6], ref32["rot6d"]), "t_": rel(fc[:, 6:9], ref32["t_"]), "rot": rel(plan.rot, ref32["rot"]),
+            "trans": rel(plan.trans, ref32["trans"])}
+    print("bf16 train bs=16, conditioned net: engine vs bf16-storage oracle:", {k: "%.2e" % v for k, v in e_st.items()})
+    print("bf16 train bs=16, conditioned net: engine vs fp32 oracle:        ", {k: "%.2e" % v for k, v in e_32.items()},
+          "| bf16-storage oracle vs fp32 oracle: maps %.2e" % rel(ref_st["maps"], maps32))
+    lerr = {k: abs(loss_dict[k].item() - v.item()) / max(abs(v.item()), 1e-3) for k, v in ref32["loss_dict"].items()}
+    print("bf16 train losses rel-err vs fp32 oracle:", {k: "%.1e" % v for k, v in lerr.items()})
+    # ---- eval mode: converge the running statistics with 60 train-mode passes of the fp32 engine, then compare inference
+    m32 = mk("fp32", sd)
+    m32.train()
+    warm = [to_dev(synth.make_batch(16, seed=50 + i)) for i in range(4)]
+    with torch.no_grad():
+        for it in range(60):
+            wb = warm[it % 4]
+            m32(wb["roi_img"], **synth.model_kwargs(wb, do_loss=True))
+    torch.cuda.synchronize()
+    sd_c = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    Be = 8
+    eb = synth.make_batch(Be, seed=77)
+    with torch.no_grad():
+        ref_e = O.gdrn_forward(sd_c, eb, do_loss=False, training=False)
+    mb = mk("bf16", sd_c)
+    mb.eval()
+    mb.cfg.TEST.USE_PNP = True
+    ebd = to_dev(eb)
+    with torch.no_grad():
+        od = mb(ebd["roi_img"], **synth.model_kwargs(ebd, do_loss=False))
+    maps_e = torch.cat([od["mask"], od["coor_x"], od["coor_y"], od["coor_z"], od["region"]], 1).cpu()
+    maps_r = torch.cat([ref_e["mask"], ref_e["coor_x"], ref_e["coor_y"], ref_e["coor_z"], ref_e["region"]], 1)
+    Ra, Rb = od["rot"].view(Be, 3, 3).double().cpu(), ref_e["rot"].view(Be, 3, 3).double()
+    cos = ((Ra.transpose(1, 2) @ Rb).diagonal(dim1=1, dim2=2).sum(1) - 1) / 2
+    ang = torch.rad2deg(torch.acos(cos.clamp(-1, 1)))
+    e_ev = {"maps": rel(maps_e, maps_r), "rot": rel(od["rot"], ref_e["rot"]), "trans": rel(od["trans"], ref_e["trans"])}
+    print("bf16 eval bs=8, conditioned net + converged running stats: engine vs fp32 oracle:", {k: "%.2e" % v for k, v in e_ev.items()},
+          "rotation error deg: mean %.3f max %.3f" % (float(ang.mean()), float(ang.max())))
+    # measured (round 2): (1) maps 4.0e-2, rot6d 4.2e-2, t_ 6.8e-3, R 8.8e-2, t 3.1e-3 -- the x80 amplification applied to the bf16
+    # flips a different summation order causes (2^-9 steps); (2) maps 7.0e-2, rot6d 5.8e-2, t_ 1.0e-2, R 1.25e-1, t 4.9e-3, the 8 losses
+    # within 5.5e-3 (dense-map losses 7e-4) -- and the bf16-storage oracle itself sits 7.1e-2 from the fp32 oracle: the error is the
+    # storage format's, not the kernels'; (3) maps 7.3e-2, t 5.3e-3.  R is the Gram-Schmidt of a 6-vector that a random-init
+    # Patch-PnP leaves near zero, so its relative error (and the angle printed above) overstates what a trained head would show.
+    assert max(e_st.values()) < 0.18, e_st
+    assert e_32["maps"] < 0.15 and e_32["rot6d"] < 0.15 and e_32["t_"] < 3e-2 and e_32["trans"] < 1.5e-2 and e_32["rot"] < 0.3, e_32
+    assert max(lerr.values()) < 2e-2, lerr
+    assert e_ev["maps"] < 0.15 and e_ev["trans"] < 1.5e-2, e_ev
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_checkpoint_roundtrip_through_the_engine(dtype, tmp_path):
+    """N4 (my_checkpoint.py:9-54, engine.py:190-212): train 3 steps, save with MyCheckpointer (model + optimizer), load into FRESH
+    models from the three on-disk shapes the reference meets -- the wrapped {"model": ...} file, a bare state_dict, a
+    ``module.``-prefixed (DDP-saved) one -- and get (a) bit-identical eval-mode inference (the engine re-packs its bf16 / fragment-major
+    operands and re-folds the BatchNorms from the loaded fp32 parameters) and (b), for the full checkpoint incl. the Ranger state,
+    a bit-identical continuation: the next training step's losses and the parameters after it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.checkpoint import MyCheckpointer
+
+    B = 4
+    batches = [to_dev(synth.make_batch(B, seed=60 + i)) for i in range(4)]
+
+    def step(model, opt, b):
+        kw = synth.model_kwargs(b, do_loss=True)
+        kw.pop("do_loss")
+        return model.train_step(b["roi_img"], optimizer=opt, **kw).clone()
+
+    def infer(model, b):
+        model.eval()
+        with torch.no_grad():
+            od = model(b["roi_img"], **synth.model_kwargs(b, do_loss=False))
+        model.train()
+        return od["rot"].clone(), od["trans"].clone()
+
+    model, opt = build(dtype)
+    model.train()
+    for i in range(3):
+        step(model, opt, batches[i])
+    ck = MyCheckpointer(model, str(tmp_path), optimizer=opt)
+    ck.save("model_0000002", iteration=2)
+    rot0, tr0 = infer(model, batches[3])
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    torch.save(sd, tmp_path / "bare.pth")
+    torch.save({"module." + k: v for k, v in sd.items()}, tmp_path / "ddp.pth")
+    l_next = step(model, opt, batches[3])
+    p_next = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    for fname, full in (("model_0000002.pth", True), ("bare.pth", False), ("ddp.pth", False)):
+        m2, o2 = build(dtype)  # fresh synth-init weights, fresh optimizer
+        m2.train()
+        ck2 = MyCheckpointer(m2, str(tmp_path), optimizer=o2)
+        extra = ck2.load(str(tmp_path / fname), checkpointables=["optimizer"] if full else [])
+        if full:
+            assert extra.get("iteration") == 2
+        rot, tr = infer(m2, batches[3])
+        assert torch.equal(rot, rot0) and torch.equal(tr, tr0), fname
+        if full:
+            l2 = step(m2, o2, batches[3])
+            torch.testing.assert_close(l2, l_next, rtol=1e-6, atol=1e-9)  # (pose losses: float atomics)
+            worst = max(rel(p.detach(), p_next[n]) for n, p in m2.named_parameters())
+            assert worst < 1e-6, worst  # weight gradients of the stride-2 / 1x1 / fc layers accumulate with fp32 atomics
+
+
+def test_bench_under_torch_distributed_run_one_rank(tmp_path):
+    """bench.py launched exactly as the driver launches the multi-GPU tiers (python -m torch.distributed.run --nproc-per-node N ...),
+    with N = 1 on this one-GPU box and --dist-force, so that the data-parallel path runs: RANK / LOCAL_RANK / WORLD_SIZE plumbing, RCCL
+    process-group set-up, parameter broadcast, the bucketed side-stream all-reduce inside every step, barrier, tear-down, the JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--bs", "8", "--no-cpu-baseline", "--no-roofline", "--no-extras", "--dist-force"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "gdrn_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(gdrn_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(gdrn_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -147,3 +147,35 @@ def test_postproc_has_no_cpu_fallback():
         postproc.get_out_mask(cfg, m)
     with pytest.raises(cabi.GdrnHipError):
         postproc.get_out_coor(cfg, m, m, m)
+
+
+def test_workspace_bytes_query_matches_the_per_op_rules():
+    """gdrn_workspace_bytes (host-only, no device needed): the sizes a non-Python host allocates == the rules the engine uses."""
+    import ctypes as C
+
+    lib = cabi.load()
+    cp = cabi.ConvParams()
+    cp.Hi = cp.Wi = cp.Ho = cp.Wo = 64
+    cp.Cin = cp.Cout = cp.x_cs = cp.y_cs = 256
+    cp.KH = cp.KW = 3
+    cp.stride = cp.pad = 1
+    cp.M, cp.dtype, cp.w_rows = 64 * 4096, cabi.BF16, 256
+    rows = lib.gdrn_conv3x3_stats_rows(C.byref(cp))
+    assert rows == 64 * 4096 // 128
+    assert lib.gdrn_workspace_bytes(1, C.byref(cp)) == rows * 2 * 256 * 4
+    assert lib.gdrn_workspace_bytes(0, C.byref(cp)) == lib.gdrn_conv_stats_rows(C.byref(cp)) * 2 * 256 * 4
+    wp = cabi.WgradParams()
+    wp.Hi = wp.Wi = wp.Ho = wp.Wo = 16
+    wp.Cin = wp.Cout = wp.x_cs = wp.dy_cs = 256
+    wp.KH = wp.KW = 3
+    wp.stride = wp.pad = 1
+    wp.M, wp.dtype, wp.splits = 64 * 256, cabi.BF16, 4
+    assert lib.gdrn_workspace_bytes(2, C.byref(wp)) == 4 * 256 * 256 * 9 * 4
+    n = C.c_int(64)
+    assert lib.gdrn_workspace_bytes(3, C.byref(n)) == lib.gdrn_stem_wgrad_parts(64) * 64 * 224 * 4
+    assert lib.gdrn_workspace_bytes(4, C.byref(n)) == lib.gdrn_stem_stats_rows(64) * 2 * 64 * 4
+    mn = (C.c_int * 2)(64, 1024)
+    assert lib.gdrn_workspace_bytes(5, mn) == (16 * 64 * 1024 + 64) * 4
+    a = (C.c_longlong * 3)(64 * 4096, 256, cabi.BF16)
+    assert lib.gdrn_workspace_bytes(6, a) == lib.gdrn_bn_bwd_reduce_rows(64 * 4096, 256, cabi.BF16) * 2 * 256 * 4
+    assert lib.gdrn_workspace_bytes(99, a) == -1 and lib.gdrn_workspace_bytes(0, None) == -1

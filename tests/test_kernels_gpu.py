@@ -191,7 +191,7 @@ def test_conv_transpose_fwd_bwd(H, dt):
 
 
 # ---------------------------------------------------------------------------------------------- weight gradient
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", [(2, 64, 64, 16, 3, 1, 1), (3, 64, 128, 16, 3, 2, 1), (2, 128, 128, 9, 3, 1, 1), (2, 128, 256, 8, 1, 2, 0),
                                   (2, 256, 69, 8, 1, 1, 0), (4, 1024, 256, 1, 1, 1, 0)])

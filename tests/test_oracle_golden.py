@@ -151,3 +151,17 @@ def test_postproc_oracle_vs_reference_golden(golden_dir):
         np.testing.assert_array_equal(ip, g[f"img_pts{i}"])
         np.testing.assert_array_equal(mp, g[f"model_pts{i}"])
     assert len(pts[2][0]) == 0 and len(pts[0][0]) > 1000
+
+
+def test_ranger_oracle(golden_dir):
+    """G6: 7 steps of the reference's own Ranger on a 3-tensor toy == oracle/ranger_oracle.py (the CPU baseline's optimizer step)."""
+    from oracle import ranger_oracle as R
+
+    g = np.load(os.path.join(golden_dir, "g6_ranger.npz"))
+    ps = [torch.from_numpy(synth.hash_normal(31, f"p{i}", s).astype(np.float32)) for i, s in enumerate(((8, 4, 3, 3), (16, 8), (16,)))]
+    state = [dict() for _ in ps]
+    for step in range(7):
+        grads = [torch.from_numpy(synth.hash_normal(32 + step, f"g{i}", tuple(p.shape)).astype(np.float32)) for i, p in enumerate(ps)]
+        R.ranger_step(ps, grads, state, lr=1e-2, weight_decay=0)
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.numpy(), g[f"step{step}/p{i}"], rtol=1e-6, atol=1e-8)

@@ -1,7 +1,7 @@
-"""rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; tools/gpu_runs/run_pmc_traffic.sh) -> profiles/r01_hbm_traffic_bs64_bf16.{txt,json}.
+"""rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; tools/gpu_runs/run_pmc_traffic.sh) -> profiles/r02_hbm_traffic_bs64_bf16.{txt,json}.
 HBM-side bytes per launch of every kernel: counter unit KB -> bytes, FETCH_SIZE x2 (gfx950 tallies 128-byte requests at 64 B,
 MI355X_MICROARCH.md 'HBM').  Usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/p_counter_collection.csv
-gpurun_out/pmc_WRITE_SIZE/p_counter_collection.csv profiles/r01_hbm_traffic_bs64_bf16"""
+gpurun_out/pmc_WRITE_SIZE/p_counter_collection.csv profiles/r02_hbm_traffic_bs64_bf16"""
 import csv
 import json
 import re
@@ -34,7 +34,12 @@ for k in sorted(set(ft) | set(wt)):
     f = ft.get(k, 0.0) * 1024 * 2 / max(fc.get(k, 1), 1)
     w = wt.get(k, 0.0) * 1024 / max(wc.get(k, 1), 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": f, "write_bytes_per_launch": w, "traffic_bytes_per_launch": f + w}
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_hash: bench.py only trusts a summary measured on the same kernel sources)
+
+out["__kernel_source_sha256_16__"] = bench.kernel_source_hash()
 json.dump(out, open(sys.argv[3] + ".json", "w"), indent=1, sort_keys=True)
+del out["__kernel_source_sha256_16__"]
 rows = sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])
 with open(sys.argv[3] + ".txt", "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes) -- python bench.py --steps 2 --warmup 2\n")
