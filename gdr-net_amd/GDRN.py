@@ -236,6 +236,7 @@ class _PathFn(torch.autograd.Function):
             raise cabi.GdrnHipError("backward of a forward pass whose activations were overwritten by a later forward of the same "
                                     "batch size: call loss.backward() before the next model(...) call")
         plan.gw.copy_(glosses.to(torch.float32))
+        plan._gw_key = None
         plan.run_backward(ctx.kctx, on_bucket=ctx.model._on_bucket)
         red = getattr(ctx.model, "_reducer", None)
         if red is not None:
@@ -432,7 +433,12 @@ class GDRN(nn.Module):
                 return out
         eng, plan, kctx = self._prepare(x, True, a)
         plan.run_forward(kctx)
-        plan.gw.copy_(self._loss_w if loss_weights is None else self._loss_w * loss_weights)
+        if loss_weights is not None:
+            plan.gw.copy_(self._loss_w * loss_weights)
+            plan._gw_key = None
+        elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version):
+            plan.gw.copy_(self._loss_w)  # dL/dloss_k = the config's loss weights: written once, not every step
+            plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version)
         plan.run_backward(kctx, on_bucket=self._on_bucket)
         red = getattr(self, "_reducer", None)
         gs = 1.0

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgdrn_hip.so")
 
 F32, BF16 = 0, 1
+PREZEROED = 0x100  # GDRN_PREZEROED
 P = C.c_void_p
 I = C.c_int
 LL = C.c_longlong
@@ -61,6 +62,10 @@ class PackTask(C.Structure):
         ("A1", I), ("A2", I), ("T", I), ("B", I), ("A1v", I), ("A2v", I), ("Bv", I), ("flip", I),
         ("s1", LL), ("s2", LL), ("st", LL), ("sb", LL), ("n", LL), ("frag", I), ("pad_", I),
     ]
+
+
+class ZeroTask(C.Structure):
+    _fields_ = [("p", P), ("n16", LL)]
 
 
 class WreduceTask(C.Structure):
@@ -128,7 +133,8 @@ _SIGS = {
     "gdrn_bn_bwd_coef": [P, I, I, LL, P, P, P, P, P, P, P, P, P],
     "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, LL, I, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],
-    "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "gdrn_maxpool_bwd_rows": [I, I, I, I, I],
+    "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_bwd": [P, P, I, I, I, I, I, P],
     "gdrn_gn_relu_fwd": [P, P, P, P, P, I, I, I, I, F, I, P],
@@ -143,6 +149,8 @@ _SIGS = {
     "gdrn_combine3": [P, P, P, I, P],
     "gdrn_ranger_step": [P, P, P, P, P, I, I, I, F, F, F, F, F, F, I, I, F, P],
     "gdrn_pack_chunk": [],
+    "gdrn_zero_chunk": [],
+    "gdrn_zero_multi": [P, P, I, I, P],
     "gdrn_pack_multi": [P, P, I, I, I, P],
     "gdrn_unpack_multi": [P, P, I, I, P],
     "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, F, P],

@@ -148,6 +148,20 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
     }
 }
 
+// zero a list of device regions (16-byte granules) in ONE launch: the small gradient accumulators of a backward pass
+constexpr int ZERO_CHUNK = 4096;  // 16-byte granules per workgroup (64 KiB)
+__global__ __launch_bounds__(256) void zero_multi_kernel(const gdrn_zero_task* __restrict__ tasks, const int* __restrict__ blk_start, int ntasks) {
+    const int t = find_task(blk_start, ntasks, blockIdx.x);
+    const gdrn_zero_task k = tasks[t];
+    const long long base = (long long)(blockIdx.x - blk_start[t]) * ZERO_CHUNK;
+    uint4* dst = reinterpret_cast<uint4*>(k.p);
+    for (int i = threadIdx.x; i < ZERO_CHUNK; i += 256) {
+        const long long g = base + i;
+        if (g >= k.n16) break;
+        dst[g] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 __global__ __launch_bounds__(256) void unpack_multi_kernel(const gdrn_pack_task* __restrict__ tasks, const int* __restrict__ blk_start,
                                                            int ntasks) {
     const int t = find_task(blk_start, ntasks, blockIdx.x);
@@ -238,6 +252,15 @@ extern "C" int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_s
 extern "C" int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
     hipLaunchKernelGGL(unpack_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_zero_chunk(void) { return ZERO_CHUNK; }
+
+extern "C" int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
+    if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -312,11 +312,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx,
                                                           const T* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, T* __restrict__ g, int N, int H,
-                                                          int W, int C) {
+                                                          int W, int C, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float* __restrict__ rows) {
     constexpr int V = Vec16<T>::VEC;
-    __shared__ float sc_s[512], sh_s[512];
-    for (int c = threadIdx.x; c < C; c += 256) { sc_s[c] = scale[c]; sh_s[c] = shift[c]; }
+    __shared__ float sc_s[512], sh_s[512], mu_s[512], is_s[512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sc_s[c] = scale[c]; sh_s[c] = shift[c];
+        mu_s[c] = rows ? mean[c] : 0.f; is_s[c] = rows ? invstd[c] : 0.f;
+    }
     __syncthreads();
+    // rows != NULL: also the two BatchNorm-backward sums of g (sum g, sum g*xhat per channel) as one partial row per workgroup --
+    // the host guarantees a thread's channel vector is the same in every grid-stride iteration (C/V divides 64 and the stride)
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     const int Ho = H / 2, Wo = W / 2, cvn = C / V;
     const unsigned total = (unsigned)((long long)N * H * W * cvn);  // < 2^31, checked by the host wrapper: 32-bit index math
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -351,6 +360,31 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         for (int j = 0; j < V; ++j)
             if (!(xv[j] * sc_s[cv * V + j] + sh_s[cv * V + j] > 0.f)) acc[j] = 0.f;
         Vec16<T>::store(g + (size_t)i * V, acc);
+        if (rows != nullptr) {
+            // the sums see g as the consumer will read it (rounded to the storage type), like a separate gdrn_bn_bwd_reduce pass
+            float gr[V];
+            Vec16<T>::unpack(Vec16<T>::pack(acc), gr);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s1[j] += gr[j];
+                s2[j] += gr[j] * (xv[j] - mu_s[cv * V + j]) * is_s[cv * V + j];
+            }
+        }
+    }
+    if (rows != nullptr) {
+        __shared__ float part[4][2 * 512];
+        const int cvn2 = C / V, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cvt = threadIdx.x % cvn2;
+        for (int o = cvn2; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+        }
+        if (lane < cvn2) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { part[wave][cvt * V + j] = s1[j]; part[wave][C + cvt * V + j] = s2[j]; }
+        }
+        __syncthreads();
+        float* dst = rows + (size_t)blockIdx.x * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
     }
 }
 
@@ -769,16 +803,28 @@ extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const
     return GDRN_OK;
 }
 
+extern "C" int gdrn_maxpool_bwd_rows(int N, int H, int W, int C, int dtype) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return GDRN_ERR_ARG;
+    const long long n = (long long)N * H * W * C;
+    return ew_grid(n / (dtype == GDRN_DT_BF16 ? 8 : 4));
+}
+
 extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale,
-                                const float* shift, void* g, int N, int H, int W, int C, int dtype, void* stream) {
+                                const float* shift, void* g, int N, int H, int W, int C, const float* mean, const float* invstd,
+                                float* rows, int dtype, void* stream) {
     if (!dy || !idx || !x || !scale || !shift || !g || N <= 0 || (H & 1) || (W & 1) || (C % 8)) return GDRN_ERR_ARG;
     if (C > 512 || (long long)N * H * W * C / 4 >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    if (rows != nullptr) {
+        if (!mean || !invstd) return GDRN_ERR_ARG;
+        const int cvn = C / (dtype == GDRN_DT_BF16 ? 8 : 4);
+        if (cvn > 64 || 64 % cvn) return GDRN_ERR_SHAPE;  // a thread keeps one channel vector over its grid-stride iterations
+    }
     const long long n = (long long)N * H * W * C;
     DISPATCH(dtype,
              hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, idx,
-                                (const float*)x, scale, shift, (float*)g, N, H, W, C),
+                                (const float*)x, scale, shift, (float*)g, N, H, W, C, mean, invstd, rows),
              hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, idx,
-                                (const bf16_t*)x, scale, shift, (bf16_t*)g, N, H, W, C));
+                                (const bf16_t*)x, scale, shift, (bf16_t*)g, N, H, W, C, mean, invstd, rows));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -832,11 +878,15 @@ extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, co
     if (!dy || !y || !x || !gamma || !mean_rstd || !dx || !dgamma || !dbeta || N <= 0 || HW <= 0 || G <= 0 || G > 128 ||
         C > 512 || (C % G) || (C % 8))
         return GDRN_ERR_ARG;
+    const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
+    dtype &= ~GDRN_PREZEROED;
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
     const int CS = gn_slab(C, G, V);
     if (256 % (CS / V)) return GDRN_ERR_SHAPE;
-    if (hipMemsetAsync(dgamma, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
-    if (hipMemsetAsync(dbeta, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (!prezeroed) {
+        if (hipMemsetAsync(dgamma, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+        if (hipMemsetAsync(dbeta, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    }
     DISPATCH(dtype,
              hipLaunchKernelGGL(gn_relu_bwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)dy, (const float*)y,
                                 (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, HW, C, G, CS),
@@ -857,9 +907,11 @@ extern "C" int gdrn_leaky_bwd(const void* dy, const void* y, void* dx, long long
 
 extern "C" int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db, int dtype, void* stream) {
     if (!dy || !db || rows <= 0 || C <= 0 || C > cs || cs > 1024 || (cs % 8)) return GDRN_ERR_ARG;
+    const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
+    dtype &= ~GDRN_PREZEROED;
     const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
     if ((cs / V) > 256 || 256 % (cs / V)) return GDRN_ERR_SHAPE;
-    if (hipMemsetAsync(db, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (!prezeroed && hipMemsetAsync(db, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     const int rpp = 256 / (cs / V);
     int rpb = rpp * 16;
     int blocks = cdiv(rows, rpb);

@@ -267,6 +267,8 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
                                float* ws, float* grad, int dtype, void* stream) {
     if (!canvas || !g || !ws || !grad || N <= 0) return GDRN_ERR_ARG;
     if (a != nullptr && (!raw || !b || !c)) return GDRN_ERR_ARG;
+    const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
+    dtype &= ~GDRN_PREZEROED;
     if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
     if ((long long)N * 128 * 128 * 64 >= (1ll << 40)) return GDRN_ERR_SHAPE;
     const int nstages = N * 256;
@@ -276,7 +278,7 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(parts), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(g),
                        reinterpret_cast<const bf16_t*>(raw), a, b, c, nstages, per, ws);
     GDRN_CHECK_LAUNCH();
-    if (hipMemsetAsync(grad, 0, 64 * 147 * sizeof(float), st) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (!prezeroed && hipMemsetAsync(grad, 0, 64 * 147 * sizeof(float), st) != hipSuccess) return GDRN_ERR_LAUNCH;
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64, SW_SLICES), dim3(256), 0, st, ws, parts, grad);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

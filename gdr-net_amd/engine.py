@@ -18,7 +18,7 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import cabi
-from .cabi import BF16, F32, ConvParams, PoseParams, WgradParams, check, ptr
+from .cabi import BF16, F32, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
 
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
@@ -300,11 +300,10 @@ class Engine:
         self._versions["sig"] = sig
         st = self._stream()
         lib = self.lib
-        with torch.no_grad():
-            self.rt_w[:6].copy_(self.P["pnp_net.fc_r.weight"])
-            self.rt_w[6:].copy_(self.P["pnp_net.fc_t.weight"])
-            self.rt_b[:6].copy_(self.P["pnp_net.fc_r.bias"])
-            self.rt_b[6:].copy_(self.P["pnp_net.fc_t.bias"])
+        with torch.no_grad():  # fc_r | fc_t as one 9-row layer: one multi-tensor copy launch
+            torch._foreach_copy_([self.rt_w[:6], self.rt_w[6:], self.rt_b[:6], self.rt_b[6:]],
+                                 [self.P["pnp_net.fc_r.weight"].detach(), self.P["pnp_net.fc_t.weight"].detach(), self.P["pnp_net.fc_r.bias"].detach(),
+                                  self.P["pnp_net.fc_t.bias"].detach()])
         Ls = self.layers["backbone.conv1"]
         check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
         if self.stem_direct:
@@ -343,10 +342,12 @@ class Plan:
         self._wreduce = {}         # layer key -> (workspace, nsplit, Cout, Cin) of the halo weight-gradient partials
         self._wgrad_deferred = []  # (forward group index, layer, WgradParams, flops) of the halo weight gradients
         self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
+        self._zero_regions = []    # fp32 tensors the backward accumulates into with atomics: cleared by ONE gdrn_zero_multi launch
         self.generation = 0        # bumped by every run_forward: a backward checks its activations are still the plan's
         self._build()
         if self.has_backward:
             self._finish_unpack()
+            self._build_zero_table()
         self.bwd_groups = [[op for op in g if op is not None] for g in self.bwd_groups]
         self.bwd = [op for g in reversed(self.bwd_groups) for op in g]
 
@@ -459,6 +460,8 @@ class Plan:
             self._wgrad_deferred.append((len(self.bwd_groups), L, wp, 2.0 * self.B * Ho * Wo * L.O * L.I * L.KK))
             return None
 
+        self._zero_regions.append(self._pad16(L.dwp, e.dwp_flat))  # accumulated with fp32 atomics
+
         def run(st, ctx):
             s = fn(ref, st)
             if s:
@@ -474,6 +477,33 @@ class Plan:
         kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>"
         run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + ":wgrad")
         return run
+
+    @staticmethod
+    def _pad16(t, flat):
+        """the 16-byte-padded slice of the flat fp32 buffer `flat` that holds the view `t` (offsets in these buffers are multiples of 4 floats)."""
+        off = (t.data_ptr() - flat.data_ptr()) // 4
+        assert 0 <= off and off % 4 == 0 and off + t.numel() <= flat.numel(), off
+        return flat[off: min(off + _ru(t.numel(), 4), flat.numel())]
+
+    def _grad16(self, g):
+        return self._pad16(g, self.e.grad_flat)
+
+    def _build_zero_table(self):
+        from .cabi import ZeroTask, to_device_table
+
+        e = self.e
+        chunk = e.lib.gdrn_zero_chunk()
+        tasks, starts = [], [0]
+        seen = set()
+        for t in self._zero_regions:
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 and (t.numel() * 4) % 16 == 0, (t.shape, t.data_ptr() % 16)
+            n16 = t.numel() * 4 // 16
+            tasks.append(ZeroTask(p=t.data_ptr(), n16=n16))
+            starts.append(starts[-1] + (n16 + chunk - 1) // chunk)
+        self._zero_tab = (to_device_table(tasks, e.dev), torch.tensor(starts, dtype=torch.int32, device=e.dev), len(tasks), starts[-1])
 
     def _unpack(self, L):
         """packed fp32 weight gradient -> the parameter's .grad layout.  Every layer except the stem is deferred to one
@@ -738,8 +768,14 @@ class Plan:
             d_p0 = E(B, 64, 64, 64)
             g_stem = E(B, 128, 128, 64)
             d_raw0 = g_stem  # in place
+            # with the fused stem weight gradient the max-pool backward also emits the BatchNorm-backward sums of the gradient it
+            # writes (one partial row per workgroup): no separate reduce pass over the two 134 MB tensors
+            mp_rows = int(lib.gdrn_maxpool_bwd_rows(B, 128, 128, 64, e.dt)) if e.stem_wgrad else 0
+            assert mp_rows * 2 * 64 <= self.stats.numel()
             grp = [lambda st, ctx: check(lib.gdrn_maxpool_bwd(ptr(d_p0), ptr(idx0), ptr(raw0), ptr(s0.scale), ptr(s0.shift),
-                                                              ptr(g_stem), B, 128, 128, 64, e.dt, st), "maxpool_bwd")]
+                                                              ptr(g_stem), B, 128, 128, 64, ptr(s0.mean) if mp_rows else None,
+                                                              ptr(s0.invstd) if mp_rows else None, ptr(self.stats) if mp_rows else None, e.dt, st),
+                                         "maxpool_bwd")]
             if e.stem_wgrad:
                 # the stem has no data gradient: its BatchNorm-backward apply is evaluated inside the weight-gradient kernel while
                 # the dy tile is staged (no 134 MB d_raw0 round trip, dy read once instead of once per kernel row)
@@ -748,12 +784,14 @@ class Plan:
                 gw = e.grads["backbone.conv1.weight"]
                 assert gw.is_contiguous() and gw.dtype == torch.float32
                 sw_ws = e._empty(int(lib.gdrn_stem_wgrad_parts(B)) * 64 * 224, dtype=torch.float32)
-                grp += self._bn_bwd("backbone.bn1", g_stem, None, raw0, d_raw0, apply=False)  # reduce + coef; the apply is fused below
+                grp.append(self._bn_coef_op("backbone.bn1", self.stats, mp_rows))  # rows -> (a, b, c), dgamma, dbeta; the apply is fused below
 
                 def stem_wgrad(st, ctx, a=(self.img_p, g_stem, raw0, sb.ka, sb.kb, sb.kc, sw_ws, gw)):
                     # tensors bound as a default argument: _build() reuses short local names further down (late-binding closures)
-                    check(lib.gdrn_stem_wgrad(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), B, ptr(a[6]), ptr(a[7]), e.dt, st),
+                    check(lib.gdrn_stem_wgrad(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), B, ptr(a[6]), ptr(a[7]), e.dt | PREZEROED, st),
                           "stem_wgrad")
+
+                self._zero_regions.append(self._grad16(gw))
 
                 stem_wgrad.meta = dict(kernel="stem_wgrad_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1:wgrad")
                 grp.append(stem_wgrad)
@@ -983,7 +1021,8 @@ class Plan:
             grp.append(self._wgrad(LO, hx, self.d_head, 64, 64, 64, 64, 1, 0, 256, e.head_c, 256, 128))
             grp.append(self._unpack(LO))
             gb = e.grads[h + "23.bias"]
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt, st), "bias_grad"))
+            self._zero_regions.append(self._grad16(gb))
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad"))
             op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256)
             grp.append(op)
             self.bwd_groups.append(grp)
@@ -1006,7 +1045,8 @@ class Plan:
                 dgam, dbet = e.grads[q + f"{gi}.weight"], e.grads[q + f"{gi}.bias"]
                 grp = [lambda st, ctx, d_g=d_g, gact=gact, r=r, gam=gam, mr=mr, d_r=d_r, dgam=dgam, dbet=dbet, Ho=Ho: check(
                     lib.gdrn_gn_relu_bwd(ptr(d_g), ptr(gact), ptr(r), ptr(gam), ptr(mr), ptr(d_r), ptr(dgam), ptr(dbet), B, Ho * Ho, 128, 32,
-                                         e.dt, st), "gn_relu_bwd")]
+                                         e.dt | PREZEROED, st), "gn_relu_bwd")]
+                self._zero_regions += [self._grad16(dgam), self._grad16(dbet)]
                 grp.append(self._wgrad(Lc, px, d_r, Hp, Hp, Ho, Ho, 2, 1, cin, 128, cin, 128))
                 grp.append(self._unpack(Lc))
                 op, _ = self._conv(Lc, d_r, 128, d_px, Ho, Ho, Hp, Hp, 2, 1, mode=1, w=Lc.wd, rows=Lc.rows_d, cin=128, cout=cin)
@@ -1043,28 +1083,30 @@ class Plan:
             d_fc32 = e._zeros(B, 64, dtype=F32t)
             d_fc = E(B, 64)
             d_f2, d_f2p, d_f1, d_f1p = E(B, 256), E(B, 256), E(B, 1024), E(B, 1024)
-            self.rt_gb = e._zeros(9, dtype=F32t)
+            self._rt_gb_full = e._zeros(12, dtype=F32t)
+            self.rt_gb = self._rt_gb_full[:9]
+            self._zero_regions += [self._rt_gb_full, self._grad16(e.grads["pnp_net.fc1.bias"]), self._grad16(e.grads["pnp_net.fc2.bias"])]
             g_b1, g_b2 = e.grads["pnp_net.fc1.bias"], e.grads["pnp_net.fc2.bias"]
             grp = [
                 lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3"),
                 lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
                 self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64),
                 self._unpack(L3),
-                lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt, st), "bias_grad"),
-                lambda st, ctx: (e.grads["pnp_net.fc_r.bias"].copy_(self.rt_gb[:6]), e.grads["pnp_net.fc_t.bias"].copy_(self.rt_gb[6:])),
+                lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt | PREZEROED, st), "bias_grad"),
+                lambda st, ctx: torch._foreach_copy_([e.grads["pnp_net.fc_r.bias"], e.grads["pnp_net.fc_t.bias"]], [self.rt_gb[:6], self.rt_gb[6:]]),
             ]
             op, _ = self._conv(L3, d_fc, 64, d_f2, 1, 1, 1, 1, 1, 0, w=L3.wd, rows=L3.rows_d, cin=64, cout=256)
             grp.append(op)
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f2), ptr(f2), ptr(d_f2p), B * 256, e.dt, st), "leaky_bwd"))
             grp.append(self._wgrad(L2, f1, d_f2p, 1, 1, 1, 1, 1, 0, 1024, 256, 1024, 256))
             grp.append(self._unpack(L2))
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt, st), "bias_grad"))
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt | PREZEROED, st), "bias_grad"))
             op, _ = self._conv(L2, d_f2p, 256, d_f1, 1, 1, 1, 1, 1, 0, w=L2.wd, rows=L2.rows_d, cin=256, cout=1024)
             grp.append(op)
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f1), ptr(f1), ptr(d_f1p), B * 1024, e.dt, st), "leaky_bwd"))
             grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024))
             grp.append(self._unpack(L1))
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt, st), "bias_grad"))
+            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad"))
             op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
             grp.append(op)
             self.bwd_groups.append(grp)
@@ -1122,7 +1164,8 @@ class Plan:
             raise cabi.GdrnHipError("dry (build-only) engine: there is no CPU execution path")
         main = torch.cuda.current_stream(e.dev)
         st = main.cuda_stream
-        e.dwp_flat.zero_()
+        ztab, zst, znt, znb = self._zero_tab
+        check(e.lib.gdrn_zero_multi(ptr(ztab), ptr(zst), znt, znb, st), "zero_multi")
         marks = self._bucket_marks() if on_bucket is not None else {}
         # The bucket-end work (grouped weight gradients, their reduction, gradient unpack) only feeds the optimizer /
         # the RCCL exchange: it goes to a second stream behind an event, so the next bucket's dependent chain of short

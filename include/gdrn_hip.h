@@ -247,8 +247,14 @@ int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long npix, const 
                      const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream);
 int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
                              int N, int H, int W, int C, int dtype, void* stream);
+/* g = gradient w.r.t. the BatchNorm OUTPUT in front of the ReLU + max-pool (ReLU mask recomputed from x*scale + shift).
+ * rows != NULL (then mean, invstd too): also that BatchNorm's backward sums of g, one partial row [2][C] per workgroup
+ * (gdrn_maxpool_bwd_rows(N, H, W, C, dtype) rows, for gdrn_bn_bwd_coef) -- the separate gdrn_bn_bwd_reduce pass over g and x
+ * disappears. */
+int gdrn_maxpool_bwd_rows(int N, int H, int W, int C, int dtype);
 int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale, const float* shift,
-                     void* g, int N, int H, int W, int C, int dtype, void* stream);
+                     void* g, int N, int H, int W, int C, const float* mean, const float* invstd, float* rows, int dtype,
+                     void* stream);
 
 /* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), cdpn_rot_head_region.py:102 */
 int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
@@ -370,6 +376,18 @@ typedef struct gdrn_ranger_task {
     int rows, cols, gc;
     float lr;
 } gdrn_ranger_task;
+/* gdrn_zero_multi: zero ntasks device regions (p 16-byte aligned, n16 granules of 16 bytes) in one launch; blk_start prefix sums of
+ * ceil(n16 / gdrn_zero_chunk()).  With it a backward pass clears all its atomically-accumulated gradients (packed weight gradients
+ * of the generic kernel, GroupNorm / bias / stem gradients) once, and the entry points below are called with GDRN_PREZEROED. */
+typedef struct gdrn_zero_task {
+    void* p;
+    long long n16;
+} gdrn_zero_task;
+int gdrn_zero_chunk(void);
+int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+/* OR-ed into the `dtype` argument of gdrn_gn_relu_bwd / gdrn_bias_grad / gdrn_stem_wgrad: the gradient outputs they accumulate
+ * into with atomics were zeroed by the caller (gdrn_zero_multi) -- skip the internal hipMemsetAsync (one launch each). */
+#define GDRN_PREZEROED 0x100
 int gdrn_pack_chunk(void);
 int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream);
 int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);

@@ -531,9 +531,20 @@ def test_bn_relu_maxpool(H, dt):
     check(lib.gdrn_bn_relu_maxpool_fwd(ptr(xd), ptr(sc), ptr(sh), ptr(y), ptr(idx), B, Hh, Hh, C_, dt, H.stream()), "pool_fwd")
     assert H.rel(H.nchw(y), ref) < TOL[dt]
     g = torch.empty_like(xd)
-    check(lib.gdrn_maxpool_bwd(ptr(dyd), ptr(idx), ptr(xd), ptr(sc), ptr(sh), ptr(g), B, Hh, Hh, C_, dt, H.stream()), "pool_bwd")
+    check(lib.gdrn_maxpool_bwd(ptr(dyd), ptr(idx), ptr(xd), ptr(sc), ptr(sh), ptr(g), B, Hh, Hh, C_, None, None, None, dt, H.stream()), "pool_bwd")
     # g = grad wrt the BN output (pre-ReLU) = x.grad / scale
     assert H.rel(H.nchw(g) * scale[None, :, None, None], x.grad) < TOL[dt]
+    # with the fused BatchNorm-backward sums: same g, rows[r] sum to (sum g, sum g*xhat) of the stored g
+    mean, invstd = (torch.rand(C_) - 0.5).to(H.DEV), (0.5 + torch.rand(C_)).to(H.DEV)
+    nrows = lib.gdrn_maxpool_bwd_rows(B, Hh, Hh, C_, dt)
+    rows = torch.full((nrows, 2, C_), float("nan"), device=H.DEV)
+    g2 = torch.empty_like(xd)
+    check(lib.gdrn_maxpool_bwd(ptr(dyd), ptr(idx), ptr(xd), ptr(sc), ptr(sh), ptr(g2), B, Hh, Hh, C_, ptr(mean), ptr(invstd), ptr(rows), dt, H.stream()), "pool_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(g2, g)
+    gf, xf = g.float().view(-1, C_), xd.float().view(-1, C_)
+    tot = rows.sum(0)
+    assert H.rel(tot[0], gf.sum(0)) < 1e-4 and H.rel(tot[1], (gf * (xf - mean) * invstd).sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("dt", DTS)
