@@ -103,19 +103,21 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         STX(0, x0) STX(1, x1) STX(2, x2) STX(3, x3)                                                   \
     }
 
-    f32x4_t acc[9][2][2];
+    // wave tile: ALL 64 output channels (4 fragments) x 16 input channels (wave w: ci block w).  The X fragments are re-read for
+    // every tap (9 x 2 k-steps), the dY fragments once per k-step: a 64 x 16 wave tile needs 16 + 36 = 52 transposed LDS reads per
+    // stage where the 32 x 32 one needed 8 + 72 = 80, for the same 72 MFMAs
+    f32x4_t acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    (void)wa; (void)wb;
 
     // transpose-read lane bases.  k (pixel) map of one 32-pixel k-step (4 image rows x 8): read r of lane group g
     // covers pixels (row = 2r + (g>>1), col = (g&1)*4 + 0..3); lane q supplies pixel col + (q>>2), channels (q&3)*4..
     const int lpy = g >> 1, lpx = (g & 1) * 4 + (q >> 2);
-    const int baseA = (lpy * 8 + lpx) * PITCH + (wa * 32 + (q & 3) * 4) * 2;             // dY patch: 8 px per row
-    const int baseB = DYB + (lpy * 10 + lpx) * PITCH + (wb * 32 + (q & 3) * 4) * 2;      // X patch: 10 px per row
+    const int baseA = (lpy * 8 + lpx) * PITCH + ((q & 3) * 4) * 2;                         // dY patch: 8 px per row
+    const int baseB = DYB + (lpy * 10 + lpx) * PITCH + (wave * 16 + (q & 3) * 4) * 2;      // X patch: 10 px per row
 
     LOAD_PATCH(p_begin)
     WRITE_PATCH(0)
@@ -130,21 +132,16 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // dY fragments (A operand, i = co): rows (ks*4 + 2r + lpy) of the 8-wide patch
-            bf16x8_t fa[2];
+            bf16x8_t fa[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
                 fa[a] = tr_pair(sa + (ks * 4) * 8 * PITCH + a * 32, sa + (ks * 4 + 2) * 8 * PITCH + a * 32);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int sh = ((ks * 4 + t / 3) * 10 + (t % 3)) * PITCH;  // tap shift inside the 10-wide halo patch
-                bf16x8_t fb[2];
+                const bf16x8_t fb = tr_pair(sx + sh, sx + sh + 2 * 10 * PITCH);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) fb[b] = tr_pair(sx + sh + b * 32, sx + sh + 2 * 10 * PITCH + b * 32);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[t][a][b], 0, 0, 0);
+                for (int a = 0; a < 4; ++a) acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[t][a], 0, 0, 0);
             }
         }
         if (more) WRITE_PATCH(buf ^ 1)
@@ -156,28 +153,26 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #undef WRITE_PATCH
 
     if (p.ws != nullptr) {
-        float* wsb = p.ws + ((size_t)split * ntile + tile) * 36864 + (size_t)(wave * 64 + lane) * 4;
+        // workspace order (read by wgrad_reduce_multi): [36 fragments (t, a', b')][4 tile quadrants (wa', wb')][64 lanes][4] with the
+        // 16 x 16 block (co16 = wa'*2 + a', ci16 = wb'*2 + b'): this wave holds co16 = a (0..3), ci16 = wave
+        float* wsb = p.ws + ((size_t)split * ntile + tile) * 36864 + (size_t)lane * 4;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4_t*>(wsb + ((t * 2 + a) * 2 + b) * 1024) = acc[t][a][b];
+            for (int a = 0; a < 4; ++a)
+                *reinterpret_cast<f32x4_t*>(wsb + ((t * 2 + (a & 1)) * 2 + (wave & 1)) * 1024 + ((a >> 1) * 2 + (wave >> 1)) * 256) = acc[t][a];
         return;
     }
     // D[i = g*4 + j (co)][col = q (ci)]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + wa * 32 + a * 16 + g * 4 + j;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int ci = ci0 + wb * 32 + b * 16 + q;
-                    unsafeAtomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t][a][b][j]);
-                }
+                const int co = co0 + a * 16 + g * 4 + j;
+                const int ci = ci0 + wave * 16 + q;
+                unsafeAtomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t][a][j]);
             }
 }
 

@@ -69,6 +69,7 @@ class Engine:
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
+        self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
         nb = _os.environ.get("GDRN_BUCKETS")
         if nb is None:
@@ -545,7 +546,7 @@ class Plan:
     def _xf_ok(self, L, mode=None, hw=0):
         """can layer L's halo launches (forward and data gradient) take a fused operand transform (of that mode, on hw x hw maps)?"""
         e = self.e
-        if mode is not None and (not (e.xf_mask >> (mode - 1)) & 1 or hw > e.xf_maxhw):
+        if mode is not None and (not (e.xf_mask >> (mode - 1)) & 1 or hw > e.xf_maxhw or L.I < e.xf_minc):
             return False
         return e.fuse_xf and self.bn_train and L.kind == "conv" and L.wfF is not None and L.KK == 9 and not L.s2
 
