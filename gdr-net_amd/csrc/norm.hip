@@ -495,11 +495,27 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
         for (int j = 0; j < V; ++j) { pp[0][rl * CS + cv * V + j] = s1[j]; pp[1][rl * CS + cv * V + j] = s2[j]; }
     }
     __syncthreads();
-    for (int gi = threadIdx.x; gi < 2 * GS; gi += 256) {  // group sums: channels of the group x row lanes, fixed order, fp64
+    // fixed-order tree: 8 partial sums per (statistic, channel) over the row lanes, then per channel, then per group (fp64)
+    __shared__ double pc[2][64 * 8];
+    if (CS <= 64) {  // (the 32-channel slabs of the path; wider slabs take the one-level loop below)
+        for (int i = threadIdx.x; i < 2 * CS * 8; i += 256) {
+            const int st = i / (CS * 8), r8 = (i / CS) & 7, c = i % CS;
+            double t = 0.0;
+            for (int r = r8; r < rpp; r += 8) t += (double)pp[st][r * CS + c];
+            pc[st][r8 * CS + c] = t;
+        }
+    }
+    __syncthreads();
+    for (int gi = threadIdx.x; gi < 2 * GS; gi += 256) {
         const int st = gi / GS, gq = gi - st * GS;
         double t = 0.0;
-        for (int k = 0; k < cpg; ++k)
-            for (int r = 0; r < rpp; ++r) t += (double)pp[st][r * CS + gq * cpg + k];
+        for (int k = 0; k < cpg; ++k) {
+            if (CS <= 64) {
+                for (int r8 = 0; r8 < 8; ++r8) t += pc[st][r8 * CS + gq * cpg + k];
+            } else {
+                for (int r = 0; r < rpp; ++r) t += (double)pp[st][r * CS + gq * cpg + k];
+            }
+        }
         sg[gi] = t;
     }
     __syncthreads();
