@@ -69,7 +69,7 @@ class ZeroTask(C.Structure):
 
 
 class WreduceTask(C.Structure):
-    _fields_ = [("ws", P), ("dst", P), ("nsplit", I), ("Cout", I), ("Cin", I), ("pad_", I), ("s_co", LL), ("s_ci", LL), ("s_t", LL)]
+    _fields_ = [("ws", P), ("dst", P), ("nsplit", I), ("Cout", I), ("Cin", I), ("cin_valid", I), ("s_co", LL), ("s_ci", LL), ("s_t", LL)]
 
 
 class RangerTask(C.Structure):

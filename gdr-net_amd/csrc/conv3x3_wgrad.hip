@@ -1,5 +1,5 @@
-// Halo-tiled weight gradient of the 3x3 stride-1 pad-1 convolutions on MFMA for gfx950 (bf16 operands, fp32
-// accumulate):   dWp[co][tap][ci] += sum_{pixels} dY[pix][co] * X[pix + tap][ci]
+// Halo-tiled weight gradient of the 3x3 pad-1 convolutions (stride 1 and stride 2) on MFMA for gfx950 (bf16 operands, fp32
+// accumulate):   dWp[co][tap][ci] += sum_{pixels} dY[pix][co] * X[stride * pix + tap][ci]
 // (autograd backward-weight of the BasicBlock / head 3x3 convs, reference: engine.py:279).
 //
 // The generic kernel (conv_wgrad.hip) handles one tap per workgroup and re-reads dY and X once per tap.  Here a
@@ -24,8 +24,19 @@ namespace {
 
 typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 constexpr int PITCH = 160;               // bytes per LDS pixel row (64 ch * 2 B + 32 pad)
-constexpr int DYB = 64 * PITCH;          // dY patch: 8x8 pixels
-constexpr int XB = 100 * PITCH;          // X patch: 10x10 pixels
+// per-stage geometry.  Stride 1: an 8x8 patch of output pixels (two 32-pixel k-steps) against the 10x10 input halo patch.
+// Stride 2 (the three ResNet stage-entry convs, the three Patch-PnP convs, and the head's ConvTranspose with the roles of
+// input and output gradient swapped): a 4x8 patch of output pixels (one k-step) against the (2*4+1) x (2*8+1) = 9x17 input
+// patch -- 153 pixels, so the staging registers (5 + 1 instead of 4 + 2 uint4) and the LDS stage stay the size of the stride-1 case.
+template <int S> struct Geo;
+// XP = LDS pitch of an X-patch pixel: the 32 lanes a transposed read services together touch 8 pixels (4 per 16-lane group) x 8 bytes x
+// 4 channel quads; they must fall into 64 distinct banks.  Consecutive pixels (stride 1): 160 B = 40 banks -> 0, 40, 16, 56 (+32 for the
+// second group).  Every second pixel (stride 2): 2 * 144 B = 72 banks = 8 mod 64 -> 0, 8, ..., 56; with 160 B the two groups collide
+// (8 * 160 B = 0 mod 256 B): a 2-way conflict on every X read.
+template <> struct Geo<1> { static constexpr int TH = 8, KS = 2, PW = 10, PH = 10, NX = 4, ND = 2, XP = 160; };
+template <> struct Geo<2> { static constexpr int TH = 4, KS = 1, PW = 17, PH = 9, NX = 5, ND = 1, XP = 144; };
+constexpr int DYB = 64 * PITCH;          // dY patch: up to 8x8 pixels
+constexpr int XB = 153 * 144;            // X patch: 10x10 pixels x 160 B or 9x17 pixels x 144 B
 constexpr int STAGEB = DYB + XB;
 
 __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p0, const unsigned char* p1) {
@@ -41,7 +52,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // one workgroup: tile `bid % ntile`, pixel-range split `bid / ntile` of the layer described by p
+template <int S>
 __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, int npatch, int nsplit, unsigned char* smem) {
+    using G_ = Geo<S>;
+    constexpr int PW = G_::PW, NPIX = G_::PW * G_::PH, NSEG = NPIX * 8, XP = G_::XP;
+    static_assert(NPIX * XP <= XB, "X patch fits its LDS slot");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int g = lane >> 4, q = lane & 15;
@@ -52,24 +67,24 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     const int per = (npatch + nsplit - 1) / nsplit;
     const int p_begin = split * per, p_end = min(npatch, p_begin + per);
     if (p_begin >= p_end) return;
-    const int tiles_x = p.Wo >> 3, tiles_y = p.Ho >> 3;
+    const int tiles_x = p.Wo >> 3, tiles_y = p.Ho / G_::TH;
 
     // ---- staging geometry (constant per thread)
-    // dY: 64 px x 8 segs = 512 -> ids tid, tid+256 ; X: 100 px x 8 segs = 800 -> ids tid + 256*i, i < 4
+    // dY: TH*8 px x 8 segs -> ids tid (, tid+256) ; X: NPIX px x 8 segs -> ids tid + 256*i, i < NX
     const int dseg = tid & 7, dpix0 = tid >> 3;                       // pixels dpix0, dpix0 + 32
     const char* dyg = reinterpret_cast<const char*>(p.dy) + (size_t)co0 * 2 + dseg * 16;
     const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * 2;
 
-    uint4 d0, d1, x0, x1, x2, x3;
-    d0 = d1 = x0 = x1 = x2 = x3 = make_uint4(0, 0, 0, 0);
+    uint4 d0, d1, x0, x1, x2, x3, x4;
+    d0 = d1 = x0 = x1 = x2 = x3 = x4 = make_uint4(0, 0, 0, 0);
 
 #define LDX(i, dst)                                                                                   \
     {                                                                                                 \
         const int id_ = tid + 256 * (i);                                                              \
         const int pp_ = id_ >> 3, sg_ = id_ & 7;                                                      \
-        const int py_ = pp_ / 10, px_ = pp_ - py_ * 10;                                               \
-        const int iy_ = y0_ + py_ - 1, ix_ = x0_ + px_ - 1;                                           \
-        const bool ok_ = id_ < 800 && iy_ >= 0 && iy_ < p.Hi && ix_ >= 0 && ix_ < p.Wi;               \
+        const int py_ = pp_ / PW, px_ = pp_ - py_ * PW;                                               \
+        const int iy_ = S * y0_ + py_ - 1, ix_ = S * x0_ + px_ - 1;                                   \
+        const bool ok_ = id_ < NSEG && iy_ >= 0 && iy_ < p.Hi && ix_ >= 0 && ix_ < p.Wi;              \
         const int iyc_ = min(max(iy_, 0), p.Hi - 1), ixc_ = min(max(ix_, 0), p.Wi - 1);               \
         const uint4 v_ = *reinterpret_cast<const uint4*>(xg + ((size_t)((n_ * p.Hi + iyc_) * p.Wi + ixc_) * p.x_cs * 2 + sg_ * 16)); \
         dst = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                      \
@@ -80,27 +95,31 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         const int tx_ = t_ % tiles_x; t_ /= tiles_x;                                                  \
         const int ty_ = t_ % tiles_y;                                                                 \
         const int n_ = t_ / tiles_y;                                                                  \
-        const int y0_ = ty_ << 3, x0_ = tx_ << 3;                                                     \
+        const int y0_ = ty_ * G_::TH, x0_ = tx_ << 3;                                                 \
         {                                                                                             \
             const int pa_ = dpix0, pb_ = dpix0 + 32;                                                  \
             const size_t ra_ = (size_t)((n_ * p.Ho + y0_ + (pa_ >> 3)) * p.Wo + x0_ + (pa_ & 7));     \
-            const size_t rb_ = (size_t)((n_ * p.Ho + y0_ + (pb_ >> 3)) * p.Wo + x0_ + (pb_ & 7));     \
             d0 = *reinterpret_cast<const uint4*>(dyg + ra_ * p.dy_cs * 2);                            \
-            d1 = *reinterpret_cast<const uint4*>(dyg + rb_ * p.dy_cs * 2);                            \
+            if constexpr (G_::ND == 2) {                                                              \
+                const size_t rb_ = (size_t)((n_ * p.Ho + y0_ + (pb_ >> 3)) * p.Wo + x0_ + (pb_ & 7)); \
+                d1 = *reinterpret_cast<const uint4*>(dyg + rb_ * p.dy_cs * 2);                        \
+            }                                                                                         \
         }                                                                                             \
         LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)                                                   \
+        if constexpr (G_::NX == 5) LDX(4, x4)                                                         \
     }
 #define STX(i, src)                                                                                   \
     {                                                                                                 \
         const int id_ = tid + 256 * (i);                                                              \
-        if (id_ < 800) *reinterpret_cast<uint4*>(sb_ + DYB + (id_ >> 3) * PITCH + (id_ & 7) * 16) = src; \
+        if (id_ < NSEG) *reinterpret_cast<uint4*>(sb_ + DYB + (id_ >> 3) * XP + (id_ & 7) * 16) = src; \
     }
 #define WRITE_PATCH(buf)                                                                              \
     {                                                                                                 \
         unsigned char* sb_ = smem + (buf) * STAGEB;                                                   \
         *reinterpret_cast<uint4*>(sb_ + dpix0 * PITCH + dseg * 16) = d0;                              \
-        *reinterpret_cast<uint4*>(sb_ + (dpix0 + 32) * PITCH + dseg * 16) = d1;                       \
+        if constexpr (G_::ND == 2) *reinterpret_cast<uint4*>(sb_ + (dpix0 + 32) * PITCH + dseg * 16) = d1; \
         STX(0, x0) STX(1, x1) STX(2, x2) STX(3, x3)                                                   \
+        if constexpr (G_::NX == 5) STX(4, x4)                                                         \
     }
 
     // wave tile: ALL 64 output channels (4 fragments) x 16 input channels (wave w: ci block w).  The X fragments are re-read for
@@ -117,7 +136,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     // covers pixels (row = 2r + (g>>1), col = (g&1)*4 + 0..3); lane q supplies pixel col + (q>>2), channels (q&3)*4..
     const int lpy = g >> 1, lpx = (g & 1) * 4 + (q >> 2);
     const int baseA = (lpy * 8 + lpx) * PITCH + ((q & 3) * 4) * 2;                         // dY patch: 8 px per row
-    const int baseB = DYB + (lpy * 10 + lpx) * PITCH + (wave * 16 + (q & 3) * 4) * 2;      // X patch: 10 px per row
+    const int baseB = DYB + (S * lpy * PW + S * lpx) * XP + (wave * 16 + (q & 3) * 4) * 2;  // X patch: PW px per row, output pixel (y, x) at (S*y, S*x)
 
     LOAD_PATCH(p_begin)
     WRITE_PATCH(0)
@@ -130,7 +149,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         const unsigned char* sa = smem + buf * STAGEB + baseA;
         const unsigned char* sx = smem + buf * STAGEB + baseB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < G_::KS; ++ks) {
             // dY fragments (A operand, i = co): rows (ks*4 + 2r + lpy) of the 8-wide patch
             bf16x8_t fa[4];
 #pragma unroll
@@ -138,8 +157,8 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
                 fa[a] = tr_pair(sa + (ks * 4) * 8 * PITCH + a * 32, sa + (ks * 4 + 2) * 8 * PITCH + a * 32);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int sh = ((ks * 4 + t / 3) * 10 + (t % 3)) * PITCH;  // tap shift inside the 10-wide halo patch
-                const bf16x8_t fb = tr_pair(sx + sh, sx + sh + 2 * 10 * PITCH);
+                const int sh = ((S * ks * 4 + t / 3) * PW + (t % 3)) * XP;  // tap shift inside the PW-wide halo patch
+                const bf16x8_t fb = tr_pair(sx + sh, sx + sh + 2 * S * PW * XP);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[t][a], 0, 0, 0);
             }
@@ -176,9 +195,15 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
             }
 }
 
+// pixel patches of a layer: 8x8 output pixels per stage for stride 1, 4x8 for stride 2
+__host__ __device__ __forceinline__ int wgrad_npatch(const gdrn_wgrad_params& p) {
+    return (p.M / (p.Ho * p.Wo)) * (p.Ho / (p.stride == 2 ? 4 : 8)) * (p.Wo >> 3);
+}
+
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (dY patch | X patch)
-    wgrad_tile(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+    if (p.stride == 2) wgrad_tile<2>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+    else wgrad_tile<1>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
 }
 
 // Grouped launch: the weight gradients of several layers (one gradient bucket) in one grid.  Weight gradients are off
@@ -196,8 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const gdrn_
     }
     lo = __builtin_amdgcn_readfirstlane(lo);
     const gdrn_wgrad_params p = tasks[lo];
-    const int npatch = (p.M / (p.Ho * p.Wo)) * (p.Ho >> 3) * (p.Wo >> 3);
-    wgrad_tile(p, bid - blk_start[lo], npatch, p.splits, smem);
+    const int npatch = wgrad_npatch(p);
+    if (p.stride == 2) wgrad_tile<2>(p, bid - blk_start[lo], npatch, p.splits, smem);
+    else wgrad_tile<1>(p, bid - blk_start[lo], npatch, p.splits, smem);
 }
 
 // Sum the workspace partials of one 16(co) x 16(ci) x 9(tap) unit per workgroup and write it in the parameter's layout
@@ -239,9 +265,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wred
     }
     __syncthreads();
     const int co0 = (tile % ncot) * 64 + (wv >> 1) * 32 + a * 16, ci0 = (tile / ncot) * 64 + (wv & 1) * 32 + b * 16;
+    const int civ = k.cin_valid > 0 ? k.cin_valid : k.Cin;  // the operand's channels beyond the parameter's (zero padding) have no gradient slot
     for (int i = threadIdx.x; i < 2304; i += 256) {
         const int col = i / 144, r = i - col * 144, cil = r / 9, t = r - cil * 9;
-        k.dst[(long long)(co0 + col) * k.s_co + (long long)(ci0 + cil) * k.s_ci + (long long)t * k.s_t] = tile_s[i];
+        if (ci0 + cil < civ)
+            k.dst[(long long)(co0 + col) * k.s_co + (long long)(ci0 + cil) * k.s_ci + (long long)t * k.s_t] = tile_s[i];
     }
 }
 
@@ -250,9 +278,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wred
 // 1 if the shape is covered by the halo weight-gradient kernel
 extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
     if (!p) return 0;
-    return p->dtype == GDRN_DT_BF16 && p->KH == 3 && p->KW == 3 && p->stride == 1 && p->pad == 1 && p->Hi == p->Ho &&
-           p->Wi == p->Wo && (p->Ho % 8) == 0 && (p->Wo % 8) == 0 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
-           (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0;
+    if (!(p->dtype == GDRN_DT_BF16 && p->KH == 3 && p->KW == 3 && p->pad == 1 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
+          (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0 && (p->Wo % 8) == 0))
+        return 0;
+    if (p->stride == 1) return p->Hi == p->Ho && p->Wi == p->Wo && (p->Ho % 8) == 0;
+    if (p->stride == 2) return p->Hi == 2 * p->Ho && p->Wi == 2 * p->Wo && (p->Ho % 4) == 0;
+    return 0;
 }
 
 // number of pixel-range splits the launcher uses for these params (p->splits <= 0: automatic); the workspace of the
@@ -262,7 +293,7 @@ extern "C" int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* pp) {
     const gdrn_wgrad_params& p = *pp;
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw) return 0;
-    const int npatch = (p.M / hw) * (p.Ho / 8) * (p.Wo / 8);
+    const int npatch = wgrad_npatch(p);
     const int tiles = (p.Cout / 64) * (p.Cin / 64);
     int splits = p.splits;
     // one partial tile per workgroup either way: target one workgroup per CU (two when the partials are plain stores)
@@ -278,7 +309,7 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     const gdrn_wgrad_params& p = *pp;
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw) return GDRN_ERR_SHAPE;
-    const int npatch = (p.M / hw) * (p.Ho / 8) * (p.Wo / 8);
+    const int npatch = wgrad_npatch(p);
     const int tiles = (p.Cout / 64) * (p.Cin / 64);
     const int splits = gdrn_conv3x3_wgrad_splits(pp);
     if (splits <= 0) return GDRN_ERR_SHAPE;

@@ -453,7 +453,8 @@ class Plan:
         wp.M, wp.dtype, wp.splits, wp.variant = self.B * Ho * Wo, e.dt, 0, 0
         self.keep.append(wp)
         ref = C.byref(wp)
-        use_halo = e.use_halo and L.kind == "conv" and bool(e.lib.gdrn_conv3x3_wgrad_ok(ref))
+        # halo-tiled kernel: every 3x3 pad-1 conv, stride 1 or 2 (incl. Patch-PnP's and, roles swapped, the head's ConvTranspose)
+        use_halo = e.use_halo and L.kind in ("conv", "convT") and L.KK == 9 and bool(e.lib.gdrn_conv3x3_wgrad_ok(ref))
         fn = e.lib.gdrn_conv3x3_wgrad if use_halo else e.lib.gdrn_conv_wgrad
         if use_halo:
             # deferred: one grouped launch per gradient bucket (see _finish_unpack) -- weight gradients are off the
@@ -642,21 +643,25 @@ class Plan:
         for bkt, items in wg_bucket.items():
             if not items:
                 continue
+            # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
             geo = []
             for L, wp, flops in items:
-                npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // 8) * (wp.Wo // 8)
-                geo.append((npatch, (wp.Cout // 64) * (wp.Cin // 64)))
-            per = max(8, sum(n * t for n, t in geo) // e.wgrad_blocks)
+                s2 = wp.stride == 2
+                npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
+                geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // 64) * (wp.Cin // 64)))
+            per = max(16, sum(u * t for _, u, t in geo) // e.wgrad_blocks)   # k-steps per workgroup
             tasks = []
-            for (L, wp, flops), (npatch, tiles) in zip(items, geo):
+            for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
                 wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
-                wp.splits = max(1, npatch // per)
+                wp.splits = max(1, units // per)
                 wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
                 ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
                 self.keep.append(ws)
                 wp.ws, wp.dw = ptr(ws), None
-                self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin)
-                tasks.append((-(npatch // wp.splits), len(tasks), wp, tiles, flops))
+                # the kernel's "Cin" role = the parameter's input channels for a conv (69 real of 128 for Patch-PnP's first conv), its
+                # second dimension for the ConvTranspose (weight [Cin_w][Cout_w][3][3] with x = output gradient, dy = input)
+                self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin, L.O if L.kind == "convT" else L.I)
+                tasks.append((-(units // wp.splits), len(tasks), wp, tiles, flops))
             tasks.sort(key=lambda t: t[:2])
             starts = [0]
             for _, _, wp, tiles, _ in tasks:
@@ -678,10 +683,11 @@ class Plan:
         for gi, L in self._unpack_pending:
             bkt = bucket_of(gi)
             if L.key in self._wreduce:
-                ws, nsplit, cout, cin = self._wreduce[L.key]
-                assert (cout, cin) == (L.O, L.I)
+                ws, nsplit, cout, cin, civ = self._wreduce[L.key]
+                assert cout == (L.I if L.kind == "convT" else L.O) and civ <= cin, (L.key, cout, cin, civ)
+                assert e.grads[L.src[0]].numel() == cout * civ * 9, L.key
                 red_bucket[bkt].append(WreduceTask(ws=ws.data_ptr(), dst=e.grads[L.src[0]].data_ptr(), nsplit=nsplit, Cout=cout, Cin=cin,
-                                                   pad_=0, s_co=cin * 9, s_ci=9, s_t=1))
+                                                   cin_valid=civ, s_co=civ * 9, s_ci=9, s_t=1))
             elif L.key == "pnp_net.fc_rt":
                 per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr(), e.grads["pnp_net.fc_r.weight"], 6))
                 per_bucket[bkt].append(self._unpack_task(L, L.dwp.data_ptr() + 6 * L.in_ch * 4, e.grads["pnp_net.fc_t.weight"], 3))

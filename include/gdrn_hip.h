@@ -168,7 +168,9 @@ typedef struct gdrn_wgrad_params {
     int M, dtype, splits, variant;
 } gdrn_wgrad_params;
 int gdrn_conv_wgrad(const gdrn_wgrad_params* p, void* stream);
-/* Halo-tiled variant for KH=KW=3, stride 1, pad 1, bf16, H and W multiples of 8, Cin and Cout multiples of 64: a workgroup
+/* Halo-tiled variant for KH=KW=3, pad 1, bf16, Cin and Cout multiples of 64; stride 1 (Ho, Wo multiples of 8) or stride 2 (Hi = 2*Ho,
+ * Wi = 2*Wo, Ho a multiple of 4, Wo of 8: the ResNet stage-entry convs, Patch-PnP's convs, and ConvTranspose2d(3, 2, 1, 1) with x = the
+ * gradient of its output and dy = its input): a workgroup
  * accumulates a 64 x 64 (co x ci) tile of all nine taps from one staged 8x8 pixel patch per stage.  Same dw layout and
  * accumulate-with-atomics contract.  gdrn_conv3x3_wgrad_ok returns 1 when the shape is covered.
  * With p->ws != NULL the partial tiles of the gdrn_conv3x3_wgrad_splits(p) pixel-range splits are stored to
@@ -185,7 +187,7 @@ int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_
 typedef struct gdrn_wreduce_task {
     const float* ws;
     float* dst;
-    int nsplit, Cout, Cin, pad_;
+    int nsplit, Cout, Cin, cin_valid; /* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
     long long s_co, s_ci, s_t;
 } gdrn_wreduce_task;
 int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);

@@ -143,7 +143,7 @@ def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride,
         wp.ws, wp.dw = ptr(wsb), None
         check(lib.gdrn_conv3x3_wgrad(C.byref(wp), stream()), "conv3x3_wgrad(ws)")
         grad = torch.full((Cout, Cin, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
-        tab = to_device_table([WreduceTask(ws=ptr(wsb), dst=ptr(grad), nsplit=ns, Cout=Cout, Cin=Cin, pad_=0, s_co=Cin * 9, s_ci=9, s_t=1)], DEV)
+        tab = to_device_table([WreduceTask(ws=ptr(wsb), dst=ptr(grad), nsplit=ns, Cout=Cout, Cin=Cin, cin_valid=0, s_co=Cin * 9, s_ci=9, s_t=1)], DEV)
         stt = torch.tensor([0, Cout * Cin // 256], dtype=torch.int32, device=DEV)
         check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), 1, Cout * Cin // 256, stream()), "wgrad_reduce_multi")
         torch.cuda.synchronize()

@@ -239,6 +239,78 @@ def test_conv3x3_wgrad_halo_workspace(H, case, splits):
     assert H.rel(grad, w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("splits", [0, 1, 3])
+@pytest.mark.parametrize("ws", [False, True])
+@pytest.mark.parametrize("case", [(2, 64, 128, 16), (3, 128, 256, 8), (2, 256, 512, 4), (1, 128, 128, 32), (5, 64, 64, 12)])
+def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws):
+    """stride-2 3x3 weight gradient on the halo kernel (4x8 output-pixel stages against a 9x17 input patch): the ResNet stage-entry
+    convs / Patch-PnP convs, against autograd; atomics path and workspace + reduce path.  case = (B, Cin, Cout, Hout)."""
+    B, I, O, Ho = case
+    Hi = 2 * Ho
+    dt = BF16
+    x = H.rounded(H.randn(143, B, I, Hi, Hi), dt)
+    w = H.randn(144, O, I, 3, 3).requires_grad_(True)
+    dy = H.rounded(H.randn(145, B, O, Ho, Ho), dt)
+    F.conv2d(x, w, None, 2, 1).backward(dy)
+    if Ho % 4 or Ho % 8:  # Wo must be a multiple of 8, Ho of 4: other shapes stay on the generic kernel
+        wp = cabi.WgradParams()
+        wp.Hi = wp.Wi = Hi
+        wp.Ho = wp.Wo = Ho
+        wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype = I, O, I, O, 3, 3, 2, 1, B * Ho * Ho, dt
+        assert cabi.load().gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0
+        return
+    got = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hi, Hi, I, I, Ho, Ho, O, O, 3, 3, 2, 1, dt, splits=splits, halo=True, ws=ws)
+    if not ws:
+        got = got.view(O, 3, 3, I).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert H.rel(got, w.grad) < 1e-2
+
+
+def test_conv3x3_wgrad_halo_conv_transpose_and_padded_channels(H):
+    """(a) ConvTranspose2d(512 -> 256, 3, stride 2, pad 1, output_padding 1) weight gradient as a stride-2 conv weight gradient with
+    the roles swapped (x = gradient of the output, dy = the input), written straight into the (Cin, Cout, 3, 3) parameter layout;
+    (b) Patch-PnP's first conv: 69 real input channels in a 128-channel operand -- the reduce skips the padded channels."""
+    from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
+
+    lib, dev, dt = cabi.load(), H.DEV, BF16
+    # (a)
+    B, Ci, Co, Hin = 2, 128, 64, 8
+    xin = H.rounded(H.randn(150, B, Ci, Hin, Hin), dt)
+    w = H.randn(151, Ci, Co, 3, 3).requires_grad_(True)
+    gout = H.rounded(H.randn(152, B, Co, 2 * Hin, 2 * Hin), dt)
+    F.conv_transpose2d(xin, w, None, 2, 1, 1).backward(gout)
+    # (b)
+    B2, I2, O2, Ho2 = 2, 69, 128, 16
+    x2 = H.rounded(H.randn(153, B2, I2, 2 * Ho2, 2 * Ho2), dt)
+    w2 = H.randn(154, O2, I2, 3, 3).requires_grad_(True)
+    dy2 = H.rounded(H.randn(155, B2, O2, Ho2, Ho2), dt)
+    F.conv2d(x2, w2, None, 2, 1).backward(dy2)
+    jobs = [  # x (kernel input), dy, Hi, Ho, kernel Cin, kernel Cout, cin_valid, destination
+        (H.nhwc(gout, dt), H.nhwc(xin, dt), 2 * Hin, Hin, Co, Ci, Co, torch.full((Ci, Co, 3, 3), float("nan"), device=dev), B),
+        (H.nhwc(x2, dt, 128), H.nhwc(dy2, dt), 2 * Ho2, Ho2, 128, O2, I2, torch.full((O2, I2, 3, 3), float("nan"), device=dev), B2),
+    ]
+    keep = []
+    for xk, dyk, Hi, Ho, cin, cout, civ, dst, Bk in jobs:
+        wp = WgradParams()
+        wp.x, wp.dy = ptr(xk), ptr(dyk)
+        wp.Hi = wp.Wi = Hi
+        wp.Ho = wp.Wo = Ho
+        wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.splits = cin, cout, cin, cout, 3, 3, 2, 1, Bk * Ho * Ho, dt, 2
+        assert lib.gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 1
+        wp.ws = ptr(dst)
+        ns = lib.gdrn_conv3x3_wgrad_splits(C.byref(wp))
+        wsb = torch.full((ns * cout * cin * 9,), float("nan"), device=dev)
+        wp.ws, wp.dw = ptr(wsb), None
+        check(lib.gdrn_conv3x3_wgrad(C.byref(wp), H.stream()), "wgrad s2")
+        tab = to_device_table([WreduceTask(ws=ptr(wsb), dst=ptr(dst), nsplit=ns, Cout=cout, Cin=cin, cin_valid=civ, s_co=civ * 9, s_ci=9, s_t=1)], dev)
+        stt = torch.tensor([0, cout * cin // 256], dtype=torch.int32, device=dev)
+        check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), 1, cout * cin // 256, H.stream()), "reduce")
+        keep += [wsb, tab, stt]
+    torch.cuda.synchronize()
+    assert H.rel(jobs[0][7], w.grad) < 1e-2
+    assert torch.isfinite(jobs[1][7]).all() and H.rel(jobs[1][7], w2.grad) < 1e-2
+
+
 @pytest.mark.parametrize("mask_kind", ["stored", "affine", "none"])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8)])
 def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
@@ -409,7 +481,7 @@ def test_conv3x3_wgrad_grouped(H):
         keep += [xd, dyd, ws]
         grads.append(g)
         wps.append(wp)
-        tasks.append(WreduceTask(ws=ptr(ws), dst=ptr(g), nsplit=wp.splits, Cout=O, Cin=I, pad_=0, s_co=I * 9, s_ci=9, s_t=1))
+        tasks.append(WreduceTask(ws=ptr(ws), dst=ptr(g), nsplit=wp.splits, Cout=O, Cin=I, cin_valid=0, s_co=I * 9, s_ci=9, s_t=1))
     st1, st2 = [0], [0]
     for wp in wps:
         st1.append(st1[-1] + (wp.Cout // 64) * (wp.Cin // 64) * wp.splits)

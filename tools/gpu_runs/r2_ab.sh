@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r2_ab
 O=gpurun_out/r2_ab
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests -m gpu -q -x -k "wgrad or fused_batchnorm or vs_oracle" > $O/pytest_sel.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q -x -k "wgrad or fused_batchnorm or vs_oracle or baseline_sizes or train_step_vs_reference or checkpoint" > $O/pytest_sel.log 2>&1
 tail -5 $O/pytest_sel.log
 B="bench.py --no-cpu-baseline --no-roofline --no-extras --steps 40 --warmup 10"
 for r in 1 2 3; do
