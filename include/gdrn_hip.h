@@ -184,10 +184,11 @@ int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* p);
  * ws != NULL and splits = gdrn_conv3x3_wgrad_splits() of an explicit request (no empty split);
  * blk_start[i] = sum_{j<i} (Cout_j/64)*(Cin_j/64)*splits_j, nblocks = blk_start[ntasks]. */
 int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+/* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
 typedef struct gdrn_wreduce_task {
     const float* ws;
     float* dst;
-    int nsplit, Cout, Cin, cin_valid; /* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
+    int nsplit, Cout, Cin, cin_valid;
     long long s_co, s_ci, s_t;
 } gdrn_wreduce_task;
 int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
