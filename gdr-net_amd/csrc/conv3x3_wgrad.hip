@@ -72,8 +72,15 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     // ---- staging geometry (constant per thread)
     // dY: TH*8 px x 8 segs -> ids tid (, tid+256) ; X: NPIX px x 8 segs -> ids tid + 256*i, i < NX
     const int dseg = tid & 7, dpix0 = tid >> 3;                       // pixels dpix0, dpix0 + 32
-    const char* dyg = reinterpret_cast<const char*>(p.dy) + (size_t)co0 * 2 + dseg * 16;
-    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)ci0 * 2;
+    // global address space stated explicitly: in the grouped kernel the task's pointers come out of a table in memory, and hipcc then
+    // emits FLAT loads -- which count on lgkmcnt as well, so every LDS wait in the MFMA loop became lgkmcnt(0) and also waited for the
+    // next patch's global loads (the prefetch overlapped nothing)
+    typedef const __attribute__((address_space(1))) char* gptr_t;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4_t* gvec_t;
+#define GLD16(ptr_) __builtin_bit_cast(uint4, *(gvec_t)(ptr_))
+    const gptr_t dyg = (gptr_t)(reinterpret_cast<const char*>(p.dy) + (size_t)co0 * 2 + dseg * 16);
+    const gptr_t xg = (gptr_t)(reinterpret_cast<const char*>(p.x) + (size_t)ci0 * 2);
 
     uint4 d0, d1, x0, x1, x2, x3, x4;
     d0 = d1 = x0 = x1 = x2 = x3 = x4 = make_uint4(0, 0, 0, 0);
@@ -86,7 +93,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         const int iy_ = S * y0_ + py_ - 1, ix_ = S * x0_ + px_ - 1;                                   \
         const bool ok_ = id_ < NSEG && iy_ >= 0 && iy_ < p.Hi && ix_ >= 0 && ix_ < p.Wi;              \
         const int iyc_ = min(max(iy_, 0), p.Hi - 1), ixc_ = min(max(ix_, 0), p.Wi - 1);               \
-        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + ((size_t)((n_ * p.Hi + iyc_) * p.Wi + ixc_) * p.x_cs * 2 + sg_ * 16)); \
+        const uint4 v_ = GLD16(xg + ((size_t)((n_ * p.Hi + iyc_) * p.Wi + ixc_) * p.x_cs * 2 + sg_ * 16)); \
         dst = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                      \
     }
 #define LOAD_PATCH(pi)                                                                                \
@@ -99,10 +106,10 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         {                                                                                             \
             const int pa_ = dpix0, pb_ = dpix0 + 32;                                                  \
             const size_t ra_ = (size_t)((n_ * p.Ho + y0_ + (pa_ >> 3)) * p.Wo + x0_ + (pa_ & 7));     \
-            d0 = *reinterpret_cast<const uint4*>(dyg + ra_ * p.dy_cs * 2);                            \
+            d0 = GLD16(dyg + ra_ * p.dy_cs * 2);                                                      \
             if constexpr (G_::ND == 2) {                                                              \
                 const size_t rb_ = (size_t)((n_ * p.Ho + y0_ + (pb_ >> 3)) * p.Wo + x0_ + (pb_ & 7)); \
-                d1 = *reinterpret_cast<const uint4*>(dyg + rb_ * p.dy_cs * 2);                        \
+                d1 = GLD16(dyg + rb_ * p.dy_cs * 2);                                                  \
             }                                                                                         \
         }                                                                                             \
         LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)                                                   \
@@ -148,24 +155,37 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         if (more) LOAD_PATCH(pi + 1)
         const unsigned char* sa = smem + buf * STAGEB + baseA;
         const unsigned char* sx = smem + buf * STAGEB + baseB;
+        // One stage = J = 9 * KS tap groups of 4 MFMAs (k-step ks = j / 9, tap t = j % 9).  Software pipeline over the groups: the X
+        // fragment of group j + RD is read before the MFMAs of group j, the dY fragments of the second k-step one per group from
+        // group 9 - 4 - RD on, so every transposed read has RD groups (~70 cycles each) of MFMAs to land under; hipcc's own order issues
+        // the reads of a tap right before its MFMAs and waits out the LDS latency seven times per stage.
+        constexpr int J = 9 * G_::KS, RD = 3;
+        bf16x8_t fa[G_::KS][4], fb[RD + 1];
+#define FA_(ks_, a_) tr_pair(sa + ((ks_) * 4) * 8 * PITCH + (a_) * 32, sa + ((ks_) * 4 + 2) * 8 * PITCH + (a_) * 32)
+#define FB_(j_) tr_pair(sx + ((S * ((j_) / 9) * 4 + ((j_) % 9) / 3) * PW + (((j_) % 9) % 3)) * XP,                               \
+                        sx + ((S * ((j_) / 9) * 4 + ((j_) % 9) / 3) * PW + (((j_) % 9) % 3)) * XP + 2 * S * PW * XP)
 #pragma unroll
-        for (int ks = 0; ks < G_::KS; ++ks) {
-            // dY fragments (A operand, i = co): rows (ks*4 + 2r + lpy) of the 8-wide patch
-            bf16x8_t fa[4];
+        for (int a = 0; a < 4; ++a) fa[0][a] = FA_(0, a);
+#pragma unroll
+        for (int j = 0; j < RD; ++j) fb[j] = FB_(j);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (j + RD < J) fb[(j + RD) % (RD + 1)] = FB_(j + RD);
+            if constexpr (G_::KS == 2) {
+                if (j >= 9 - 4 - RD && j < 9 - RD) fa[1][j - (9 - 4 - RD)] = FA_(1, j - (9 - 4 - RD));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                fa[a] = tr_pair(sa + (ks * 4) * 8 * PITCH + a * 32, sa + (ks * 4 + 2) * 8 * PITCH + a * 32);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int sh = ((S * ks * 4 + t / 3) * PW + (t % 3)) * XP;  // tap shift inside the PW-wide halo patch
-                const bf16x8_t fb = tr_pair(sx + sh, sx + sh + 2 * S * PW * XP);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[t][a], 0, 0, 0);
-            }
+                acc[j % 9][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef FA_
+#undef FB_
         if (more) WRITE_PATCH(buf ^ 1)
         __syncthreads();
     }
+#undef GLD16
 #undef LDX
 #undef LOAD_PATCH
 #undef STX
