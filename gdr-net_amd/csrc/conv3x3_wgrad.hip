@@ -85,40 +85,45 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     uint4 d0, d1, x0, x1, x2, x3, x4;
     d0 = d1 = x0 = x1 = x2 = x3 = x4 = make_uint4(0, 0, 0, 0);
 
+    // The next patch's addresses are computed branch-free in pieces (the dY pair, one X slot each) that sit INSIDE the MFMA groups of
+    // the current stage, so their ~100 VALU instructions issue in the MFMAs' shadow; as a block in front of the MFMA loop they cost a
+    // wave ~1000 cycles per stage with the matrix pipe idle.  Out-of-image granules are loaded from a clamped address and zeroed at
+    // the LDS write (bit i of okm); the last stage re-loads its own patch (nothing is written from it).
+    unsigned cpp[G_::NX];  // X slot i of this thread: patch pixel row | column << 8
+#pragma unroll
+    for (int i = 0; i < G_::NX; ++i) {
+        const int pp_ = (tid + 256 * i) >> 3;
+        const int py_ = pp_ / PW;
+        cpp[i] = (unsigned)py_ | ((unsigned)(pp_ - py_ * PW) << 8);
+    }
+    const unsigned xrow = (unsigned)p.x_cs * 2u, drow = (unsigned)p.dy_cs * 2u;
+    unsigned okm = 0;
+    int pn_n, pn_y, pn_x;  // image / pixel-tile coordinates of the patch being fetched
+    {
+        int t_ = p_begin;
+        pn_x = t_ % tiles_x; t_ /= tiles_x;
+        pn_y = t_ % tiles_y;
+        pn_n = t_ / tiles_y;
+    }
+#define LDD()                                                                                         \
+    {                                                                                                 \
+        const int y0_ = pn_y * G_::TH, x0_ = pn_x << 3;                                               \
+        const unsigned ra_ = (unsigned)((pn_n * p.Ho + y0_ + (dpix0 >> 3)) * p.Wo + x0_ + (dpix0 & 7)); \
+        d0 = GLD16(dyg + ra_ * drow);                                                                 \
+        if constexpr (G_::ND == 2) d1 = GLD16(dyg + (ra_ + 4u * (unsigned)p.Wo) * drow);              \
+    }
 #define LDX(i, dst)                                                                                   \
     {                                                                                                 \
-        const int id_ = tid + 256 * (i);                                                              \
-        const int pp_ = id_ >> 3, sg_ = id_ & 7;                                                      \
-        const int py_ = pp_ / PW, px_ = pp_ - py_ * PW;                                               \
-        const int iy_ = S * y0_ + py_ - 1, ix_ = S * x0_ + px_ - 1;                                   \
-        const bool ok_ = id_ < NSEG && iy_ >= 0 && iy_ < p.Hi && ix_ >= 0 && ix_ < p.Wi;              \
+        const int iy_ = S * pn_y * G_::TH + (int)(cpp[i] & 255u) - 1, ix_ = S * (pn_x << 3) + (int)(cpp[i] >> 8) - 1; \
+        const bool ok_ = (unsigned)iy_ < (unsigned)p.Hi && (unsigned)ix_ < (unsigned)p.Wi;            \
         const int iyc_ = min(max(iy_, 0), p.Hi - 1), ixc_ = min(max(ix_, 0), p.Wi - 1);               \
-        const uint4 v_ = GLD16(xg + ((size_t)((n_ * p.Hi + iyc_) * p.Wi + ixc_) * p.x_cs * 2 + sg_ * 16)); \
-        dst = ok_ ? v_ : make_uint4(0, 0, 0, 0);                                                      \
-    }
-#define LOAD_PATCH(pi)                                                                                \
-    {                                                                                                 \
-        int t_ = (pi);                                                                                \
-        const int tx_ = t_ % tiles_x; t_ /= tiles_x;                                                  \
-        const int ty_ = t_ % tiles_y;                                                                 \
-        const int n_ = t_ / tiles_y;                                                                  \
-        const int y0_ = ty_ * G_::TH, x0_ = tx_ << 3;                                                 \
-        {                                                                                             \
-            const int pa_ = dpix0, pb_ = dpix0 + 32;                                                  \
-            const size_t ra_ = (size_t)((n_ * p.Ho + y0_ + (pa_ >> 3)) * p.Wo + x0_ + (pa_ & 7));     \
-            d0 = GLD16(dyg + ra_ * p.dy_cs * 2);                                                      \
-            if constexpr (G_::ND == 2) {                                                              \
-                const size_t rb_ = (size_t)((n_ * p.Ho + y0_ + (pb_ >> 3)) * p.Wo + x0_ + (pb_ & 7)); \
-                d1 = GLD16(dyg + rb_ * p.dy_cs * 2);                                                  \
-            }                                                                                         \
-        }                                                                                             \
-        LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)                                                   \
-        if constexpr (G_::NX == 5) LDX(4, x4)                                                         \
+        dst = GLD16(xg + ((unsigned)((pn_n * p.Hi + iyc_) * p.Wi + ixc_) * xrow + dseg * 16));        \
+        okm = (okm & ~(1u << (i))) | (ok_ ? (1u << (i)) : 0u);                                        \
     }
 #define STX(i, src)                                                                                   \
     {                                                                                                 \
         const int id_ = tid + 256 * (i);                                                              \
-        if (id_ < NSEG) *reinterpret_cast<uint4*>(sb_ + DYB + (id_ >> 3) * XP + (id_ & 7) * 16) = src; \
+        if (id_ < NSEG) *reinterpret_cast<uint4*>(sb_ + DYB + (id_ >> 3) * XP + (id_ & 7) * 16) = ((okm >> (i)) & 1u) ? src : make_uint4(0, 0, 0, 0); \
     }
 #define WRITE_PATCH(buf)                                                                              \
     {                                                                                                 \
@@ -145,14 +150,20 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     const int baseA = (lpy * 8 + lpx) * PITCH + ((q & 3) * 4) * 2;                         // dY patch: 8 px per row
     const int baseB = DYB + (S * lpy * PW + S * lpx) * XP + (wave * 16 + (q & 3) * 4) * 2;  // X patch: PW px per row, output pixel (y, x) at (S*y, S*x)
 
-    LOAD_PATCH(p_begin)
+    LDD() LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)
+    if constexpr (G_::NX == 5) LDX(4, x4)
     WRITE_PATCH(0)
     __syncthreads();
 
     for (int pi = p_begin; pi < p_end; ++pi) {
         const int buf = (pi - p_begin) & 1;
         const bool more = pi + 1 < p_end;
-        if (more) LOAD_PATCH(pi + 1)
+        if (more) {  // uniform: advance to patch pi + 1
+            if (++pn_x == tiles_x) {
+                pn_x = 0;
+                if (++pn_y == tiles_y) { pn_y = 0; ++pn_n; }
+            }
+        }
         const unsigned char* sa = smem + buf * STAGEB + baseA;
         const unsigned char* sx = smem + buf * STAGEB + baseB;
         // One stage = J = 9 * KS tap groups of 4 MFMAs (k-step ks = j / 9, tap t = j % 9).  Software pipeline over the groups: the X
@@ -160,6 +171,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         // group 9 - 4 - RD on, so every transposed read has RD groups (~70 cycles each) of MFMAs to land under; hipcc's own order issues
         // the reads of a tap right before its MFMAs and waits out the LDS latency seven times per stage.
         constexpr int J = 9 * G_::KS, RD = 3;
+        constexpr int PSTEP = (G_::KS == 2) ? 2 : 1;  // address pieces go into groups 1, 1 + PSTEP, ...
         bf16x8_t fa[G_::KS][4], fb[RD + 1];
 #define FA_(ks_, a_) tr_pair(sa + ((ks_) * 4) * 8 * PITCH + (a_) * 32, sa + ((ks_) * 4 + 2) * 8 * PITCH + (a_) * 32)
 #define FB_(j_) tr_pair(sx + ((S * ((j_) / 9) * 4 + ((j_) % 9) / 3) * PW + (((j_) % 9) % 3)) * XP,                               \
@@ -178,6 +190,15 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 acc[j % 9][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a], 0, 0, 0);
+            // next patch: one address piece + its loads per group (same scheduling region as the MFMAs above)
+            if (j == 0) LDD()
+            if (j == 1) LDX(0, x0)
+            if (j == 1 + PSTEP) LDX(1, x1)
+            if (j == 1 + 2 * PSTEP) LDX(2, x2)
+            if (j == 1 + 3 * PSTEP) LDX(3, x3)
+            if constexpr (G_::NX == 5) {
+                if (j == 1 + 4 * PSTEP) LDX(4, x4)
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef FA_
@@ -185,9 +206,9 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         if (more) WRITE_PATCH(buf ^ 1)
         __syncthreads();
     }
+#undef LDD
 #undef GLD16
 #undef LDX
-#undef LOAD_PATCH
 #undef STX
 #undef WRITE_PATCH
 
