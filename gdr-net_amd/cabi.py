@@ -142,6 +142,7 @@ _SIGS = {
     "gdrn_leaky_bwd": [P, P, P, LL, I, P],
     "gdrn_bias_grad": [P, I, I, I, P, I, P],
     "gdrn_head_tail_fwd": [P, I, P, P, P, I, I, I, I, I, P],
+    "gdrn_head_tail_loss_fwd": [P, I, P, P, P, I, P, P, P, P, P, I, I, I, I, P],
     "gdrn_map_loss_fwd": [P, I, P, P, P, P, I, I, I, P, P],
     "gdrn_map_loss_finalize": [P, I, I, P, P],
     "gdrn_head_tail_bwd": [P, I, P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, P],

@@ -58,6 +58,110 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------ head tail fwd, nreg == 64
+// The shape the network uses (64 regions, 72-float head rows): lane q of a pixel's 16 lanes holds the FOUR consecutive classes 4q..4q+3
+// (one 16-byte load at float 4 + 4q; class 64 rides on lane 15), the softmax lands as one 4-channel store per lane, and in train mode
+// (LOSS) the same pass accumulates the map losses of gdrn_map_loss_fwd -- the logits are read once instead of twice and the two
+// kernels' ~40 scalar loads / stores per lane become ~8 wide ones.
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+template <typename T, bool LOSS>
+__global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __restrict__ head, int hs, const float* __restrict__ coord2d,
+                                                              const float* __restrict__ extents, T* __restrict__ pnp, int pcs,
+                                                              const float* __restrict__ gt_xyz, const float* __restrict__ mvis,
+                                                              const float* __restrict__ mtr, const long long* __restrict__ gt_region,
+                                                              double* acc, int N, int HW, int write_pad) {
+    __shared__ float red[6][16];
+    const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long long M = (long long)N * HW;
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long m = g0; m < M; m += ng) {
+        const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+        const float* h = head + m * hs;
+        float r[4];
+        load4<float>(h + 4 + 4 * q, r);                       // classes 4q .. 4q+3
+        const float r64 = (q == 15) ? h[68] : -INFINITY;      // class 64
+        // softmax over classes 1..64 (region[:, 1:])
+        float mx = fmaxf(fmaxf(q == 0 ? -INFINITY : r[0], r[1]), fmaxf(fmaxf(r[2], r[3]), r64));
+        mx = row16_max(mx);
+        float e[4], e64;
+        e[0] = (q == 0) ? 0.f : expf(r[0] - mx);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) e[j] = expf(r[j] - mx);
+        e64 = (q == 15) ? expf(r64 - mx) : 0.f;
+        const float inv = 1.f / row16_sum(e[0] + e[1] + e[2] + e[3] + e64);
+        T* o = pnp + m * pcs;
+        float v[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+        if (q == 0) v[0] = coord2d[((size_t)n * 2 + 1) * HW + pix];   // channel 4 = second roi_coord_2d channel
+        store4<T>(o + 4 + 4 * q, v);                                   // channels 4 + 4q .. 7 + 4q
+        if (q == 15) {
+            const float w[4] = {e64 * inv, 0.f, 0.f, 0.f};             // channel 68 = class 64, 69..71 pad
+            store4<T>(o + 68, w);
+        } else if (q == 14) {
+            const float w[4] = {(h[1] - 0.5f) * extents[n * 3 + 0], (h[2] - 0.5f) * extents[n * 3 + 1], (h[3] - 0.5f) * extents[n * 3 + 2],
+                                coord2d[((size_t)n * 2 + 0) * HW + pix]};
+            store4<T>(o, w);
+        }
+        if (write_pad) {
+            const float z[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 72 + 4 * q; c < pcs; c += 64) store4<T>(o + c, z);
+        }
+        if constexpr (LOSS) {
+            // cross entropy over the 65 classes of logits * visib (GDRN.py:392-400)
+            const float mv = mvis[m];
+            const int tgt = (int)(gt_region[m] * (long long)mv);
+            float z[4], zt = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z[j] = r[j] * mv;
+                if (4 * q + j == tgt) zt = z[j];
+            }
+            const float z64 = (q == 15) ? r64 * mv : -INFINITY;
+            if (q == 15 && tgt == 64) zt = z64;
+            float mz = fmaxf(fmaxf(z[0], z[1]), fmaxf(fmaxf(z[2], z[3]), z64));
+            mz = row16_max(mz);
+            float es = expf(z[0] - mz) + expf(z[1] - mz) + expf(z[2] - mz) + expf(z[3] - mz) + (q == 15 ? expf(z64 - mz) : 0.f);
+            es = row16_sum(es);
+            zt = row16_sum(zt);
+            if (q == 0) {
+                a[4] += (logf(es) + mz) - zt;
+                a[5] += mv;
+                a[3] += fabsf(h[0] - mtr[m]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a[c] += fabsf(h[1 + c] * mv - gt_xyz[((size_t)n * 3 + c) * HW + pix] * mv);
+            }
+        }
+    }
+    if constexpr (LOSS) {
+        if (q == 0)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[k][grp] = a[k];
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v += (double)red[threadIdx.x][i];
+            unsafeAtomicAdd(&acc[threadIdx.x], v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ map losses fwd
 __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restrict__ head, int hs,
                                                            const float* __restrict__ gt_xyz,
@@ -193,6 +297,80 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restr
             st1<T>(o + q, d);
         }
         for (int c = 4 + ncls + q; c < dcs; c += 16) st1<T>(o + c, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ head tail bwd, nreg == 64
+// same lane <-> class map as head_tail_fwd64_kernel: 16-byte logit loads, 4-channel loads of the softmax / its gradient, one
+// 4-channel store per lane.  write_pad = 0: channels >= 72 of d_head are the caller's (zero-filled once).
+template <typename T>
+__global__ __launch_bounds__(256) void head_tail_bwd64_kernel(const float* __restrict__ head, int hs, const T* __restrict__ pnp,
+                                                              const T* __restrict__ dpnp, int pcs, const float* __restrict__ extents,
+                                                              const float* __restrict__ gt_xyz, const float* __restrict__ mvis,
+                                                              const float* __restrict__ mtr, const long long* __restrict__ gt_region,
+                                                              const double* __restrict__ acc, const float* __restrict__ gw,
+                                                              T* __restrict__ dhead, int dcs, int N, int HW, int write_pad) {
+    const int q = threadIdx.x & 15;
+    const long long M = (long long)N * HW;
+    const long long g0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ng = ((long long)gridDim.x * blockDim.x) >> 4;
+    const float inv_den = (float)(1.0 / (acc[5] < 1.0 ? 1.0 : acc[5]));
+    const float inv_np = (float)(1.0 / (double)M);
+    const float gx[3] = {gw[0], gw[1], gw[2]};
+    const float gmask = gw[3], gce = gw[4];
+    for (long long m = g0; m < M; m += ng) {
+        const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+        const float* h = head + m * hs;
+        const float mv = mvis[m];
+        const int tgt = (int)(gt_region[m] * (long long)mv);
+        float r[4];
+        load4<float>(h + 4 + 4 * q, r);
+        // CE gradient: mv * (softmax(region*mv)_k - onehot_k) / den over the 65 classes
+        float z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = r[j] * mv;
+        const float z64 = (q == 15) ? h[68] * mv : -INFINITY;
+        float mz = fmaxf(fmaxf(z[0], z[1]), fmaxf(fmaxf(z[2], z[3]), z64));
+        mz = row16_max(mz);
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = expf(z[j] - mz);
+        const float e64 = (q == 15) ? expf(z64 - mz) : 0.f;
+        const float inv = 1.f / row16_sum(e[0] + e[1] + e[2] + e[3] + e64);
+        // attention softmax chain: region class k (>= 1) <- pnp channel 4 + k
+        float sk[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f}, s64 = 0.f, d64 = 0.f;
+        if (dpnp != nullptr) {
+            load4<T>(pnp + m * pcs + 4 + 4 * q, sk);
+            load4<T>(dpnp + m * pcs + 4 + 4 * q, dk);
+            if (q == 0) { sk[0] = 0.f; dk[0] = 0.f; }   // channel 4 is roi_coord_2d, not a class
+            if (q == 15) { s64 = ld1<T>(pnp + m * pcs + 68); d64 = ld1<T>(dpnp + m * pcs + 68); }
+        }
+        const float dot = row16_sum(sk[0] * dk[0] + sk[1] * dk[1] + sk[2] * dk[2] + sk[3] * dk[3] + s64 * d64);
+        T* o = dhead + m * dcs;
+        const float cs = gce * mv * inv_den;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = cs * (e[j] * inv - (tgt == 4 * q + j ? 1.f : 0.f)) + sk[j] * (dk[j] - dot);
+        store4<T>(o + 4 + 4 * q, v);
+        if (q == 15) {
+            const float w[4] = {cs * (e64 * inv - (tgt == 64 ? 1.f : 0.f)) + s64 * (d64 - dot), 0.f, 0.f, 0.f};
+            store4<T>(o + 68, w);
+        } else if (q == 14) {
+            float w[4];
+            w[0] = gmask * inv_np * sgn(h[0] - mtr[m]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gt = gt_xyz[((size_t)n * 3 + c) * HW + pix];
+                float d = gx[c] * mv * inv_den * sgn(h[1 + c] * mv - gt * mv);
+                if (dpnp != nullptr) d += ld1<T>(dpnp + m * pcs + c) * extents[n * 3 + c];
+                w[1 + c] = d;
+            }
+            store4<T>(o, w);
+        }
+        if (write_pad) {
+            const float zz[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 72 + 4 * q; c < dcs; c += 64) store4<T>(o + c, zz);
+        }
     }
 }
 
@@ -432,21 +610,56 @@ __global__ void combine3_kernel(const float* in, const float* w, float* out, int
 
 #define ST reinterpret_cast<hipStream_t>(stream)
 
-extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
-                                  int N, int HW, int nreg, int dtype, void* stream) {
-    if (!head || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0 || nreg < 1 || nreg > 64 || hs < nreg + 5 ||
-        pcs < nreg + 5)
-        return GDRN_ERR_ARG;
+namespace {
+// fast path of the head-tail kernels: 64 regions, rows of whole 4-element groups (16-byte head rows, 8-byte bf16 rows)
+inline bool ht64_ok(int nreg, int hs, int pcs) { return nreg == 64 && hs >= 72 && (hs & 3) == 0 && pcs >= 72 && (pcs & 3) == 0; }
+
+template <bool LOSS>
+int launch_ht_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs, const float* gt_xyz,
+                  const float* mv, const float* mt, const long long* greg, double* acc, int N, int HW, int nreg, int dtype, hipStream_t st) {
+    const int dt = dtype & 0xff, write_pad = (dtype & GDRN_PREZEROED) ? 0 : 1;
     const long long M = (long long)N * HW;
     const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
-    if (dtype == GDRN_DT_F32)
-        hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
-    else if (dtype == GDRN_DT_BF16)
-        hipLaunchKernelGGL(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
-    else
-        return GDRN_ERR_ARG;
+    if (ht64_ok(nreg, hs, pcs)) {
+        if (dt == GDRN_DT_F32)
+            hipLaunchKernelGGL((head_tail_fwd64_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs,
+                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad);
+        else
+            hipLaunchKernelGGL((head_tail_fwd64_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs,
+                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad);
+    } else {
+        if (dt == GDRN_DT_F32)
+            hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
+        else
+            hipLaunchKernelGGL(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
+        if (LOSS) {
+            const int lb = (int)std::min<long long>((M + 15) / 16, 2048);
+            hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(lb), dim3(256), 0, st, head, hs, gt_xyz, mv, mt, greg, N, HW, nreg, acc);
+        }
+    }
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
+}
+}  // namespace
+
+extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
+                                  int N, int HW, int nreg, int dtype, void* stream) {
+    const int dt = dtype & 0xff;
+    if (!head || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0 || nreg < 1 || nreg > 64 || hs < nreg + 5 ||
+        pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
+        return GDRN_ERR_ARG;
+    return launch_ht_fwd<false>(head, hs, coord2d, extents, pnp_in, pcs, nullptr, nullptr, nullptr, nullptr, nullptr, N, HW, nreg, dtype, ST);
+}
+
+extern "C" int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
+                                       const float* gt_xyz, const float* mask_visib, const float* mask_trunc, const long long* gt_region,
+                                       double* acc, int N, int HW, int nreg, int dtype, void* stream) {
+    const int dt = dtype & 0xff;
+    if (!head || !coord2d || !extents || !pnp_in || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || N <= 0 || HW <= 0 ||
+        nreg < 1 || nreg > 64 || hs < nreg + 5 || pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
+        return GDRN_ERR_ARG;
+    if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    return launch_ht_fwd<true>(head, hs, coord2d, extents, pnp_in, pcs, gt_xyz, mask_visib, mask_trunc, gt_region, acc, N, HW, nreg, dtype, ST);
 }
 
 extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
@@ -472,22 +685,31 @@ extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in,
                                   const float* extents, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
                                   const long long* gt_region, const double* acc, const float* gw, void* d_head, int dcs, int N,
                                   int HW, int nreg, int dtype, void* stream) {
+    const int dt = dtype & 0xff, write_pad = (dtype & GDRN_PREZEROED) ? 0 : 1;
     if (!head || !extents || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || !gw || !d_head || N <= 0 ||
-        HW <= 0 || nreg < 1 || nreg > 64 || dcs < nreg + 5)
+        HW <= 0 || nreg < 1 || nreg > 64 || dcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
         return GDRN_ERR_ARG;
     if (d_pnp_in != nullptr && pnp_in == nullptr) return GDRN_ERR_ARG;
     const long long M = (long long)N * HW;
     const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
-    if (dtype == GDRN_DT_F32)
-        hipLaunchKernelGGL(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
-                           (const float*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
-                           (float*)d_head, dcs, N, HW, nreg);
-    else if (dtype == GDRN_DT_BF16)
-        hipLaunchKernelGGL(head_tail_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in,
-                           (const bf16_t*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
-                           (bf16_t*)d_head, dcs, N, HW, nreg);
-    else
-        return GDRN_ERR_ARG;
+    const bool fast = ht64_ok(nreg, hs, dcs) && (d_pnp_in == nullptr || ht64_ok(nreg, hs, pcs));
+    if (dt == GDRN_DT_F32) {
+        if (fast)
+            hipLaunchKernelGGL(head_tail_bwd64_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in, (const float*)d_pnp_in, pcs,
+                               extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw, (float*)d_head, dcs, N, HW, write_pad);
+        else
+            hipLaunchKernelGGL(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
+                               (const float*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
+                               (float*)d_head, dcs, N, HW, nreg);
+    } else {
+        if (fast)
+            hipLaunchKernelGGL(head_tail_bwd64_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in, (const bf16_t*)d_pnp_in,
+                               pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw, (bf16_t*)d_head, dcs, N, HW, write_pad);
+        else
+            hipLaunchKernelGGL(head_tail_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in,
+                               (const bf16_t*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
+                               (bf16_t*)d_head, dcs, N, HW, nreg);
+    }
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -1011,20 +1011,27 @@ class Plan:
         bias_o = e.P[h + "23.bias"]
         op, _ = self._conv(LO, hx, 256, self.head_out, 64, 64, 64, 64, 1, 0, bias=bias_o, out_f32=1, y_cs=self.hs, cout=e.head_c)
         self.fwd.append(op)
-        self.pnp_in = E(M, 128)
-        self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"],
-                                                                     ptr(self.pnp_in), 128, B, 4096, nreg, e.dt, st), "head_tail_fwd"))
+        self.pnp_in = e._zeros(M, 128)   # channels >= 5 + nreg stay zero (PREZEROED: the kernels do not re-write the pad)
+        self.keep.append(self.pnp_in)
         if WL:
             self.acc = E(8, dtype=torch.float64)
             self.losses = e._zeros(8, dtype=F32t)
+            # head tail + map-loss sums in one pass over the logits (train mode)
+            self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_loss_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"], ptr(self.pnp_in), 128,
+                                                                              ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"], ctx["gt_region"], ptr(self.acc),
+                                                                              B, 4096, nreg, e.dt | PREZEROED, st), "head_tail_loss_fwd"))
+        else:
+            self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"],
+                                                                         ptr(self.pnp_in), 128, B, 4096, nreg, e.dt | PREZEROED, st), "head_tail_fwd"))
         if T:
-            self.d_head = E(M, 128)
+            self.d_head = e._zeros(M, 128)   # pad channels zero-filled once (PREZEROED)
+            self.keep.append(self.d_head)
             self.d_pnp_in = E(M, 128)
             self.gw = e._zeros(8, dtype=F32t)
             grp = [lambda st, ctx: check(lib.gdrn_head_tail_bwd(ptr(self.head_out), self.hs, ptr(self.pnp_in), ptr(self.d_pnp_in), 128,
                                                                 ctx["extents"], ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"],
                                                                 ctx["gt_region"], ptr(self.acc), ptr(self.gw), ptr(self.d_head), 128, B,
-                                                                4096, nreg, e.dt, st), "head_tail_bwd")]
+                                                                4096, nreg, e.dt | PREZEROED, st), "head_tail_bwd")]
             grp.append(self._wgrad(LO, hx, self.d_head, 64, 64, 64, 64, 1, 0, 256, e.head_c, 256, 128))
             grp.append(self._unpack(LO))
             gb = e.grads[h + "23.bias"]
@@ -1140,9 +1147,6 @@ class Plan:
 
         self.fwd.append(pose)
         if WL:
-            self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_fwd(ptr(self.head_out), self.hs, ctx["gt_xyz"], ctx["mask_visib"],
-                                                                        ctx["mask_trunc"], ctx["gt_region"], B, 4096, nreg, ptr(self.acc),
-                                                                        st), "map_loss_fwd"))
             self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize(ptr(self.acc), B, 4096, ptr(self.losses), st), "map_loss_finalize"))
 
     # ---- execution ---------------------------------------------------------------------------

@@ -282,6 +282,12 @@ int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db, int dtype
  * pnp_in: dtype [N*HW][pcs], channels (xyz(3), coord2d(2), softmax(nreg), zero pad). */
 int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
                        int N, int HW, int nreg, int dtype, void* stream);
+/* Train mode: gdrn_head_tail_fwd and gdrn_map_loss_fwd in ONE pass over the logits (acc as below, zeroed inside).
+ * dtype | GDRN_PREZEROED (here and in gdrn_head_tail_fwd / gdrn_head_tail_bwd): the channels >= 72 of the pcs / dcs wide rows are
+ * already zero and stay the caller's (the engine zero-fills its buffers once instead of re-writing 56 pad channels per pixel and step). */
+int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
+                            const float* gt_xyz, const float* mask_visib, const float* mask_trunc, const long long* gt_region,
+                            double* acc, int N, int HW, int nreg, int dtype, void* stream);
 /* Map losses (GDRN.py:345-400): acc[0..2] = sum|x*m-gt*m| per coordinate, acc[3] = sum|mask-trunc|,
  * acc[4] = CE_sum(region*m, gt_region*m), acc[5] = sum m  (acc: fp64 [8], zeroed inside). */
 int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,

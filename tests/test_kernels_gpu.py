@@ -727,6 +727,15 @@ def test_head_tail_and_map_losses(H, dt):
     check(lib.gdrn_map_loss_finalize(ptr(acc), B, HW, ptr(losses), st), "map_loss_finalize")
     ref = torch.stack([L[k] for k in ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region")]).detach()
     np.testing.assert_allclose(losses[:5].cpu().numpy(), ref.numpy(), rtol=2e-5)
+    # train-mode entry point: both of the above in one pass; with GDRN_PREZEROED the pad channels are left to the caller
+    pnp2 = torch.full((M, 128), 7.0, dtype=H.tdt(dt), device=dev)
+    acc2 = torch.full((8,), float("nan"), dtype=torch.float64, device=dev)
+    losses2 = torch.zeros(8, device=dev)
+    check(lib.gdrn_head_tail_loss_fwd(ptr(head_d), hs, ptr(c2d), ptr(ext), ptr(pnp2), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc2), B, HW,
+                                      nreg, dt | cabi.PREZEROED, st), "head_tail_loss_fwd")
+    check(lib.gdrn_map_loss_finalize(ptr(acc2), B, HW, ptr(losses2), st), "map_loss_finalize")
+    assert torch.equal(pnp2[:, :72], pnp[:, :72]) and float((pnp2[:, 72:].float() - 7.0).abs().max()) == 0.0
+    np.testing.assert_allclose(losses2[:5].cpu().numpy(), ref.numpy(), rtol=2e-5)
     dpn = torch.zeros(M, 128, dtype=H.tdt(dt), device=dev)
     dpn[:, :69] = d_pnp.permute(0, 2, 3, 1).reshape(M, 69).to(dev).to(H.tdt(dt))
     dh = torch.full((M, 128), float("nan"), dtype=H.tdt(dt), device=dev)
@@ -736,6 +745,50 @@ def test_head_tail_and_map_losses(H, dt):
     gotd = dh.float().cpu().view(B, 64, 64, 128)
     assert H.rel(gotd[..., :69].permute(0, 3, 1, 2), head.grad) < (1e-4 if dt == F32 else 2e-2)
     assert float(gotd[..., 69:].abs().max()) == 0.0
+    dh2 = torch.full((M, 128), 7.0, dtype=H.tdt(dt), device=dev)
+    check(lib.gdrn_head_tail_bwd(ptr(head_d), hs, ptr(pnp), ptr(dpn), 128, ptr(ext), ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc),
+                                 ptr(gw_d), ptr(dh2), 128, B, HW, nreg, dt | cabi.PREZEROED, st), "head_tail_bwd")
+    assert torch.equal(dh2[:, :72], dh[:, :72]) and float((dh2[:, 72:].float() - 7.0).abs().max()) == 0.0
+
+
+def test_head_tail_generic_region_count(H):
+    """a region count other than 64 takes the generic kernels (the 64-region fast path needs 72-float rows): same numbers as the fast
+    path gives when the 32 surplus classes carry -inf-like logits and are never the target."""
+    from gdrnet_amd import synth
+
+    lib = cabi.load()
+    dt = F32
+    B, HW, hs = 1, 4096, 72
+    M = B * HW
+    b = synth.make_batch(B, seed=3)
+    dev, st = H.DEV, H.stream()
+    f = lambda t: t.to(dev).float().contiguous()
+    c2d, ext, gxyz, mv, mt = f(b["roi_coord_2d"]), f(b["roi_extent"]), f(b["roi_xyz"]), f(b["roi_mask_visib"]), f(b["roi_mask_trunc"])
+    greg = (b["roi_region"] % 33).to(dev).contiguous()
+    head = torch.zeros(M, hs, device=dev)
+    head[:, :37] = H.randn(5, M, 37).to(dev)
+    head64 = head.clone()
+    head64[:, 37:69] = -80.0          # classes 33..64: exp() == 0 next to the live ones
+    out = {}
+    for nreg, hd in ((32, head), (64, head64)):
+        pnp = torch.zeros(M, 128, device=dev)
+        acc = torch.zeros(8, dtype=torch.float64, device=dev)
+        check(lib.gdrn_head_tail_loss_fwd(ptr(hd), hs, ptr(c2d), ptr(ext), ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc), B, HW, nreg,
+                                          dt, st), "head_tail_loss_fwd")
+        dh = torch.zeros(M, 128, device=dev)
+        gw = torch.ones(5, device=dev)
+        dpn = (H.randn(6, M, 128) * 0.01).to(dev)
+        dpn[:, 37:] = 0
+        check(lib.gdrn_head_tail_bwd(ptr(hd), hs, ptr(pnp), ptr(dpn), 128, ptr(ext), ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc), ptr(gw), ptr(dh),
+                                     128, B, HW, nreg, dt, st), "head_tail_bwd")
+        torch.cuda.synchronize()
+        out[nreg] = (pnp.cpu(), acc.cpu(), dh.cpu())
+    # only where the mask is 1: a masked-out pixel's cross entropy is log(number of classes)
+    vis = (mv.view(-1) > 0).cpu()
+    assert float((out[32][0][:, :37] - out[64][0][:, :37]).abs().max()) < 1e-6
+    assert float(out[64][0][:, 37:69].abs().max()) < 1e-20
+    np.testing.assert_allclose(out[32][1][[0, 1, 2, 3, 5]].numpy(), out[64][1][[0, 1, 2, 3, 5]].numpy(), rtol=1e-6)
+    assert float((out[32][2][vis][:, :37] - out[64][2][vis][:, :37]).abs().max()) < 1e-6
 
 
 @pytest.mark.parametrize("rows,C_", [(1000, 64), (4096, 64), (513, 256), (130, 512), (64, 128)])
