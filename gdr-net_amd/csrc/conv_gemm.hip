@@ -293,6 +293,93 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const gdrn_conv_param
         const char* ab = reinterpret_cast<const char*>(p.addend);
         char* yb = reinterpret_cast<char*>(p.y);
         const unsigned cl = (unsigned)(co0 + wn * WN + g * 4);
+        if constexpr (sizeof(T) == 2) {
+            if (p.bnb_x != nullptr) {
+                // data gradient feeding a BatchNorm(+ReLU) backward (the 1x1 output conv, the stride-2 / transposed data gradients):
+                // ReLU mask + the BatchNorm backward's two per-channel sums on the accumulators, as the halo kernel's epilogue does
+                // (conv3x3_halo.hip) -- the separate gdrn_bn_bwd_reduce pass over (dy, x, mask) disappears
+                const char* xb = reinterpret_cast<const char*>(p.bnb_x);
+                const char* mb = reinterpret_cast<const char*>(p.bnb_mask);
+                const bool affine = mb == nullptr && p.bnb_scale != nullptr;
+                float kmu[FN][4], kis[FN][4], ksc[FN][4], ksh[FN][4], t1[FN][4], t2[FN][4];
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 16);
+                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 16);
+                    kmu[a][0] = mu.x; kmu[a][1] = mu.y; kmu[a][2] = mu.z; kmu[a][3] = mu.w;
+                    kis[a][0] = is.x; kis[a][1] = is.y; kis[a][2] = is.z; kis[a][3] = is.w;
+                    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(1.f, 1.f, 1.f, 1.f);  // mask always true
+                    if (affine) {
+                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 16);
+                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 16);
+                    }
+                    ksc[a][0] = sc.x; ksc[a][1] = sc.y; ksc[a][2] = sc.z; ksc[a][3] = sc.w;
+                    ksh[a][0] = sh.x; ksh[a][1] = sh.y; ksh[a][2] = sh.z; ksh[a][3] = sh.w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t1[a][j] = 0.f; t2[a][j] = 0.f; }
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int r = row0 + wm * WM + b * 16 + r16;
+                    if (r >= Mrows) continue;
+                    unsigned orow;
+                    if (p.mode == 1) {
+                        const int n = r / (Hc * Wc);
+                        const int rem = r - n * (Hc * Wc);
+                        const int yc = rem / Wc, xc = rem - yc * Wc;
+                        orow = (unsigned)((n * p.Ho + 2 * yc + py) * p.Wo + 2 * xc + px);
+                    } else {
+                        orow = (unsigned)r;
+                    }
+                    uint2 xq[FN], aq[FN], mq[FN];
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        xq[a] = *reinterpret_cast<const uint2*>(xb + (orow * (unsigned)p.bnb_cs + cl + a * 16) * 2u);
+                        aq[a] = ab != nullptr ? *reinterpret_cast<const uint2*>(ab + (orow * (unsigned)p.add_cs + cl + a * 16) * 2u) : make_uint2(0u, 0u);
+                        mq[a] = mb != nullptr ? *reinterpret_cast<const uint2*>(mb + (orow * (unsigned)p.bnb_cs + cl + a * 16) * 2u)
+                                              : make_uint2(0x3f803f80u, 0x3f803f80u);
+                    }
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        const float xv[4] = {__uint_as_float(xq[a].x << 16), __uint_as_float(xq[a].x & 0xffff0000u),
+                                             __uint_as_float(xq[a].y << 16), __uint_as_float(xq[a].y & 0xffff0000u)};
+                        const float mv[4] = {__uint_as_float(mq[a].x << 16), __uint_as_float(mq[a].x & 0xffff0000u),
+                                             __uint_as_float(mq[a].y << 16), __uint_as_float(mq[a].y & 0xffff0000u)};
+                        const float ad[4] = {__uint_as_float(aq[a].x << 16), __uint_as_float(aq[a].x & 0xffff0000u),
+                                             __uint_as_float(aq[a].y << 16), __uint_as_float(aq[a].y & 0xffff0000u)};
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool keep = (mv[j] > 0.f) && (xv[j] * ksc[a][j] + ksh[a][j] > 0.f);
+                            const float gv = keep ? acc[a][b][j] + ad[j] : 0.f;
+                            v[j] = gv;
+                            t1[a][j] += gv;
+                            t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
+                        }
+                        *reinterpret_cast<uint2*>(yb + (orow * (unsigned)p.y_cs + cl + a * 16) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+                }
+                // one row of the two sums per pixel tile (the two pixel halves of the tile are added through LDS in a fixed order)
+                float* red = reinterpret_cast<float*>(smem + 512);  // [2 (wm)][BN][2]
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u1 = row16_sum(t1[a][j]), u2 = row16_sum(t2[a][j]);
+                        if (r16 == 0) {
+                            const int c = wn * WN + a * 16 + g * 4 + j;
+                            red[(wm * BN + c) * 2 + 0] = u1;
+                            red[(wm * BN + c) * 2 + 1] = u2;
+                        }
+                    }
+                __syncthreads();
+                if (tid < BN) {
+                    p.bnb_rows[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+                    p.bnb_rows[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int r = row0 + wm * WM + b * 16 + r16;
@@ -429,6 +516,12 @@ extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
     int bm, bn;
     gdrn_conv_tile(pp, &bm, &bn);
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
+    if (p.bnb_x) {  // fused BatchNorm-backward statistics: the straight-line bf16 epilogue only
+        if (p.dtype != GDRN_DT_BF16 || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (p.bias || p.act || p.out_f32 || p.stats || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
+        const unsigned long long rows_out = (p.mode == 1) ? 4ull * (unsigned long long)p.M : (unsigned long long)p.M;
+        if (rows_out * (unsigned long long)std::max(std::max(p.y_cs, p.add_cs), p.bnb_cs) * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (p.dtype == GDRN_DT_BF16) {
         if (bn == 64) return bm == 128 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 64, 64>(p, st);

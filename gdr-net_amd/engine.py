@@ -67,6 +67,8 @@ class Engine:
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
         self.fuse_xf = self.use_halo and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
+        # BatchNorm-backward mask + sums also in the generic kernel's epilogue (1x1 output conv, stride-2 / transposed data gradients)
+        self.gemm_bnb = dtype == "bf16" and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
@@ -387,7 +389,7 @@ class Plan:
         elif use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
         if bnb is not None:
-            assert use_halo, L.key
+            assert use_halo or e.gemm_bnb, L.key
             bkey, braw, bmask, baffine = bnb
             sb = self.bn[bkey]
             cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(braw), ptr(bmask), braw.shape[-1]
@@ -873,7 +875,8 @@ class Plan:
                     # d_out comes from the next block's conv1 data gradient when that is a plain (stride-1) block of the
                     # same layer: its halo epilogue has then already applied this block's output ReLU mask and reduced
                     # the bn2-backward sums (and d_out itself is the residual-path gradient g2)
-                    pre2 = (b + 1 < nb) and self._fusable(e.layers[f"backbone.layer{li}.{b + 1}.conv1"])
+                    # ... or, for the last block of a layer, the generic kernel's epilogue (next layer's stride-2 conv1 / the head's ConvTranspose)
+                    pre2 = self._fusable(e.layers[f"backbone.layer{li}.{b + 1}.conv1"]) if b + 1 < nb else e.gemm_bnb
                     # BatchNorm-backward apply passes fused into the data-gradient conv that consumes their result (xf modes 3 / 4)
                     xfb2 = pre2 and self._xf_ok(L2, 3, Ho)
                     need_dx = d_x is not None
@@ -908,8 +911,10 @@ class Plan:
                         grp.append(self._unpack(Ld))
                         op, _ = self._conv(Ld, d_rawd, pl, d_xd, Ho, Ho, Hc, Hc, 2, 0, mode=1, w=Ld.wd, rows=Ld.rows_d, cin=Ld.cin_d, cout=inpl)
                         grp.append(op)
+                        # d_x = gradient w.r.t. the previous layer's last block output (mask = x): its bn2 backward is reduced here
                         op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 2, 1, mode=1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d,
-                                           cout=inpl, addend=d_xd, add_cs=inpl)
+                                           cout=inpl, addend=d_xd, add_cs=inpl,
+                                           bnb=(f"backbone.layer{li - 1}.{RESNET34_LAYERS[li - 2] - 1}.bn2", prev_raw2, x, False) if e.gemm_bnb else None)
                         grp.append(op)
                     elif need_dx:
                         # previous block of the same layer: d_x is the gradient w.r.t. its output (mask = x, stored) and
@@ -943,7 +948,8 @@ class Plan:
             # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
             grp.append(self._wgrad(LT, d_rawt, feat, 16, 16, 8, 8, 2, 1, 256, 512, 256, 512))
             grp.append(self._unpack(LT))
-            op, _ = self._conv(LT, d_rawt, 256, d_feat, 16, 16, 8, 8, 2, 1, mode=0, w=LT.wd, rows=LT.rows_d, cin=256, cout=512)
+            op, _ = self._conv(LT, d_rawt, 256, d_feat, 16, 16, 8, 8, 2, 1, mode=0, w=LT.wd, rows=LT.rows_d, cin=256, cout=512,
+                               bnb=("backbone.layer4.2.bn2", prev_raw2, feat, False) if e.gemm_bnb else None)
             grp.append(op)
             self.bwd_groups.append(grp)
         hx, d_hx, Hh = h0, (d_h0 if T else None), 16
@@ -983,7 +989,7 @@ class Plan:
                 self.tensors.update({h + f"{ci}.d_act": d_act, h + f"{ci}.d_raw": d_raw})
                 # d_act is produced by the NEXT head conv's data gradient; when no upsampling sits in between, that
                 # launch masks it and reduces this BN's backward sums
-                pre = nxt is not None and not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])
+                pre = (not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])) if nxt is not None else e.gemm_bnb  # (last conv: the 1x1 output conv's data gradient)
                 xfb = self._xf_ok(Lc, 3 if pre else 4, Hh)  # this BN's backward apply inside Lc's data-gradient launch (mode 3, or 4 = with the ReLU mask)
                 xd = None
                 if xfb:
@@ -1037,7 +1043,8 @@ class Plan:
             gb = e.grads[h + "23.bias"]
             self._zero_regions.append(self._grad16(gb))
             grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad"))
-            op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256)
+            op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256,
+                               bnb=(prev_bn, prev_raw, None, True) if e.gemm_bnb else None)
             grp.append(op)
             self.bwd_groups.append(grp)
 

@@ -79,7 +79,7 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
               out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None):
-    """bnb (halo only): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
+    """bnb (halo and generic kernel, bf16): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
     the second return value is then the [tiles][2][Cout] rows buffer.
     xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging."""
     lib = cabi.load()
@@ -106,7 +106,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
         cp.stats = ptr(stats)
     if bnb is not None:
-        nrows = lib.gdrn_conv3x3_stats_rows(C.byref(cp))
+        nrows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
         rows_t = torch.full((nrows, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
         cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(bnb["x"]), ptr(bnb.get("mask")), bnb["x"].shape[-1]
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))

@@ -328,7 +328,7 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
         assert eng.fuse_xf == (fx == "1")
         plan = eng.plan(B, True, True)
         n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith("conv3x3_halo") and not op.meta["kernel"].endswith(",0>"))
-        assert n_xf == (63 if fx == "1" else 0), n_xf
+        assert n_xf == (67 if fx == "1" else 0), n_xf
         res[fx] = (losses.cpu(), {k: v.float().cpu().clone() for k, v in plan.tensors.items()}, {n: g.cpu().clone() for n, g in eng.grads.items()},
                    plan.head_out.cpu().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
     l0, t0, g0, h0, r0 = res["0"]

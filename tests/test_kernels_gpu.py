@@ -347,6 +347,60 @@ def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
     assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
 
 
+@pytest.mark.parametrize("kind", ["out1x1", "s2_dgrad", "convT_dgrad"])
+def test_conv_gemm_fused_bn_backward_stats(H, kind):
+    """the same fused BatchNorm(+ReLU)-backward epilogue on the generic kernel, for the data gradients that do not run on the halo
+    kernel: the 1x1 output conv (affine mask), a stride-2 conv's transposed gather with an addend (stored mask, all four parity
+    classes), the ConvTranspose's stride-2 gather (stored mask).  Reference: autograd data gradient -> mask -> the two sums."""
+    dt, dev = BF16, H.DEV
+    d = lambda t: t.to(dev)
+    if kind == "out1x1":      # y = conv1x1(x): dgrad = dy (N) x W^T, C = 256 channels of the BatchNorm in front
+        B, Cb, O, Hh, k, stride, pad = 2, 256, 128, 32, 1, 1, 0
+    elif kind == "s2_dgrad":  # y = conv3x3 s2 (x), C = 64
+        B, Cb, O, Hh, k, stride, pad = 2, 64, 128, 32, 3, 2, 1
+    else:                     # y = conv3x3 s2 seen from the ConvTranspose side: its data gradient is a plain stride-2 conv of d_y
+        B, Cb, O, Hh, k, stride, pad = 2, 128, 64, 16, 3, 2, 1
+    gen = lambda sd, *sh: H.rounded(H.randn(sd, *sh), dt)
+    bx = H.rounded(H.randn(193, B, Cb, Hh, Hh) * 1.5 + 0.3, dt)
+    mean, invstd = H.randn(194, Cb) * 0.2, torch.rand(Cb, generator=torch.Generator().manual_seed(195)) + 0.5
+    scale, shift = torch.rand(Cb, generator=torch.Generator().manual_seed(196)) + 0.5, H.randn(197, Cb) * 0.3
+    ystored = H.rounded(F.relu(bx * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + H.randn(198, B, Cb, Hh, Hh)), dt)
+    bnb = dict(x=H.nhwc(bx, dt), mean=d(mean), invstd=d(invstd))
+    if kind == "convT_dgrad":
+        # forward y = convT(x_in [Cb ch, Hh]) -> [O, 2Hh]; data gradient g = conv3x3 s2 (dy) with the ConvTranspose weight [Cb][O][3][3]
+        w = H.rounded(H.randn(191, Cb, O, 3, 3) / math.sqrt(O * 9), dt)
+        dy = gen(190, B, O, 2 * Hh, 2 * Hh)
+        g = F.conv2d(dy, w, None, 2, 1)
+        wd = H.pack(w, Cb, 1, 9, O, Cb, 1, O, O * 9, 0, 1, 9, 0, dt).view(Cb, 9, O)   # rows = Cb (ConvT in channels), b = O
+        m = ystored > 0
+        bnb["mask"] = H.nhwc(ystored, dt)
+        y, sums = H.conv_gemm(H.nhwc(dy, dt), wd, B, 2 * Hh, 2 * Hh, O, O, Hh, Hh, Cb, 3, 3, 2, 1, dt, mode=0, bnb=bnb)
+    else:
+        w = H.rounded(H.randn(191, O, Cb, k, k) / math.sqrt(Cb * k * k), dt)
+        Ho = Hh // stride
+        dy = gen(190, B, O, Ho, Ho)
+        xin = torch.zeros(B, Cb, Hh, Hh, requires_grad=True)
+        F.conv2d(xin, w, None, stride, pad).backward(dy)
+        g = xin.grad
+        if kind == "out1x1":
+            m = (bx * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) > 0
+            bnb["scale"], bnb["shift"] = d(scale), d(shift)
+            y, sums = H.conv_gemm(H.nhwc(dy, dt), H.pack_dgrad(w, dt, 0), B, Ho, Ho, O, O, Hh, Hh, Cb, 1, 1, 1, 0, dt, mode=0, bnb=bnb)
+        else:
+            add = gen(192, B, Cb, Hh, Hh)
+            g = g + add
+            m = ystored > 0
+            bnb["mask"] = H.nhwc(ystored, dt)
+            y, sums = H.conv_gemm(H.nhwc(dy, dt), H.pack_dgrad(w, dt, 0), B, Ho, Ho, O, O, Hh, Hh, Cb, 3, 3, 2, 1, dt, mode=1, addend=H.nhwc(add, dt), bnb=bnb)
+    gm = g * m
+    xhat = (bx - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    ref1, ref2 = gm.sum((0, 2, 3)), (gm * xhat).sum((0, 2, 3))
+    assert H.rel(H.nchw(y, Cb), gm) < 1e-2
+    got = sums.sum(0).cpu()
+    assert torch.isfinite(got).all()
+    assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (1, 256, 256, 64), (2, 512, 512, 8)])
 def test_conv3x3_halo_operand_transform(H, case, mode):
