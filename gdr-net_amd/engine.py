@@ -72,7 +72,7 @@ class Engine:
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
-        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1024"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured best at two full rounds (1024), non-multiples of 512 lose a partial round
+        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1536"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step (non-multiples of 512 lose a partial round)
         nb = _os.environ.get("GDRN_BUCKETS")
         if nb is None:
             import torch.distributed as _dist
