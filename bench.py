@@ -144,9 +144,12 @@ def measure_roofline(model, plan, kctx, dtype):
             meta = getattr(op, "meta", None)
             if meta is not None:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                parts = getattr(op, "parts", None)  # conv launch + the BatchNorm-coefficient launch behind it: time the conv alone
                 a.record()
-                op(st, kctx)
+                (parts[0] if parts else op)(st, kctx)
                 b.record()
+                if parts:
+                    parts[1](st, kctx)
                 allev.append((a, b, meta))
             else:
                 op(st, kctx)
@@ -198,10 +201,22 @@ def measure_roofline(model, plan, kctx, dtype):
             traffic_src = "profiles/r02_hbm_traffic_bs64_bf16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)"
         else:
             traffic_src = "null: the committed PMC summary belongs to another build of the kernels"
+    # every conv / GEMM instantiation of the step, largest first (the dominant kernel above is row 0): the operand-transform variants of
+    # the halo kernel are separate instantiations, and the per-launch figure of one averages over feature maps from 8x8 to 64x64
+    table = []
+    for kname in sorted(per_k, key=per_k.get, reverse=True)[:8]:
+        kev = [x for x in allev if x[2]["kernel"] == kname]
+        kms = sum(max(a.elapsed_time(b) - ovh_ms, 1e-6) for a, b, _ in kev)
+        kfl = sum(m["flops"] for _, _, m in kev)
+        table.append({"kernel": kname, "launches_per_step": len(kev), "ms_per_step": round(kms, 3), "achieved": round(kfl / (kms * 1e-3) / 1e12, 1),
+                      "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 3)})
+    best = max(allev, key=lambda x: x[2]["flops"] / max(x[0].elapsed_time(x[1]) - ovh_ms, 1e-6))
     return {"bound": "mfma", "kernel": dom, "launches_per_step": len(ev), "avg_launch_us": round(tot_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_launch": round(flops / max(len(ev), 1) / 1e9, 3), "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "event_overhead_us": round(ovh_ms * 1e3, 2)}
+            "event_overhead_us": round(ovh_ms * 1e3, 2), "conv_kernels": table,
+            "best_launch": {"kernel": best[2]["kernel"], "layer": best[2]["layer"],
+                            "achieved": round(best[2]["flops"] / ((best[0].elapsed_time(best[1]) - ovh_ms) * 1e-3) / 1e12, 1)}}
 
 
 def roi_cropper_extras(B, dev, timed):
