@@ -19,15 +19,11 @@ bw0 = next(T(r) for r in step if name(r).startswith("zero_multi_kernel"))
 ends = [T(r) for r in step if name(r).startswith("wgrad_reduce_multi_kernel") or name(r).startswith("unpack_multi_kernel")]
 opt0 = next((int(r["Start_Timestamp"]) - t0) / 1e3 for r in step if name(r).startswith("ranger_multi_kernel"))
 end_step = T(step[-1])
-# bucket boundaries: pnp has only an unpack; head / layer4 / layer3 / rest end with a wgrad_reduce (after their unpack)
-marks = []
+# bucket boundaries: every bucket's last launch is its wgrad_reduce_multi (grouped weight gradients -> unpack -> reduce are appended in
+# that order to the group that completes the bucket; since the Patch-PnP convs run on the halo weight-gradient kernel, pnp has one too)
 names = [name(r) for r in step]
-for i, r in enumerate(step):
-    n = names[i]
-    if n.startswith("wgrad_reduce_multi_kernel"):
-        marks.append(T(r))
-pnp_end = next(T(r) for i, r in enumerate(step) if names[i].startswith("unpack_multi_kernel"))
-marks = [pnp_end] + marks
+marks = [T(r) for i, r in enumerate(step) if names[i].startswith("wgrad_reduce_multi_kernel")]
+assert len(marks) == 5, "expected the 5-bucket layout (GDRN_BUCKETS=5): %d reduce launches" % len(marks)
 sizes_mb = {"pnp": 36.1, "head": 19.0, "layer4": 52.4, "layer3": 27.3, "rest": 5.4}
 print("one training step (us from its first kernel): backward starts %.0f, optimizer starts %.0f, step ends %.0f" % (bw0, opt0, end_step))
 for (k, mb), t in zip(sizes_mb.items(), marks):
