@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_pa
                         }
                     }
                 }
-                // per-tile partial rows with plain stores (as the forward statistics); gdrn_bn_fold_rows folds them into the
-                // GDRN_BN_SUM_COPIES layout bn_bwd_apply reads.  (Atomics from every workgroup onto 16 x 2C addresses
+                // per-tile partial rows with plain stores (as the forward statistics); gdrn_bn_bwd_coef adds them up in a fixed order
+                // and turns them into the backward's coefficients.  (Atomics from every workgroup onto 16 x 2C addresses
                 // cost 25-55 us per launch on the large maps -- same-address atomics run at a few G/s.)
                 float* srow = p.bnb_rows + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void bn_finalize_rows_kernel(const float* __re
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
 }
 
-// BatchNorm-backward sums (per-tile rows of the fused data-gradient epilogue, or the GDRN_BN_SUM_COPIES rows of
+// BatchNorm-backward sums (per-tile rows of the fused data-gradient epilogue, or the per-workgroup rows of
 // gdrn_bn_bwd_reduce) -> the per-channel coefficients of dx = a*g + (b*x + c) (bn_bwd_apply_kernel's prologue arithmetic),
 // dgamma / dbeta: what a consumer that applies the BatchNorm backward while staging its operand needs.
 __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ rows, int nrows, int C, float inv_n,
