@@ -124,7 +124,7 @@ __device__ __forceinline__ uint4 xf_apply(uint4 v1, uint4 v2, const float* tab, 
 }
 
 template <typename T, int TH, int TW, int BN, int XF>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
+__global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
