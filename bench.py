@@ -179,7 +179,7 @@ def measure_roofline(model, plan, kctx, dtype):
     dom = max(per_k, key=per_k.get)
     ev = [x for x in allev if x[2]["kernel"] == dom]
     if os.environ.get("GDRN_LAYER_TABLE"):
-        rows = sorted(((a.elapsed_time(b) * 1e3, m) for a, b, m in allev), key=lambda r: -r[0])
+        rows = sorted(((max(a.elapsed_time(b) - ovh_ms, 1e-3) * 1e3, m) for a, b, m in allev), key=lambda r: -r[0])  # event overhead subtracted
         with open(os.environ["GDRN_LAYER_TABLE"], "w") as f:
             for us, m in rows:
                 f.write("%9.1f us %8.1f TF  %-40s %s\n" % (us, m["flops"] / us / 1e6, m["kernel"], m["layer"]))

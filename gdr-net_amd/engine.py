@@ -444,7 +444,7 @@ class Plan:
             macs = self.B * sp * L.O * L.I * L.KK
         dn = "bf16" if e.dt == BF16 else "f32"
         kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>" if use_halo else f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
-        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key)
+        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + (":dgrad" if w is not None else ""))
         return run, cp
 
     def _stats_rows(self, cp):
