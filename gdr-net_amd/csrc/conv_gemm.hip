@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
     // Fast path (full channel tile, storage-dtype output, no bias / activation; optional addend): straight-line stores
     // with 32-bit offsets.  The generic code below is ~2000-3500 instructions with 200-400 branches per wave, which
     // exceeds the MFMA loop of the short-K layers (1x1 convs, stride-2 convs of the small feature maps).
-    if (p.bias == nullptr && p.act == 0 && (!p.out_f32 || sizeof(T) == 4) && co0 + BN <= p.Cout) {
+    if (p.act <= 1 && (!p.out_f32 || sizeof(T) == 4) && co0 + BN <= p.Cout) {
         const char* ab = reinterpret_cast<const char*>(p.addend);
         char* yb = reinterpret_cast<char*>(p.y);
         const unsigned cl = (unsigned)(co0 + wn * WN + g * 4);
@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
             for (int a = 0; a < FN; ++a) {
                 float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
                 const unsigned c = cl + a * 16;
+                if (p.bias != nullptr) {  // eval mode: the folded BatchNorm shift
+                    const float4 bq = *reinterpret_cast<const float4*>(p.bias + c);
+                    v0 += bq.x; v1 += bq.y; v2 += bq.z; v3 += bq.w;
+                }
                 if (ab != nullptr) {
                     if constexpr (sizeof(T) == 2) {
                         const uint2 q = *reinterpret_cast<const uint2*>(ab + ((size_t)orow * p.add_cs + c) * 2);
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                         v0 += q.x; v1 += q.y; v2 += q.z; v3 += q.w;
                     }
                 }
+                if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(yb + ((size_t)orow * p.y_cs + c) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                 else *reinterpret_cast<float4*>(yb + ((size_t)orow * p.y_cs + c) * 4) = make_float4(v0, v1, v2, v3);
             }
