@@ -125,6 +125,18 @@ def param_schema(num_regions=64, pnp_in=69, rot_dim=6):
     return s
 
 
+def conditioned_state_dict(seed=0):
+    """make_state_dict with the last BatchNorm weight of every residual block scaled by 0.1 (the usual zero-gamma residual init).  The plain
+    synthetic init's BatchNorm-ReLU chain multiplies every perturbation by ~1.2 per layer (x700-1600 over the graph's 43 BatchNorms), so a
+    bf16-vs-fp32 comparison on it measures that chaos; with near-identity blocks the amplification is ~x80 and the arithmetic's own error
+    is what is left (tests/test_e2e_gpu.py::test_bf16_parity_on_a_conditioned_network, __graft_entry__.smoke)."""
+    sd = make_state_dict(seed)
+    for k in sd:
+        if k.startswith("backbone.layer") and k.endswith("bn2.weight"):
+            sd[k] = sd[k] * 0.1
+    return sd
+
+
 def make_state_dict(seed=0, as_torch=True):
     """Deterministic, well-conditioned weights keyed by the reference's state_dict names."""
     sd = OrderedDict()

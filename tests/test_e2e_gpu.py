@@ -703,15 +703,8 @@ def test_loss_kernels_replay_reference_golden_g4(golden_dir):
 
 
 def _conditioned_state_dict():
-    """synth weights with the last BatchNorm of every residual block scaled by 0.1 (the usual zero-gamma residual init): the
-    random-init BatchNorm-ReLU chain multiplies every perturbation by ~1.2 per layer (x700-1600 over the 43 BatchNorms of this graph:
-    fp32 rounding -> 1e-4 at the pose, test_fp32_*), which makes any bf16-vs-fp32 comparison a measurement of that chaos; with
-    near-identity blocks the amplification drops to ~x80 (fp32 vs fp64: 5e-6) and what is left is the arithmetic's own error."""
-    sd = synth.make_state_dict(0)
-    for k in sd:
-        if k.startswith("backbone.layer") and k.endswith("bn2.weight"):
-            sd[k] = sd[k] * 0.1
-    return sd
+    """see synth.conditioned_state_dict: near-identity residual blocks, amplification ~x80 instead of ~x1000."""
+    return synth.conditioned_state_dict(0)
 
 
 def test_bf16_parity_on_a_conditioned_network():
