@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ s
         const int kc = (int)(r % kch); r /= kch;
         const int tap = (int)(r % 9);
         const int cb = (int)(r / 9);
-        const int co = cb * 16 + (lane & 15), g = lane >> 4;
+        // row of block cb, fragment row r: the FNp blocks of a 16*FNp-row group interleave in units of 4 rows, so that the lane of an MFMA
+        // result that holds rows 4g..4g+3 of block a = 0 holds the NEXT four rows in block a = 1: 8 contiguous output channels per lane
+        // (one 16-byte access in the conv's epilogue instead of two 8-byte ones).  FNp = 1 for the 64-row operands (64-channel tile).
+        const int FNp = rows <= 64 ? 1 : 2, rr = lane & 15;
+        const int co = (cb / FNp) * 16 * FNp + (rr >> 2) * (4 * FNp) + (cb % FNp) * 4 + (rr & 3), g = lane >> 4;
         const size_t so = ((size_t)(co * 9 + tap) * Cin + (size_t)kc * EPS) + (size_t)(ks * 4 + g) * GE;
         *reinterpret_cast<uint4*>(dst + i * GE) = *reinterpret_cast<const uint4*>(src + so);
     }
@@ -340,14 +344,33 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #undef RP
 #undef RQ
 
-    // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + a*16 + g*4) of pixel b*16 + r16
+    // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + g*4*FN + a*4) of pixel b*16 + r16
     // Fast path for what the engine actually launches (full channel tiles, bf16 out, bias / ReLU / addend / statistics
     // optional): straight-line code, 32-bit offsets from uniform bases, DPP row sums.  The generic
     // epilogue below costs ~4600 instructions per wave (264 branches) -- more than the MFMA loop of a 256-channel
     // layer (3700) and 5x the loop of a 64-channel layer.
     if constexpr (sizeof(T) == 2) {
         if (p.act <= 1 && !p.out_f32 && (p.Cout % BN) == 0) {
-            const int cl = co0 + wave * (BN / 4) + g * 4;  // + a*16
+            const int cl = co0 + wave * (BN / 4) + g * (4 * FN);  // + a*4: the lane's 4*FN contiguous channels (row order of gdrn_pack_wfrag)
+            // one access per pixel for the lane's 4*FN contiguous channels: 16 bytes on the 128-channel tile (FN = 2), 8 on the 64-channel one
+            auto ld_ch = [&](const char* base, unsigned elem_off, uint2 (&dst)[FN]) {
+                if constexpr (FN == 2) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(base + elem_off * 2u);
+                    dst[0] = make_uint2(q.x, q.y);
+                    dst[1] = make_uint2(q.z, q.w);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) dst[a] = *reinterpret_cast<const uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u);
+                }
+            };
+            auto st_ch = [&](char* base, unsigned elem_off, const uint2 (&src)[FN]) {
+                if constexpr (FN == 2) {
+                    *reinterpret_cast<uint4*>(base + elem_off * 2u) = make_uint4(src[0].x, src[0].y, src[1].x, src[1].y);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) *reinterpret_cast<uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u) = src[a];
+                }
+            };
             if (p.stats != nullptr) {
                 float* srow = p.stats + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll
@@ -362,8 +385,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         s2[j] = row16_sum(q);
                     }
                     if (r16 == 0) {
-                        *reinterpret_cast<float4*>(srow + a * 16) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-                        *reinterpret_cast<float4*>(srow + p.Cout + a * 16) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
                     }
                 }
             }
@@ -381,14 +404,14 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                 float kmu[FN][4], kis[FN][4], ksc[FN][4], ksh[FN][4], t1[FN][4], t2[FN][4];
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
-                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 16);
-                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 16);
+                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 4);
+                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 4);
                     kmu[a][0] = mu.x; kmu[a][1] = mu.y; kmu[a][2] = mu.z; kmu[a][3] = mu.w;
                     kis[a][0] = is.x; kis[a][1] = is.y; kis[a][2] = is.z; kis[a][3] = is.w;
                     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(1.f, 1.f, 1.f, 1.f);  // mask always true
                     if (affine) {
-                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 16);
-                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 16);
+                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 4);
+                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 4);
                     }
                     ksc[a][0] = sc.x; ksc[a][1] = sc.y; ksc[a][2] = sc.z; ksc[a][3] = sc.w;
                     ksh[a][0] = sh.x; ksh[a][1] = sh.y; ksh[a][2] = sh.z; ksh[a][3] = sh.w;
@@ -406,9 +429,9 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                     for (int bb = 0; bb < HB_; ++bb) {
                         const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
+                        ld_ch(xb, pr * (unsigned)p.bnb_cs + (unsigned)cl, xq[bb]);
 #pragma unroll
                         for (int a = 0; a < FN; ++a) {
-                            xq[bb][a] = *reinterpret_cast<const uint2*>(xb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
                             av[bb][a] = make_uint2(0u, 0u);
                             mq[bb][a] = make_uint2(0x3f803f80u, 0x3f803f80u);
                         }
@@ -417,22 +440,21 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                         for (int bb = 0; bb < HB_; ++bb) {
                             const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
-#pragma unroll
-                            for (int a = 0; a < FN; ++a) av[bb][a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
+                            ld_ch(ab, pr * (unsigned)p.add_cs + (unsigned)cl, av[bb]);
                         }
                     }
                     if (mb != nullptr) {
 #pragma unroll
                         for (int bb = 0; bb < HB_; ++bb) {
                             const unsigned pr = (unsigned)(prow0 + (h * HB_ + bb) * pstep);
-#pragma unroll
-                            for (int a = 0; a < FN; ++a) mq[bb][a] = *reinterpret_cast<const uint2*>(mb + (pr * (unsigned)p.bnb_cs + (unsigned)(cl + a * 16)) * 2u);
+                            ld_ch(mb, pr * (unsigned)p.bnb_cs + (unsigned)cl, mq[bb]);
                         }
                     }
 #pragma unroll
                     for (int bb = 0; bb < HB_; ++bb) {
                         const int b = h * HB_ + bb;
                         const unsigned pr = (unsigned)(prow0 + b * pstep);
+                        uint2 ov[FN];
 #pragma unroll
                         for (int a = 0; a < FN; ++a) {
                             const uint2 xw = xq[bb][a], aw = av[bb][a], mw = mq[bb][a];
@@ -451,8 +473,9 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                                 t1[a][j] += gv;
                                 t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
                             }
-                            *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                            ov[a] = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                         }
+                        st_ch(yb, pr * (unsigned)p.y_cs + (unsigned)cl, ov);
                     }
                 }
                 // per-tile partial rows with plain stores (as the forward statistics); gdrn_bn_bwd_coef adds them up in a fixed order
@@ -465,8 +488,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { u1[j] = row16_sum(t1[a][j]); u2[j] = row16_sum(t2[a][j]); }
                     if (r16 == 0) {
-                        *reinterpret_cast<float4*>(srow + a * 16) = make_float4(u1[0], u1[1], u1[2], u1[3]);
-                        *reinterpret_cast<float4*>(srow + p.Cout + a * 16) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
                     }
                 }
                 return;
@@ -476,7 +499,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + cl + a * 16);
+                if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + cl + a * 4);
                 bq[a][0] = bv.x; bq[a][1] = bv.y; bq[a][2] = bv.z; bq[a][3] = bv.w;
             }
             const bool relu = p.act == 1;
@@ -485,31 +508,34 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
                     const unsigned pr = (unsigned)(prow0 + b * pstep);
-#pragma unroll
-                    for (int a = 0; a < FN; ++a) avq[b][a] = *reinterpret_cast<const uint2*>(ab + (pr * (unsigned)p.add_cs + (unsigned)(cl + a * 16)) * 2u);
+                    ld_ch(ab, pr * (unsigned)p.add_cs + (unsigned)cl, avq[b]);
                 }
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
                     const unsigned pr = (unsigned)(prow0 + b * pstep);
+                    uint2 ov[FN];
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         const uint2 av_ = avq[b][a];
                         float v0 = acc[a][b][0] + bq[a][0] + __uint_as_float(av_.x << 16), v1 = acc[a][b][1] + bq[a][1] + __uint_as_float(av_.x & 0xffff0000u);
                         float v2 = acc[a][b][2] + bq[a][2] + __uint_as_float(av_.y << 16), v3 = acc[a][b][3] + bq[a][3] + __uint_as_float(av_.y & 0xffff0000u);
                         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                        ov[a] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     }
+                    st_ch(yb, pr * (unsigned)p.y_cs + (unsigned)cl, ov);
                 }
             } else {
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
                     const unsigned pr = (unsigned)(prow0 + b * pstep);
+                    uint2 ov[FN];
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         float v0 = acc[a][b][0] + bq[a][0], v1 = acc[a][b][1] + bq[a][1], v2 = acc[a][b][2] + bq[a][2], v3 = acc[a][b][3] + bq[a][3];
                         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                        *reinterpret_cast<uint2*>(yb + (pr * (unsigned)p.y_cs + (unsigned)(cl + a * 16)) * 2u) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                        ov[a] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     }
+                    st_ch(yb, pr * (unsigned)p.y_cs + (unsigned)cl, ov);
                 }
             }
             return;
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                 for (int b = 0; b < FM; ++b) { const float v = acc[a][b][j]; s1 += v; s2 += v * v; }
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                const int c = co0 + wave * (BN / 4) + a * 16 + g * 4 + j;
+                const int c = co0 + wave * (BN / 4) + g * (4 * FN) + a * 4 + j;
                 if (r16 == 0 && c < p.Cout) {
                     p.stats[((size_t)mt * 2 + 0) * p.Cout + c] = s1;
                     p.stats[((size_t)mt * 2 + 1) * p.Cout + c] = s2;
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
         const size_t orow = (size_t)(n * p.Ho + y0 + m / TW) * p.Wo + x0 + (m % TW);
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
-            const int c0 = co0 + wave * (BN / 4) + a * 16 + g * 4;
+            const int c0 = co0 + wave * (BN / 4) + g * (4 * FN) + a * 4;
             if (c0 >= p.Cout) continue;
             float v[4];
 #pragma unroll
@@ -619,15 +645,9 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     *th = 8;
     *tw = (p->Wo % 16 == 0) ? 16 : 8;
     *bn = p->Cout <= 64 ? 64 : 128;
-    // (measured and rejected: 4x16-pixel tiles -- 164 VGPRs, three workgroups per CU -- are 4 % slower over the step;
-    //  the kernel wants reuse per staged patch, not occupancy)
-    // small feature maps: a 128-channel tiling leaves one workgroup (one wave per SIMD) per CU; halve the channel tile
-    // when that grid is below `min_wg` workgroups (measured: no gain at bs=64, so off unless GDRN_HALO_MIN_WG is set)
-    static const int min_wg = [] { const char* e = getenv("GDRN_HALO_MIN_WG"); return e ? atoi(e) : 0; }();
-    if (*bn == 128 && p->M > 0) {
-        const long long wg = (long long)(p->M / (*th * *tw)) * cdiv(p->Cout, 128);
-        if (wg < min_wg) *bn = 64;
-    }
+    // (measured and rejected: 4x16-pixel tiles -- 164 VGPRs, three workgroups per CU -- are 4 % slower over the step; 64-channel tiles
+    //  for the small grids of the 8x8 / 16x16 maps: +0.1 ms.  The channel tile is a function of Cout alone: gdrn_pack_wfrag's row
+    //  order depends on it.)
     return GDRN_OK;
 }
 
@@ -662,6 +682,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     gdrn_conv3x3_tile(pp, &th, &tw, &bn);
     if (th == 0) return GDRN_ERR_SHAPE;
     if (p.Cin <= 0 || (p.Cin * esz) % ROWB != 0 || (p.x_cs * esz) % 16 != 0 || p.Cout <= 0 || (p.y_cs & 3)) return GDRN_ERR_SHAPE;
+    if (bn == 128 && ((p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || (p.bnb_x && (p.bnb_cs & 7)))) return GDRN_ERR_SHAPE;  // 16-byte epilogue accesses
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;

@@ -40,29 +40,33 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             const int brick = blockIdx.x - blk_start[t];
             const int kch = k.B >> 6;
             const int cb = brick / kch, kc = brick - cb * kch;
-            const int a0 = cb * 16, b0 = kc * 64;
+            const int b0 = kc * 64;
+            // source row of block cb, fragment row a: gdrn_pack_wfrag's interleave (blocks of a 32-row group alternate in units of 4 rows
+            // for operands of more than 64 rows)
+            const int FNp = k.A1 <= 64 ? 1 : 2;
+            auto srow = [&](int a) { return (cb / FNp) * 16 * FNp + (a >> 2) * (4 * FNp) + (cb % FNp) * 4 + (a & 3); };
             __shared__ float rsc[16];              // optional per-row factor (eval mode: BatchNorm scale folded into the weights)
-            if (threadIdx.x < 16) rsc[threadIdx.x] = (k.scale != nullptr && a0 + (int)threadIdx.x < k.A1v) ? k.scale[a0 + threadIdx.x] : 1.f;
+            if (threadIdx.x < 16) rsc[threadIdx.x] = (k.scale != nullptr && srow((int)threadIdx.x) < k.A1v) ? k.scale[srow((int)threadIdx.x)] : 1.f;
             __syncthreads();
             if (k.st == 1 && k.sb == 9) {          // src[a1*s1 + b*9 + t]
                 for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
                     const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
-                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * 9 + tp] * rsc[a] : 0.f;
+                    const bool ok = srow(a) < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)srow(a) * k.s1 + (long long)(b0 + b) * 9 + tp] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             } else if (k.st == 1 && k.s1 == 9) {   // src[a1*9 + b*sb + t]
                 for (int idx = threadIdx.x; idx < 64 * 144; idx += 256) {
                     const int b = idx / 144, r = idx - b * 144, a = r / 9, tp = r - a * 9;
-                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * 9 + (long long)(b0 + b) * k.sb + tp] * rsc[a] : 0.f;
+                    const bool ok = srow(a) < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)srow(a) * 9 + (long long)(b0 + b) * k.sb + tp] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             } else {
                 for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
                     const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
-                    const bool ok = a0 + a < k.A1v && b0 + b < k.Bv;
-                    const float v = ok ? k.src[(long long)(a0 + a) * k.s1 + (long long)(b0 + b) * k.sb + (long long)tp * k.st] * rsc[a] : 0.f;
+                    const bool ok = srow(a) < k.A1v && b0 + b < k.Bv;
+                    const float v = ok ? k.src[(long long)srow(a) * k.s1 + (long long)(b0 + b) * k.sb + (long long)tp * k.st] * rsc[a] : 0.f;
                     tile[a][k.flip ? 8 - tp : tp][b] = f2bf(v);
                 }
             }
@@ -93,7 +97,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
                 if (k.pad_ > 0) { kc = r & (kch - 1u); r >>= (unsigned)(k.pad_ - 1); }  // kch = 2^(pad_-1): no 32-bit division
                 else { kc = r % kch; r /= kch; }
                 tt = r % 9u;
-                a1 = (r / 9u) * 16u + (lane & 15u);
+                {
+                    const unsigned cbq = r / 9u, rr = lane & 15u, fnp = k.A1 <= 64 ? 1u : 2u;
+                    a1 = (cbq / fnp) * 16u * fnp + (rr >> 2) * (4u * fnp) + (cbq % fnp) * 4u + (rr & 3u);
+                }
                 a2 = 0;
                 b0 = kc * EPS + (ks * 4u + (lane >> 4)) * GE;
             } else {
@@ -129,7 +136,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             const int kch = k.B / EPS;
             const int kc = (int)(r % kch); r /= kch;
             tt = (int)(r % 9);
-            a1 = (int)(r / 9) * 16 + (lane & 15);
+            {
+                const int cbq = (int)(r / 9), rr = lane & 15, fnp = k.A1 <= 64 ? 1 : 2;
+                a1 = (cbq / fnp) * 16 * fnp + (rr >> 2) * (4 * fnp) + (cbq % fnp) * 4 + (rr & 3);
+            }
             a2 = 0;
             b = kc * EPS + (ks * 4 + (lane >> 4)) * GE + el;
         } else {

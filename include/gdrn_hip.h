@@ -146,7 +146,9 @@ int gdrn_conv_stats_rows(const gdrn_conv_params* p);
  * gdrn_conv3x3_stats_rows the number of per-tile partial-statistics rows it writes. */
 /* p->w of gdrn_conv3x3_halo is the FRAGMENT-MAJOR operand: gdrn_pack_wfrag permutes the 16-byte granules of the
  * row-major [rows][9][Cin] operand into one contiguous 1 KiB block per (16 rows, tap, 128-byte chunk, k-step) =
- * exactly the 64 lanes of an MFMA A operand, so the kernel streams weights L2 -> registers without LDS. bf16 only. */
+ * exactly the 64 lanes of an MFMA A operand, so the kernel streams weights L2 -> registers without LDS. bf16 only.
+ * Row order: for operands of more than 64 rows (128-channel tile) the two 16-row blocks of a 32-row group interleave in units of
+ * 4 rows, so that an MFMA result lane holds 8 contiguous output channels and the conv's epilogue moves 16 bytes per access. */
 int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, void* stream);
 int gdrn_conv3x3_halo(const gdrn_conv_params* p, void* stream);
 int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
