@@ -140,14 +140,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
     const char* xg = reinterpret_cast<const char*>(p.x);
     const char* wg = reinterpret_cast<const char*>(p.w);
     // weight buffer is zero-padded to a multiple of BN rows
-    const unsigned wrow0 = (unsigned)(co0 + lrow) * (unsigned)(KK * p.Cin) * (unsigned)sizeof(T) + seg * 16;
-    const unsigned wstep = 32u * (unsigned)(KK * p.Cin) * (unsigned)sizeof(T);
+    // LDS row l of the weight tile holds the operand's row co0 + perm(l): inside a wave's WN rows the FN 16-row fragments interleave in
+    // units of 4 rows, so that an MFMA result lane (rows 4g..4g+3 of every fragment) owns 4*FN CONTIGUOUS output channels and the
+    // epilogue moves 16 bytes per access instead of 8 (the halo kernel gets the same order from gdrn_pack_wfrag)
+    unsigned wrow[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int l = lrow + 32 * i, lw = l % WN, a_ = lw / 16, r_ = lw % 16;
+        const int pr = (l / WN) * WN + (r_ >> 2) * (4 * FN) + a_ * 4 + (r_ & 3);
+        wrow[i] = (unsigned)(co0 + pr) * (unsigned)(KK * p.Cin) * (unsigned)sizeof(T) + seg * 16;
+    }
     const int HiM = p.Hi - 1, WiM = p.Wi - 1;
 
     // stage s <-> (channel chunk kc, valid-tap index ti): chunk outer, tap inner -- the taps of one
     // 128-byte channel chunk re-read the same few input rows back to back (L1/L2 hits).
     int n_kc = 0, n_ti = 0;  // coordinates of the NEXT stage to load
-#define GDRN_LDW(i, dst) dst = *reinterpret_cast<const uint4*>(wg + (wrow0 + (i) * wstep + wo_));
+#define GDRN_LDW(i, dst) dst = *reinterpret_cast<const uint4*>(wg + (wrow[i] + wo_));
 #define GDRN_LDX(i, dst)                                                                                       \
     {                                                                                                         \
         int iy_, ix_;                                                                                         \
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     s2 = row16_sum(s2);
                 }
                 if (r16 == 0) {
-                    const int c = wn * WN + a * 16 + g * 4 + j;
+                    const int c = wn * WN + g * (4 * FN) + a * 4 + j;
                     red[(wm * BN + c) * 2 + 0] = s1;
                     red[(wm * BN + c) * 2 + 1] = s2;
                 }
@@ -289,10 +297,35 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
     // Fast path (full channel tile, storage-dtype output, no bias / activation; optional addend): straight-line stores
     // with 32-bit offsets.  The generic code below is ~2000-3500 instructions with 200-400 branches per wave, which
     // exceeds the MFMA loop of the short-K layers (1x1 convs, stride-2 convs of the small feature maps).
-    if (p.act <= 1 && (!p.out_f32 || sizeof(T) == 4) && co0 + BN <= p.Cout) {
+    if (p.act <= 1 && (!p.out_f32 || sizeof(T) == 4) && co0 + BN <= p.Cout &&
+        (sizeof(T) == 4 || (((p.y_cs | p.add_cs | p.bnb_cs) & 7) == 0))) {   // bf16: rows of whole 16-byte groups
         const char* ab = reinterpret_cast<const char*>(p.addend);
         char* yb = reinterpret_cast<char*>(p.y);
-        const unsigned cl = (unsigned)(co0 + wn * WN + g * 4);
+        const unsigned cl = (unsigned)(co0 + wn * WN + g * (4 * FN));  // + a*4: the lane's 4*FN contiguous channels
+        // bf16: the lane's channels in 16-byte accesses (two fragments a = 2k, 2k + 1 per access)
+        auto ld_ch = [&](const char* base, unsigned elem_off, uint2 (&dst)[FN]) {
+            if constexpr ((FN & 1) == 0) {
+#pragma unroll
+                for (int k = 0; k < FN / 2; ++k) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(base + (elem_off + (unsigned)(k * 8)) * 2u);
+                    dst[2 * k] = make_uint2(q.x, q.y);
+                    dst[2 * k + 1] = make_uint2(q.z, q.w);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < FN; ++a) dst[a] = *reinterpret_cast<const uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u);
+            }
+        };
+        auto st_ch = [&](char* base, unsigned elem_off, const uint2 (&src)[FN]) {
+            if constexpr ((FN & 1) == 0) {
+#pragma unroll
+                for (int k = 0; k < FN / 2; ++k)
+                    *reinterpret_cast<uint4*>(base + (elem_off + (unsigned)(k * 8)) * 2u) = make_uint4(src[2 * k].x, src[2 * k].y, src[2 * k + 1].x, src[2 * k + 1].y);
+            } else {
+#pragma unroll
+                for (int a = 0; a < FN; ++a) *reinterpret_cast<uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u) = src[a];
+            }
+        };
         if constexpr (sizeof(T) == 2) {
             if (p.bnb_x != nullptr) {
                 // data gradient feeding a BatchNorm(+ReLU) backward (the 1x1 output conv, the stride-2 / transposed data gradients):
@@ -304,14 +337,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                 float kmu[FN][4], kis[FN][4], ksc[FN][4], ksh[FN][4], t1[FN][4], t2[FN][4];
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
-                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 16);
-                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 16);
+                    const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + a * 4);
+                    const float4 is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + a * 4);
                     kmu[a][0] = mu.x; kmu[a][1] = mu.y; kmu[a][2] = mu.z; kmu[a][3] = mu.w;
                     kis[a][0] = is.x; kis[a][1] = is.y; kis[a][2] = is.z; kis[a][3] = is.w;
                     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = make_float4(1.f, 1.f, 1.f, 1.f);  // mask always true
                     if (affine) {
-                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 16);
-                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 16);
+                        sc = *reinterpret_cast<const float4*>(p.bnb_scale + cl + a * 4);
+                        sh = *reinterpret_cast<const float4*>(p.bnb_shift + cl + a * 4);
                     }
                     ksc[a][0] = sc.x; ksc[a][1] = sc.y; ksc[a][2] = sc.z; ksc[a][3] = sc.w;
                     ksh[a][0] = sh.x; ksh[a][1] = sh.y; ksh[a][2] = sh.z; ksh[a][3] = sh.w;
@@ -331,14 +364,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     } else {
                         orow = (unsigned)r;
                     }
-                    uint2 xq[FN], aq[FN], mq[FN];
+                    uint2 xq[FN], aq[FN], mq[FN], ov[FN];
+                    ld_ch(xb, orow * (unsigned)p.bnb_cs + cl, xq);
 #pragma unroll
-                    for (int a = 0; a < FN; ++a) {
-                        xq[a] = *reinterpret_cast<const uint2*>(xb + (orow * (unsigned)p.bnb_cs + cl + a * 16) * 2u);
-                        aq[a] = ab != nullptr ? *reinterpret_cast<const uint2*>(ab + (orow * (unsigned)p.add_cs + cl + a * 16) * 2u) : make_uint2(0u, 0u);
-                        mq[a] = mb != nullptr ? *reinterpret_cast<const uint2*>(mb + (orow * (unsigned)p.bnb_cs + cl + a * 16) * 2u)
-                                              : make_uint2(0x3f803f80u, 0x3f803f80u);
-                    }
+                    for (int a = 0; a < FN; ++a) { aq[a] = make_uint2(0u, 0u); mq[a] = make_uint2(0x3f803f80u, 0x3f803f80u); }
+                    if (ab != nullptr) ld_ch(ab, orow * (unsigned)p.add_cs + cl, aq);
+                    if (mb != nullptr) ld_ch(mb, orow * (unsigned)p.bnb_cs + cl, mq);
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         const float xv[4] = {__uint_as_float(xq[a].x << 16), __uint_as_float(xq[a].x & 0xffff0000u),
@@ -356,8 +387,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                             t1[a][j] += gv;
                             t2[a][j] += gv * (xv[j] - kmu[a][j]) * kis[a][j];
                         }
-                        *reinterpret_cast<uint2*>(yb + (orow * (unsigned)p.y_cs + cl + a * 16) * 2u) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        ov[a] = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                     }
+                    st_ch(yb, orow * (unsigned)p.y_cs + cl, ov);
                 }
                 // one row of the two sums per pixel tile (the two pixel halves of the tile are added through LDS in a fixed order)
                 float* red = reinterpret_cast<float*>(smem + 512);  // [2 (wm)][BN][2]
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     for (int j = 0; j < 4; ++j) {
                         const float u1 = row16_sum(t1[a][j]), u2 = row16_sum(t2[a][j]);
                         if (r16 == 0) {
-                            const int c = wn * WN + a * 16 + g * 4 + j;
+                            const int c = wn * WN + g * (4 * FN) + a * 4 + j;
                             red[(wm * BN + c) * 2 + 0] = u1;
                             red[(wm * BN + c) * 2 + 1] = u2;
                         }
@@ -393,17 +425,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
             } else {
                 orow = (unsigned)r;
             }
+            uint2 aqb[FN], ovb[FN];
+            if constexpr (sizeof(T) == 2) {
+                if (ab != nullptr) ld_ch(ab, orow * (unsigned)p.add_cs + cl, aqb);
+            }
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 float v0 = acc[a][b][0], v1 = acc[a][b][1], v2 = acc[a][b][2], v3 = acc[a][b][3];
-                const unsigned c = cl + a * 16;
+                const unsigned c = cl + a * 4;
                 if (p.bias != nullptr) {  // eval mode: the folded BatchNorm shift
                     const float4 bq = *reinterpret_cast<const float4*>(p.bias + c);
                     v0 += bq.x; v1 += bq.y; v2 += bq.z; v3 += bq.w;
                 }
                 if (ab != nullptr) {
                     if constexpr (sizeof(T) == 2) {
-                        const uint2 q = *reinterpret_cast<const uint2*>(ab + ((size_t)orow * p.add_cs + c) * 2);
+                        const uint2 q = aqb[a];
                         v0 += __uint_as_float(q.x << 16); v1 += __uint_as_float(q.x & 0xffff0000u);
                         v2 += __uint_as_float(q.y << 16); v3 += __uint_as_float(q.y & 0xffff0000u);
                     } else {
@@ -412,9 +448,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     }
                 }
                 if (p.act == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(yb + ((size_t)orow * p.y_cs + c) * 2) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+                if constexpr (sizeof(T) == 2) ovb[a] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                 else *reinterpret_cast<float4*>(yb + ((size_t)orow * p.y_cs + c) * 4) = make_float4(v0, v1, v2, v3);
             }
+            if constexpr (sizeof(T) == 2) st_ch(yb, orow * (unsigned)p.y_cs + cl, ovb);
         }
         return;
     }
@@ -426,7 +463,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
             float* yf = reinterpret_cast<float*>(p.y);
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
-                const int c0 = co0 + wn * WN + a * 16 + g * 4;
+                const int c0 = co0 + wn * WN + g * (4 * FN) + a * 4;
                 if (c0 >= p.y_cs) continue;
                 float bq[4] = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias != nullptr) {
@@ -459,7 +496,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
         }
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
-            const int c0 = co0 + wn * WN + a * 16 + g * 4;
+            const int c0 = co0 + wn * WN + g * (4 * FN) + a * 4;
             if (c0 >= p.Cout) continue;
             float v[4];
 #pragma unroll
@@ -549,7 +586,8 @@ extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: the straight-line bf16 epilogue only
         if (p.dtype != GDRN_DT_BF16 || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
-        if (p.bias || p.act || p.out_f32 || p.stats || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
+        if (p.bias || p.act || p.out_f32 || p.stats || (p.Cout % bn) || (p.bnb_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || p.bnb_cs < p.Cout)
+            return GDRN_ERR_SHAPE;  // (rows of whole 16-byte groups: the epilogue's accesses)
         const unsigned long long rows_out = (p.mode == 1) ? 4ull * (unsigned long long)p.M : (unsigned long long)p.M;
         if (rows_out * (unsigned long long)std::max(std::max(p.y_cs, p.add_cs), p.bnb_cs) * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     }
