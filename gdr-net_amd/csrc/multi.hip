@@ -48,7 +48,33 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             __shared__ float rsc[16];              // optional per-row factor (eval mode: BatchNorm scale folded into the weights)
             if (threadIdx.x < 16) rsc[threadIdx.x] = (k.scale != nullptr && srow((int)threadIdx.x) < k.A1v) ? k.scale[srow((int)threadIdx.x)] : 1.f;
             __syncthreads();
-            if (k.st == 1 && k.sb == 9) {          // src[a1*s1 + b*9 + t]
+            // whole bricks of 16-byte-aligned operands: four source floats per load (the kernel waits on memory 80 % of its time: bytes in
+            // flight per thread are what it lacks)
+            const bool full = srow(15) < k.A1v && b0 + 63 < k.Bv && ((size_t)k.src & 15) == 0;
+            if (full && k.st == 1 && k.sb == 9 && (k.s1 & 3) == 0) {  // src[a1*s1 + b*9 + t]: rows of 576 contiguous floats
+                for (int q = threadIdx.x; q < 16 * 144; q += 256) {
+                    const int a = q / 144, r4 = (q - a * 144) * 4;
+                    const float4 v4 = *reinterpret_cast<const float4*>(k.src + (long long)srow(a) * k.s1 + (long long)b0 * 9 + r4);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r4 + e, b = r / 9, tp = r - b * 9;
+                        tile[a][k.flip ? 8 - tp : tp][b] = f2bf(vv[e] * rsc[a]);
+                    }
+                }
+            } else if (full && k.st == 1 && k.s1 == 9 && (k.sb & 3) == 0) {  // src[a1*9 + b*sb + t]: per b a run of 144 contiguous floats (rows srow(0..15) contiguous
+                                                          // only for the non-interleaved 64-row operands; else per 4-row group of 36 floats)
+                for (int q = threadIdx.x; q < 64 * 4 * 9; q += 256) {   // (b, 4-row group, 9 float4 of its 36 floats)
+                    const int b = q / 36, r = q - b * 36, grp = r / 9, f4 = r - grp * 9;
+                    const float4 v4 = *reinterpret_cast<const float4*>(k.src + (long long)srow(grp * 4) * 9 + (long long)(b0 + b) * k.sb + f4 * 4);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int w = f4 * 4 + e, al = w / 9, tp = w - al * 9, a = grp * 4 + al;
+                        tile[a][k.flip ? 8 - tp : tp][b] = f2bf(vv[e] * rsc[a]);
+                    }
+                }
+            } else if (k.st == 1 && k.sb == 9) {          // src[a1*s1 + b*9 + t]
                 for (int idx = threadIdx.x; idx < 16 * 576; idx += 256) {
                     const int a = idx / 576, r = idx - a * 576, b = r / 9, tp = r - b * 9;
                     const bool ok = srow(a) < k.A1v && b0 + b < k.Bv;
