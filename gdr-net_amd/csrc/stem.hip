@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) wq[t][ky] = *reinterpret_cast<const uint4*>(w32 + ((t * 16 + r16) * 7 + ky) * 32 + g * 8);
+        for (int ky = 0; ky < 7; ++ky)  // fragment t, row r16 <-> channel (r16 >> 2) * 16 + t * 4 + (r16 & 3): a result lane owns 16 contiguous channels
+            wq[t][ky] = *reinterpret_cast<const uint4*>(w32 + ((((r16 >> 2) * 16 + t * 4 + (r16 & 3)) * 7 + ky) * 32) + g * 8);
     float s1[4][4], s2[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -67,12 +68,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
             for (int t = 0; t < 4; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[t][ky]), __builtin_bit_cast(bf16x8_t, xq[ky]),
                                                                  acc[t], 0, 0, 0);
-        // D[i = g*4 + j (channel t*16 + i)][col = r16 (pixel)]: 4 consecutive channels of one pixel per lane
+        // D[i = g*4 + j][col = r16 (pixel)] of fragment t = channel g*16 + t*4 + j: 16 consecutive channels of one pixel per lane, two
+        // 16-byte stores (four 8-byte ones with the plain row order)
         const int seg = tile & 7, oy = (tile >> 3) & 127, n = tile >> 10;
-        bf16_t* yp = y + ((size_t)(n * 128 + oy) * 128 + seg * 16 + r16) * 64 + g * 4;
+        bf16_t* yp = y + ((size_t)(n * 128 + oy) * 128 + seg * 16 + r16) * 64 + g * 16;
+        *reinterpret_cast<uint4*>(yp) = make_uint4(pack_bf2(acc[0][0], acc[0][1]), pack_bf2(acc[0][2], acc[0][3]), pack_bf2(acc[1][0], acc[1][1]), pack_bf2(acc[1][2], acc[1][3]));
+        *reinterpret_cast<uint4*>(yp + 8) = make_uint4(pack_bf2(acc[2][0], acc[2][1]), pack_bf2(acc[2][2], acc[2][3]), pack_bf2(acc[3][0], acc[3][1]), pack_bf2(acc[3][2], acc[3][3]));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            *reinterpret_cast<uint2*>(yp + t * 16) = make_uint2(pack_bf2(acc[t][0], acc[t][1]), pack_bf2(acc[t][2], acc[t][3]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s1[t][j] += acc[t][j]; s2[t][j] += acc[t][j] * acc[t][j]; }
         }
@@ -80,15 +83,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
         for (int ky = 0; ky < 7; ++ky) xq[ky] = xn[ky];
     }
     if (stats != nullptr && t_begin < t_end) {  // one partial row per wave that had work: [gw][2][64]
-        float* row = stats + (size_t)gw * 128 + g * 4;
+        float* row = stats + (size_t)gw * 128 + g * 16;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float u1[4], u2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { u1[j] = row16_sum(s1[t][j]); u2[j] = row16_sum(s2[t][j]); }
             if (r16 == 0) {
-                *reinterpret_cast<float4*>(row + t * 16) = make_float4(u1[0], u1[1], u1[2], u1[3]);
-                *reinterpret_cast<float4*>(row + 64 + t * 16) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+                *reinterpret_cast<float4*>(row + t * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                *reinterpret_cast<float4*>(row + 64 + t * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
             }
         }
     }
