@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "lib", "libgdrn_hip.so")
-SOURCES = ["conv_gemm.hip", "conv3x3_halo.hip", "conv_wgrad.hip", "conv3x3_wgrad.hip", "norm.hip", "head_pose_loss.hip", "pack.hip", "multi.hip", "fc.hip", "postproc.hip", "stem.hip", "roi.hip", "workspace.hip"]
+SOURCES = ["conv_gemm.hip", "conv3x3_halo.hip", "conv3x3_v3.hip", "conv_wgrad.hip", "conv3x3_wgrad.hip", "norm.hip", "head_pose_loss.hip", "pack.hip", "multi.hip", "fc.hip", "postproc.hip", "stem.hip", "roi.hip", "workspace.hip"]
 
 
 def _hipcc():
@@ -21,7 +21,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "gdrn_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "halo_xf.h"), os.path.join(INCLUDE, "gdrn_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

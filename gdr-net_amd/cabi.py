@@ -26,7 +26,7 @@ class ConvParams(C.Structure):
     _fields_ = [
         ("x", P), ("w", P), ("y", P), ("bias", P), ("addend", P), ("stats", P),
         ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_scale", P), ("bnb_shift", P), ("bnb_rows", P),
-        ("bnb_cs", I), ("pad0_", I),
+        ("bnb_cs", I), ("w_frag", I),
         ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("add_cs", I),
         ("KH", I), ("KW", I), ("stride", I), ("pad", I),
@@ -108,6 +108,8 @@ _SIGS = {
     "gdrn_conv_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv_stats_rows": [C.POINTER(ConvParams)],
     "gdrn_pack_wfrag": [P, P, I, I, I, P],
+    "gdrn_pack_wfrag32": [P, P, I, I, I, P],
+    "gdrn_conv3x3_wfrag": [C.POINTER(ConvParams)],
     "gdrn_conv3x3_halo": [C.POINTER(ConvParams), P],
     "gdrn_conv3x3_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv3x3_stats_rows": [C.POINTER(ConvParams)],

@@ -10,13 +10,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-#define GDRN_OK 0
-#define GDRN_ERR_ARG (-1)
-#define GDRN_ERR_SHAPE (-2)
-#define GDRN_ERR_LAUNCH (-3)
-
-#define GDRN_DT_F32 0
-#define GDRN_DT_BF16 1
+#include "../../include/gdrn_hip.h"  // status codes (GDRN_OK, GDRN_ERR_*) and dtype selectors (GDRN_DT_*)
 
 #define GDRN_CHECK_LAUNCH()                                  \
     do {                                                     \

@@ -1,0 +1,641 @@
+// Halo-tiled 3x3 stride-1 pad-1 convolution, second generation ("v3"), for the layers with >= 128 channels: the BasicBlock convs of
+// ResNet-34's layer2..4 (resnet_backbone.py:69-80, torchvision BasicBlock) and the six 256->256 head convs
+// (cdpn_rot_head_region.py:103-123), forward and data gradient.  Same contract as conv3x3_halo.hip (gdrn_conv_params), selected by
+// p->w_frag == 2 (operand packed by gdrn_pack_wfrag32).
+//
+// What changed against the first halo kernel, and why (profiles/r02_*: that kernel ran 0.31-0.52 of the MFMA peak; its weight
+// stream L2 -> VGPR cost 28 %, the BatchNorm operand transform 40 % on the 64x64 maps, one wave per SIMD on the small maps):
+//   * v_mfma_f32_32x32x16_bf16 (micro-benchmark ceiling 2382 TF against 2075 TF of the 16x16x32 form), wave tile 128 channels x 64
+//     pixels (or 64 x 64): 0.75 (1.0) LDS fragment reads per MFMA of 32 cycles;
+//   * the weights stream global/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, inline asm: hipcc's waitcnt pass would drain every
+//     DMA in flight before the next ds_read of the array) into a 3-slot ring of 16 KiB units, one s_barrier per unit, shared by all
+//     waves of the workgroup -- no VGPR ring, no vmcnt stall in front of an MFMA.  Counted waits: s_waitcnt vmcnt(N) with N = the
+//     loads issued after the unit that must have landed (loads return in order);
+//   * the input patch goes global -> LDS raw staging (LDS-DMA too) -> VGPR -> operand transform -> padded patch image in LDS, one
+//     slice of 512 granules at a time, two units (>= 2000 cycles) after its DMA: HBM latency never meets an MFMA;
+//   * 256-channel tile: the patch (and the operand transform, and the copy-out of the transformed tensor) is staged ONCE per pixel
+//     tile instead of once per 128-channel tile; 16x16-pixel tile: half the weight traffic per FLOP of the 8x16 one;
+//   * small maps (one workgroup per CU): 8 waves split the K range of every unit between two wave groups (WK = 2) -- two waves per
+//     SIMD on a 128 x 128 tile, partial accumulators exchanged through LDS once at the end.
+// LDS image of the patch: [pixel (TH+2) x 18][144 B] (128 B of one channel chunk + 16 B pad: 16 consecutive pixels hit 16 distinct
+// 16-byte bank slots).  The 32 pixels of an MFMA B fragment are 2 tile rows x 16; lane -> pixel follows the hardware's
+// ds_read_b128 lane groups ({0-3,12-15,20-27} / {4-11,16-19,28-31}) so that every group reads 16 consecutive pixels of one row.
+#include <algorithm>
+#include <cstdlib>
+#include <utility>
+
+#include "common.h"
+#include "halo_xf.h"
+#include "../../include/gdrn_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+constexpr int V3_PITCH = 144;      // LDS bytes per patch pixel
+constexpr int V3_PW = 18;          // patch width (TW = 16)
+constexpr int V3_UNIT = 16384;     // weight bytes per unit (one ring slot)
+constexpr int V3_RING = 3;
+
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) { return (unsigned)(uintptr_t)(lds_u8*)p; }
+
+// one LDS-DMA: 64 lanes x 16 bytes, global (uniform base + per-lane 32-bit offset) -> LDS (uniform address + lane*16).  Not counted by
+// hipcc: every consumer sits behind a hand-placed s_waitcnt vmcnt.
+__device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned ldsa) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(gbase), "s"(ldsa)
+                 : "memory");
+}
+
+template <class F, int... Us>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int N>
+__device__ __forceinline__ void wait_barrier() {
+    // own DMAs (all but the last N loads) landed, own LDS traffic drained, then the workgroup barrier: everybody's DMA of the next unit
+    // is visible and everybody has finished reading the previous unit's slot.  One asm statement with a memory clobber: neither
+    // hipcc's LDS reads nor the DMA statements move across it.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int TH, int BN, int WM, int WN, int WK, int XF>
+struct V3 {
+    static constexpr int NW = WM * WN * WK, NT = NW * 64;
+    static constexpr int PH = TH + 2, PPIX = PH * V3_PW, PBYTES = PPIX * V3_PITCH;
+    static constexpr int NFRB = BN / 32;                   // A fragments (32 channels) per channel tile
+    static constexpr int FA = NFRB / WM;                   // ... per wave
+    static constexpr int ROWS_W = TH / WN;                 // pixel rows per wave
+    static constexpr int FB = ROWS_W / 2;                  // B fragments (2 rows x 16 pixels) per wave
+    static constexpr int KSU = V3_UNIT / (NFRB * 1024);    // 16-deep k-substeps per unit (all wave groups together)
+    static constexpr int KSW = KSU / WK;                   // ... per wave
+    static constexpr int UPT = 4 / KSU;                    // units per tap (a tap of a 128-byte chunk = 4 k-substeps)
+    static constexpr int UPC = 9 * UPT;                    // units per chunk
+    static constexpr int NSL = (PPIX * 8 + NT - 1) / NT;   // patch slices (NT granules of 16 bytes) per chunk
+    static constexpr int NIN = XF >= 2 ? 2 : 1;            // input tensors
+    static constexpr int RAWSLOTS = UPC == 18 ? 1 : 2;
+    static constexpr int SLICE_BYTES = NT * 16;
+    static constexpr int DPW = 16 / NW;                    // DMA instructions (1 KiB) per wave and unit
+    static constexpr int FBE = FB / WK;                    // B fragments a wave owns in the epilogue
+    // LDS map
+    static constexpr int OFF_P0 = 0;
+    static constexpr int OFF_RING = PBYTES;
+    static constexpr int OFF_P1 = OFF_RING + V3_RING * V3_UNIT;
+    static constexpr int OFF_RAW = OFF_P1 + PBYTES;
+    static constexpr int OFF_TAB = OFF_RAW + RAWSLOTS * NIN * SLICE_BYTES;
+    // prologue staging: ring slot 2 + patch 1 + raw are free until the loop starts
+    static constexpr int OFF_PRO = OFF_RING + 2 * V3_UNIT;
+    static constexpr int PRO_SLICES = (OFF_TAB - OFF_PRO) / (NIN * SLICE_BYTES);
+    static_assert(KSW == 2 && DPW >= 1 && 16 % NW == 0 && FA % 2 == 0 && FB >= 1 && FB % WK == 0, "tile configuration");
+    static_assert(NT % 8 == 0 && PRO_SLICES >= 1 && (UPC == 18 || UPC == 9), "tile configuration");
+    static_assert((UPC == 18 && NSL <= 6) || (UPC == 9 && NSL <= 3), "patch slice schedule");
+    static constexpr size_t smem_bytes(int Cin) { return (size_t)OFF_TAB + (size_t)xf_nk(XF) * Cin * sizeof(float); }
+
+    // patch pipeline of the NEXT chunk inside a chunk's units: slice whose DMA goes out / whose transform runs in unit U
+    static constexpr int dma_slice(int U) {
+        if (UPC == 18) return (U % 3 == 0 && U <= 12) ? U / 3 : (U == 14 ? 5 : -1);
+        return U == 0 ? 0 : (U == 1 ? 1 : (U == 3 ? 2 : -1));
+    }
+    static constexpr int xf_slice(int U) {
+        if (UPC == 18) return (U % 3 == 2 && U <= 14) ? U / 3 : (U == 16 ? 5 : -1);
+        return U == 3 ? 0 : (U == 4 ? 1 : (U == 6 ? 2 : -1));
+    }
+    static constexpr int raw_slot(int s) { return RAWSLOTS == 1 ? 0 : (s & 1); }
+    // loads issued by a wave in unit U AFTER its weight DMA (the patch DMAs; issued in every chunk, also the last, so that the count is static)
+    static constexpr int pd(int U) { return (dma_slice(U) >= 0 && dma_slice(U) < NSL) ? NIN : 0; }
+};
+
+// operand row of fragment f, fragment row r (gdrn_hip.h, gdrn_pack_wfrag32)
+__host__ __device__ __forceinline__ int wfrag32_row(int f, int r) { return (f >> 1) * 64 + ((r >> 2) & 1) * 32 + (f & 1) * 16 + (r >> 3) * 4 + (r & 3); }
+
+// granule (16 B) permutation of the row-major bf16 [rows][9][Cin] operand into MFMA-32x32x16 A fragments
+__global__ __launch_bounds__(256) void pack_wfrag32_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int Cin) {
+    const int nfr = rows >> 5, kch = Cin >> 6;
+    const long long total = (long long)kch * 9 * 4 * nfr * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int f = (int)(r % nfr); r /= nfr;
+        const int ks = (int)(r & 3); r >>= 2;
+        const int tap = (int)(r % 9);
+        const int kc = (int)(r / 9);
+        const int row = wfrag32_row(f, lane & 31);
+        const size_t so = ((size_t)row * 9 + tap) * Cin + (size_t)kc * 64 + ks * 16 + (lane >> 5) * 8;
+        *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(src + so);
+    }
+}
+
+template <int TH, int BN, int WM, int WN, int WK, int XF>
+__global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_conv_params p) {
+    using K = V3<TH, BN, WM, WN, WK, XF>;
+    constexpr int NT = K::NT, FA = K::FA, FB = K::FB, NFRB = K::NFRB, UPC = K::UPC, NSL = K::NSL, NIN = K::NIN, PBYTES = K::PBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = (wave / WN) % WM, wk = wave / (WN * WM);
+    const int l5 = lane & 31, hh = lane >> 5;
+
+    const int NTn = p.Cout / BN;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: neighbouring pixel tiles (and the channel tiles of one pixel tile) share an L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = bid % NTn;
+    const int mt = bid / NTn;  // pixel-tile index (statistics row)
+    int t = mt;
+    const int tiles_x = p.Wo / 16, tiles_y = p.Ho / TH;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int co0 = nt * BN;
+    const int y0 = ty * TH, x0 = tx * 16;
+    const int kch = p.Cin >> 6;
+    const int total_units = kch * UPC;
+
+    // ---- weight stream: unit g = kc*UPC + U is KSU*NFRT blocks of 1 KiB at w + g*wstride; this wave moves DPW consecutive blocks
+    const int NFRT = p.w_rows >> 5;
+    const int j0 = wave * K::DPW;  // first block of this wave inside a unit: (k-substep j0 / NFRB, fragment j0 % NFRB)
+    const unsigned wlane = (unsigned)((((j0 / NFRB) * NFRT + nt * NFRB + (j0 % NFRB)) << 10) + lane * 16);
+    const size_t wstride = (size_t)K::KSU * NFRT * 1024;
+    const char* wg = reinterpret_cast<const char*>(p.w);
+    const unsigned ring_a = lds_addr(smem + K::OFF_RING) + (unsigned)(j0 * 1024);
+    auto dma_w = [&](int g, int slot) {
+        const int gc = g < total_units ? g : total_units - 1;  // past the end: a harmless reload into a free slot keeps the counts static
+        const char* src = wg + (size_t)gc * wstride;
+#pragma unroll
+        for (int i = 0; i < K::DPW; ++i) dma16(src + i * 1024, wlane, ring_a + (unsigned)(slot * V3_UNIT + i * 1024));
+    };
+    dma_w(0, 0);
+    dma_w(1, 1);
+
+    // ---- patch slice geometry of this thread: slice s covers granules [s*NT, (s+1)*NT), granule id -> pixel id>>3, 16-byte part id&7
+    const int g8 = tid & 7;
+    unsigned poff[NSL];
+    unsigned pokm = 0, pinm = 0, ppm = 0;  // per slice: input pixel inside the image / one of the tile's own pixels / slot exists
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+        const int pp = s * (NT / 8) + (tid >> 3);
+        const int py = pp / V3_PW, px = pp - py * V3_PW;
+        const int iy = y0 + py - 1, ix = x0 + px - 1;
+        const bool inpatch = pp < K::PPIX;
+        const bool ok = inpatch && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+        poff[s] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * 2u + (unsigned)(g8 * 16);
+        pokm |= ok ? (1u << s) : 0u;
+        pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= 16) ? (1u << s) : 0u;
+        ppm |= inpatch ? (1u << s) : 0u;
+    }
+    const int pdst0 = (tid >> 3) * V3_PITCH + g8 * 16;          // LDS slot of slice s: pdst0 + s * PDSTEP
+    constexpr int PDSTEP = (NT / 8) * V3_PITCH;
+    const char* xg = reinterpret_cast<const char*>(p.x);
+    const char* xg2 = reinterpret_cast<const char*>(p.xf_x2);
+    char* xo = (XF != 0 && nt == 0) ? reinterpret_cast<char*>(p.xf_out) : nullptr;
+    const float xlo = p.xf_relu ? 0.f : -__builtin_inff();
+    const float* xtab = reinterpret_cast<const float*>(smem + K::OFF_TAB) + g8 * 8;  // + kc*64: this thread's 8 channels of chunk kc
+    if constexpr (XF != 0) {
+        float* tabw = reinterpret_cast<float*>(smem + K::OFF_TAB);
+        for (int c = tid; c < p.Cin; c += NT) {
+            tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
+            tabw[p.Cin + c] = p.xf_c[c];
+            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
+            if constexpr (XF == 2) tabw[3 * p.Cin + c] = p.xf_c2 ? p.xf_c2[c] : 0.f;
+            if constexpr (XF == 4) { tabw[3 * p.Cin + c] = p.xf_msc[c]; tabw[4 * p.Cin + c] = p.xf_msh[c]; }
+        }
+    }
+    // raw staging: DMA of slice s of chunk kc into raw area `ra` (bytes from smem); a thread reads back its own granule only (covered
+    // by its own vmcnt wait, no barrier needed)
+    auto dma_p = [&](int kc, int s, int ra) {
+        const int kcc = kc < kch ? kc : kch - 1;
+        dma16(xg + kcc * 128, poff[s], lds_addr(smem + ra) + (unsigned)(wave * 1024));
+        if constexpr (NIN == 2) dma16(xg2 + kcc * 128, poff[s], lds_addr(smem + ra + K::SLICE_BYTES) + (unsigned)(wave * 1024));
+    };
+    // transform slice s of chunk kc from raw area `ra` into patch buffer pb (XF 0: zero the halo outside the image)
+    auto xf_p = [&](int kc, int s, int ra, int pb) {
+        if ((ppm >> s) & 1u) {
+            const uint4 v1 = *reinterpret_cast<const uint4*>(smem + ra + tid * 16);
+            uint4 t_;
+            if constexpr (XF == 0) t_ = v1;
+            else {
+                uint4 v2 = v1;
+                if constexpr (NIN == 2) v2 = *reinterpret_cast<const uint4*>(smem + ra + K::SLICE_BYTES + tid * 16);
+                t_ = xf_apply<XF>(v1, v2, xtab + kc * 64, p.Cin, xlo);
+            }
+            t_ = ((pokm >> s) & 1u) ? t_ : make_uint4(0, 0, 0, 0);   // the padding applies to the conv's input v, and v(0) != 0
+            *reinterpret_cast<uint4*>(smem + (pb ? K::OFF_P1 : K::OFF_P0) + pdst0 + s * PDSTEP) = t_;
+            if constexpr (XF != 0) {
+                if (xo != nullptr && ((pinm >> s) & 1u)) *reinterpret_cast<uint4*>(xo + (poff[s] + (unsigned)(kc * 128))) = t_;
+            }
+        }
+    };
+
+    // ---- prologue: patch of chunk 0 through the free LDS (ring slot 2, patch 1, raw), PRO_SLICES slices per pass
+    if constexpr (XF != 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // transform table complete
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < NSL; s0 += K::PRO_SLICES) {
+#pragma unroll
+        for (int s = s0; s < s0 + K::PRO_SLICES && s < NSL; ++s) dma_p(0, s, K::OFF_PRO + (s - s0) * NIN * K::SLICE_BYTES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = s0; s < s0 + K::PRO_SLICES && s < NSL; ++s) xf_p(0, s, K::OFF_PRO + (s - s0) * NIN * K::SLICE_BYTES, 0);
+        if (s0 + K::PRO_SLICES < NSL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw reads done before the next pass overwrites them
+    }
+
+    // ---- fragment addressing
+    // B: lane -> pixel of a 2 x 16 fragment following the ds_read_b128 lane groups; k-group (8 channels) = lane >> 5
+    const int frow = ((l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28) ? 1 : 0;
+    const int fx = l5 < 4 ? l5 : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : (l5 < 28 ? l5 - 12 : l5 - 16)));
+    const int lbase = ((wn * K::ROWS_W + frow) * V3_PW + fx) * V3_PITCH + hh * 16 + wk * K::KSW * 32;
+    // A: block (k-substep, fragment) of the unit at ((ks * NFRB) + frag) KiB, lane-linear inside
+    const unsigned char* abase = smem + K::OFF_RING + ((wk * K::KSW * NFRB + wm * FA) << 10) + lane * 16;
+
+    f32x16_t acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    uint4 fa0[FA], fb0[FB], fa1[FA], fb1[FB];
+    // fragments of (unit U, local k-substep sl) from ring slot U % 3 and patch buffer pcur
+#define V3_LDA(dst_, U_, SL_)                                                                                           \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int a_ = 0; a_ < FA; ++a_)                                                               \
+            dst_[a_] = *reinterpret_cast<const uint4*>(abase + (((U_) % V3_RING) * V3_UNIT + ((SL_) * NFRB + a_) * 1024)); \
+    }
+#define V3_LDB(dst_, pc_, U_, SL_)                                                                                      \
+    {                                                                                                                   \
+        constexpr int tap_ = (U_) / K::UPT, ks_ = ((U_) % K::UPT) * K::KSU + (SL_);                                     \
+        constexpr int tsh_ = ((tap_ / 3) * V3_PW + (tap_ % 3)) * V3_PITCH + ks_ * 32;                                   \
+        _Pragma("unroll") for (int b_ = 0; b_ < FB; ++b_)                                                               \
+            dst_[b_] = *reinterpret_cast<const uint4*>((pc_) + (b_ * 2 * V3_PW * V3_PITCH + tsh_));                     \
+    }
+#define V3_MM(fa_, fb_)                                                                                                 \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int a_ = 0; a_ < FA; ++a_)                                                               \
+            _Pragma("unroll") for (int b_ = 0; b_ < FB; ++b_)                                                           \
+                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_[a_]),            \
+                                                                      __builtin_bit_cast(bf16x8_t, fb_[b_]), acc[a_][b_], 0, 0, 0); \
+    }
+
+    // first barrier: patch 0 complete, units 0 and 1 landed
+    wait_barrier<0>();
+    dma_w(2, 2);
+    {
+        const unsigned char* pc0 = smem + K::OFF_P0 + lbase;
+        V3_LDA(fa0, 0, 0)
+        V3_LDB(fb0, pc0, 0, 0)
+    }
+
+    for (int kc = 0; kc < kch; ++kc) {
+        const int pb = kc & 1;
+        const bool more_p = kc + 1 < kch;
+        const unsigned char* pcur = smem + (pb ? K::OFF_P1 : K::OFF_P0) + lbase;
+        const unsigned char* pnxt = smem + (pb ? K::OFF_P0 : K::OFF_P1) + lbase;
+        const int gbase = kc * UPC;
+        auto unit = [&](auto Uc) {
+            constexpr int U = decltype(Uc)::value;
+            if constexpr (U > 0) {
+                // [A][B] weights of unit U+1 (issued one unit ago) landed everywhere; slot (U-1)%3 is free
+                wait_barrier<K::pd(U - 1)>();
+                // [C] refill it with unit U+2
+                dma_w(gbase + U + 2, (U + 2) % V3_RING);
+            }
+            // [D] next chunk's patch: transform a landed slice, send the next DMA (always issued: static load counts)
+            if constexpr (K::xf_slice(U) >= 0 && K::xf_slice(U) < NSL) {
+                if (more_p) xf_p(kc + 1, K::xf_slice(U), K::OFF_RAW + K::raw_slot(K::xf_slice(U)) * NIN * K::SLICE_BYTES, pb ^ 1);
+            }
+            if constexpr (K::dma_slice(U) >= 0 && K::dma_slice(U) < NSL) {
+                if constexpr (K::xf_slice(U) >= 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw slot's reads are done
+                dma_p(kc + 1, K::dma_slice(U), K::OFF_RAW + K::raw_slot(K::dma_slice(U)) * NIN * K::SLICE_BYTES);
+            }
+            // [E] this unit's MFMAs; the other k-substep's fragments and the next unit's first fragments load underneath
+            V3_LDA(fa1, U, 1)
+            V3_LDB(fb1, pcur, U, 1)
+            V3_MM(fa0, fb0)
+            if constexpr (U + 1 < UPC) {
+                V3_LDA(fa0, U + 1, 0)
+                V3_LDB(fb0, pcur, U + 1, 0)
+            } else {
+                V3_LDA(fa0, 0, 0)              // UPC % 3 == 0: unit 0 of the next chunk sits in slot 0
+                V3_LDB(fb0, pnxt, 0, 0)
+            }
+            V3_MM(fa1, fb1)
+        };
+        static_for<UPC>(unit);
+        // chunk boundary = the barrier of the next chunk's unit 0
+        if (more_p) {
+            wait_barrier<K::pd(UPC - 1)>();
+            dma_w(gbase + UPC + 2, 2);   // (UPC + 2) % 3 == 2
+        }
+    }
+#undef V3_LDA
+#undef V3_LDB
+#undef V3_MM
+    // every DMA (incl. the reloads past the end) landed and every wave is done with the LDS operands: LDS is scratch from here
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- K-split: the two wave groups hold partial sums of the same tile.  Group wk keeps B fragments [wk*FBE, (wk+1)*FBE) and
+    // hands the others to its partner (16-byte rows [reg quad][lane]: conflict-free ds_write_b128 / ds_read_b128).
+    constexpr int FBE = K::FBE;
+    if constexpr (WK == 2) {
+        float* xch = reinterpret_cast<float*>(smem) + (size_t)wave * (FA * FBE * 16 * 64);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int be = 0; be < FBE; ++be) {
+                const int bo = (1 - wk) * FBE + be;  // a fragment of the partner
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    if (wk == 0) v = make_float4(acc[a][FBE + be][4 * q], acc[a][FBE + be][4 * q + 1], acc[a][FBE + be][4 * q + 2], acc[a][FBE + be][4 * q + 3]);
+                    else v = make_float4(acc[a][be][4 * q], acc[a][be][4 * q + 1], acc[a][be][4 * q + 2], acc[a][be][4 * q + 3]);
+                    (void)bo;
+                    *reinterpret_cast<float4*>(xch + (((a * FBE + be) * 4 + q) * 64 + lane) * 4) = v;
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int pw = (wave + WM * WN) % (2 * WM * WN);  // partner: same (wm, wn), other k group
+        const float* rch = reinterpret_cast<const float*>(smem) + (size_t)pw * (FA * FBE * 16 * 64);
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int be = 0; be < FBE; ++be)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(rch + (((a * FBE + be) * 4 + q) * 64 + lane) * 4);
+                    if (wk == 0) {
+                        acc[a][be][4 * q] += v.x; acc[a][be][4 * q + 1] += v.y; acc[a][be][4 * q + 2] += v.z; acc[a][be][4 * q + 3] += v.w;
+                    } else {  // keep the upper fragments in the lower slots: the epilogue below works on acc[a][0..FBE)
+                        acc[a][be][4 * q] = acc[a][FBE + be][4 * q] + v.x; acc[a][be][4 * q + 1] = acc[a][FBE + be][4 * q + 1] + v.y;
+                        acc[a][be][4 * q + 2] = acc[a][FBE + be][4 * q + 2] + v.z; acc[a][be][4 * q + 3] = acc[a][FBE + be][4 * q + 3] + v.w;
+                    }
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the exchange area becomes the statistics scratch
+    }
+
+    // ---- epilogue.  Lane (hh, l5): pixel (frow, fx) of its fragments, channels cw + ap*64 + hh*32 + [0, 32) for fragment pair ap
+    // = registers of acc[2ap] then acc[2ap+1] (row order of gdrn_pack_wfrag32): 64 contiguous bytes per pixel and pair.
+    const int cwl = wm * (BN / WM) + hh * 32;                        // channel inside the tile (+ ap*64)
+    const int cw = co0 + cwl;
+    const int brow0 = wn * K::ROWS_W + (WK == 2 ? wk * FBE * 2 : 0) + frow;   // tile row of epilogue fragment 0 (+ 2 per fragment)
+    const unsigned pix0 = (unsigned)((n * p.Ho + y0 + brow0) * p.Wo + x0 + fx);
+    const unsigned pstep = 2u * (unsigned)p.Wo;
+    constexpr int FAP = FA / 2;
+    char* yb = reinterpret_cast<char*>(p.y);
+    const char* ab = reinterpret_cast<const char*>(p.addend);
+    // per-channel sums over the tile's pixels: 32-lane reduction (DPP row sums + the other row of the half), partials of the
+    // (wn, wk) wave groups through LDS, added in a fixed order: one plain row [2][Cout] per pixel tile (deterministic)
+    float* cst = reinterpret_cast<float*>(smem);                 // [4][BN] per-channel constants of the fused BatchNorm backward
+    float* part = reinterpret_cast<float*>(smem) + 4 * BN;       // [WN*WK][2][BN]
+    const int grp = wn * WK + wk;
+    auto red_put = [&](int c, float v1, float v2) {              // c: channel inside the tile
+        v1 = row16_sum(v1);
+        v2 = row16_sum(v2);
+        v1 += __shfl_xor(v1, 16, 64);
+        v2 += __shfl_xor(v2, 16, 64);
+        if (l5 == 0) {
+            part[(grp * 2 + 0) * BN + c] = v1;
+            part[(grp * 2 + 1) * BN + c] = v2;
+        }
+    };
+    auto put_rows = [&](float* rows) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int i = tid; i < 2 * BN; i += NT) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < WN * WK; ++g) s += part[g * 2 * BN + i];
+            rows[(size_t)mt * 2 * p.Cout + (size_t)(i / BN) * p.Cout + co0 + (i % BN)] = s;
+        }
+    };
+    // the lane's part of fragment pair ap of an NHWC bf16 tensor: [fragment][16-byte quarter of the pair's 64 bytes]
+    auto ld_pair = [&](const char* base, int cs, int ap, uint4 (&dst)[FBE][4]) {
+#pragma unroll
+        for (int be = 0; be < FBE; ++be)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dst[be][q] = *reinterpret_cast<const uint4*>(base + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)cs + (unsigned)(cw + ap * 64)) * 2u + q * 16);
+    };
+    // LEAN: the 256-channel tile holds 128 accumulator registers per lane; its epilogue takes neither an addend nor a stored ReLU
+    // mask (gdrn_v3_config routes such launches to the 128-channel configuration): one more tile-sized operand would not fit the
+    // register file next to the accumulators
+    constexpr bool LEAN = FAP * FBE >= 4;
+
+    if (p.bnb_x != nullptr) {
+        // data gradient feeding a BatchNorm(+ReLU) backward: ReLU mask + the two per-channel sums of that backward on the accumulators
+        const char* xb = reinterpret_cast<const char*>(p.bnb_x);
+        const char* mb = LEAN ? nullptr : reinterpret_cast<const char*>(p.bnb_mask);
+        const char* ab2 = LEAN ? nullptr : ab;
+        const bool affine = p.bnb_mask == nullptr && p.bnb_scale != nullptr;
+        uint4 xq[2][FBE][4], aq[LEAN ? 1 : 2][FBE][4], mq[LEAN ? 1 : 2][FBE][4];
+        ld_pair(xb, p.bnb_cs, 0, xq[0]);                         // the tile loads of a pair go out before the first use
+        if constexpr (!LEAN) {
+            if (ab2 != nullptr) ld_pair(ab2, p.add_cs, 0, aq[0]);
+            if (mb != nullptr) ld_pair(mb, p.bnb_cs, 0, mq[0]);
+        }
+        for (int c = tid; c < BN; c += NT) {
+            cst[c] = p.bnb_mean[co0 + c];
+            cst[BN + c] = p.bnb_invstd[co0 + c];
+            cst[2 * BN + c] = affine ? p.bnb_scale[co0 + c] : 0.f;
+            cst[3 * BN + c] = affine ? p.bnb_shift[co0 + c] : 1.f;   // no affine: the mask term is always true
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int ap = 0; ap < FAP; ++ap) {
+            if (ap + 1 < FAP) {                                  // next pair's loads under this pair's arithmetic
+                ld_pair(xb, p.bnb_cs, ap + 1, xq[(ap + 1) & 1]);
+                if constexpr (!LEAN) {
+                    if (ab2 != nullptr) ld_pair(ab2, p.add_cs, ap + 1, aq[(ap + 1) & 1]);
+                    if (mb != nullptr) ld_pair(mb, p.bnb_cs, ap + 1, mq[(ap + 1) & 1]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = cwl + ap * 64 + q * 8;            // 8 channels of this step
+                float kmu[8], kis[8], ksc[8], ksh[8], t1[8], t2[8];
+                Vec16<float>::load(cst + cl, kmu); Vec16<float>::load(cst + cl + 4, kmu + 4);
+                Vec16<float>::load(cst + BN + cl, kis); Vec16<float>::load(cst + BN + cl + 4, kis + 4);
+                Vec16<float>::load(cst + 2 * BN + cl, ksc); Vec16<float>::load(cst + 2 * BN + cl + 4, ksc + 4);
+                Vec16<float>::load(cst + 3 * BN + cl, ksh); Vec16<float>::load(cst + 3 * BN + cl + 4, ksh + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t1[e] = t2[e] = 0.f;
+#pragma unroll
+                for (int be = 0; be < FBE; ++be) {
+                    float xv[8], av[8], mv[8], v[8];
+                    Vec16<bf16_t>::unpack(xq[ap & 1][be][q], xv);
+                    if constexpr (!LEAN) {
+                        if (ab2 != nullptr) Vec16<bf16_t>::unpack(aq[ap & 1][be][q], av);
+                        if (mb != nullptr) Vec16<bf16_t>::unpack(mq[ap & 1][be][q], mv);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ch = q * 8 + e;            // channel inside the pair's 32: fragment 2ap + (ch >> 4), register ch & 15
+                        bool keep = xv[e] * ksc[e] + ksh[e] > 0.f;
+                        float gv = acc[2 * ap + (ch >> 4)][be][ch & 15];
+                        if constexpr (!LEAN) {
+                            if (mb != nullptr) keep = keep && (mv[e] > 0.f);
+                            if (ab2 != nullptr) gv += av[e];
+                        }
+                        gv = keep ? gv : 0.f;
+                        v[e] = gv;
+                        t1[e] += gv;
+                        t2[e] += gv * (xv[e] - kmu[e]) * kis[e];
+                    }
+                    *reinterpret_cast<uint4*>(yb + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)p.y_cs + (unsigned)(cw + ap * 64)) * 2u + q * 16) = Vec16<bf16_t>::pack(v);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red_put(cl + e, t1[e], t2[e]);
+            }
+        }
+        put_rows(p.bnb_rows);
+        return;
+    }
+
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float u = 0.f, q = 0.f;
+#pragma unroll
+                for (int be = 0; be < FBE; ++be) { const float v = acc[a][be][i]; u += v; q += v * v; }
+                red_put(cwl + (a >> 1) * 64 + (a & 1) * 16 + i, u, q);
+            }
+        put_rows(p.stats);
+    }
+    const bool relu = p.act == 1;
+    const char* ab2 = LEAN ? nullptr : ab;
+#pragma unroll
+    for (int ap = 0; ap < FAP; ++ap) {
+        uint4 aq[FBE][4];
+        if constexpr (!LEAN) {
+            if (ab2 != nullptr) ld_pair(ab2, p.add_cs, ap, aq);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float bq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bq[e] = 0.f;
+            if (p.bias != nullptr) { Vec16<float>::load(p.bias + cw + ap * 64 + q * 8, bq); Vec16<float>::load(p.bias + cw + ap * 64 + q * 8 + 4, bq + 4); }
+#pragma unroll
+            for (int be = 0; be < FBE; ++be) {
+                float av[8], v[8];
+                if constexpr (!LEAN) {
+                    if (ab2 != nullptr) Vec16<bf16_t>::unpack(aq[be][q], av);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = q * 8 + e;
+                    float r = acc[2 * ap + (ch >> 4)][be][ch & 15] + bq[e];
+                    if constexpr (!LEAN) {
+                        if (ab2 != nullptr) r += av[e];
+                    }
+                    v[e] = relu ? fmaxf(r, 0.f) : r;
+                }
+                *reinterpret_cast<uint4*>(yb + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)p.y_cs + (unsigned)(cw + ap * 64)) * 2u + q * 16) = Vec16<bf16_t>::pack(v);
+            }
+        }
+    }
+}
+
+template <int TH, int BN, int WM, int WN, int WK, int XF>
+int launch_v3(const gdrn_conv_params& p, int N, hipStream_t st) {
+    using K = V3<TH, BN, WM, WN, WK, XF>;
+    const size_t smem = K::smem_bytes(p.Cin);
+    if (smem > 160 * 1024) return GDRN_ERR_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_v3_kernel<TH, BN, WM, WN, WK, XF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return GDRN_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int grid = N * (p.Ho / TH) * (p.Wo / 16) * (p.Cout / BN);
+    hipLaunchKernelGGL((conv3x3_v3_kernel<TH, BN, WM, WN, WK, XF>), dim3(grid), dim3(K::NT), smem, st, p);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+template <int XF>
+int launch_v3_cfg(const gdrn_conv_params& p, int cfg, int N, hipStream_t st) {
+    if (cfg == 1) return launch_v3<16, 256, 2, 4, 1, XF>(p, N, st);
+    return launch_v3<8, 128, 2, 2, 2, XF>(p, N, st);
+}
+
+}  // namespace
+
+// tile configuration of the v3 kernel for a shape: 1 = 16x16 pixels x 256 channels (8 waves, 128 x 64 wave tiles), 2 = 8x16 pixels x 128
+// channels (8 waves, 64 x 64 wave tiles, K range split between two wave groups); 0 = shape not covered.
+int gdrn_v3_config(const gdrn_conv_params* p) {
+    if (p->mode != 0 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->Hi != p->Ho || p->Wi != p->Wo) return 0;
+    if (p->dtype != GDRN_DT_BF16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
+    if (p->act > 1 || p->out_f32) return 0;
+    const int N = p->M / (p->Ho * p->Wo);
+    const char* force = getenv("GDRN_V3_CFG");
+    if (force && force[0] == '2') return 2;
+    // 256-channel tile when the grid still has at least one workgroup per CU: the patch (+ transform) is staged once per pixel tile
+    if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= 256) {
+        if (p->xf_mode == 4 && (size_t)V3<16, 256, 2, 4, 1, 4>::smem_bytes(p->Cin) > 160 * 1024) return 2;
+        return 1;
+    }
+    return 2;
+}
+
+int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn) {
+    const int cfg = gdrn_v3_config(p);
+    *th = cfg == 1 ? 16 : (cfg == 2 ? 8 : 0);
+    *tw = cfg ? 16 : 0;
+    *bn = cfg == 1 ? 256 : (cfg == 2 ? 128 : 0);
+    return cfg;
+}
+
+extern "C" int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, int dtype, void* stream) {
+    if (!src || !dst || rows <= 0 || (rows & 63) || Cin <= 0 || (Cin & 63)) return GDRN_ERR_ARG;
+    if (dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    const long long n = (long long)rows * 9 * Cin / 8;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_wfrag32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+int gdrn_v3_launch(const gdrn_conv_params* pp, void* stream) {
+    const gdrn_conv_params& p = *pp;
+    const int cfg = gdrn_v3_config(pp);
+    if (cfg == 0) return GDRN_ERR_SHAPE;
+    const int bn = cfg == 1 ? 256 : 128;
+    if ((p.x_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || (p.bnb_x && (p.bnb_cs & 7))) return GDRN_ERR_SHAPE;  // 16-byte accesses
+    if (p.w_rows < p.Cout || (p.w_rows & 63) || (p.Cout % bn)) return GDRN_ERR_SHAPE;
+    const int hw = p.Ho * p.Wo;
+    if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
+    if (p.bnb_x) {
+        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (p.bias || p.act || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
+        if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
+    }
+    if ((unsigned long long)p.M * (unsigned long long)(p.y_cs > p.add_cs ? p.y_cs : p.add_cs) * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
+    if ((unsigned long long)p.M * (unsigned long long)p.x_cs * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
+    if (p.xf_mode) {
+        if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > 512) return GDRN_ERR_ARG;
+        if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
+        if (p.xf_mode == 4 && (!p.xf_msc || !p.xf_msh)) return GDRN_ERR_ARG;
+        if (p.xf_mode != 2 && p.xf_c2) return GDRN_ERR_ARG;
+    }
+    const int N = p.M / hw;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (p.xf_mode) {
+        case 0: return launch_v3_cfg<0>(p, cfg, N, st);
+        case 1: return launch_v3_cfg<1>(p, cfg, N, st);
+        case 2: return launch_v3_cfg<2>(p, cfg, N, st);
+        case 3: return launch_v3_cfg<3>(p, cfg, N, st);
+        default: return launch_v3_cfg<4>(p, cfg, N, st);
+    }
+}

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             // source row of block cb, fragment row a: gdrn_pack_wfrag's interleave (blocks of a 32-row group alternate in units of 4 rows
             // for operands of more than 64 rows)
             const int FNp = k.A1 <= 64 ? 1 : 2;
-            auto srow = [&](int a) { return (cb / FNp) * 16 * FNp + (a >> 2) * (4 * FNp) + (cb % FNp) * 4 + (a & 3); };
+            // frag == 2 (gdrn_pack_wfrag32): brick cb = half (cb & 1) of 32-row fragment cb >> 1, fragment row r = half*16 + a
+            auto srow = [&](int a) {
+                if (k.frag == 2) { const int f = cb >> 1, r = (cb & 1) * 16 + a; return (f >> 1) * 64 + ((r >> 2) & 1) * 32 + (f & 1) * 16 + (r >> 3) * 4 + (r & 3); }
+                return (cb / FNp) * 16 * FNp + (a >> 2) * (4 * FNp) + (cb % FNp) * 4 + (a & 3);
+            };
             __shared__ float rsc[16];              // optional per-row factor (eval mode: BatchNorm scale folded into the weights)
             if (threadIdx.x < 16) rsc[threadIdx.x] = (k.scale != nullptr && srow((int)threadIdx.x) < k.A1v) ? k.scale[srow((int)threadIdx.x)] : 1.f;
             __syncthreads();
@@ -97,6 +101,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
                 }
             }
             __syncthreads();
+            if (k.frag == 2) {
+                // destination block ((kc*9 + tap)*4 + ks)*(A1/32) + f, lane = hh*32 + half*16 + a: row a of this brick, k = (ks*2 + hh)*8 ..+7
+                const int nfr = k.A1 >> 5, f = cb >> 1, half = cb & 1;
+                for (int gi = threadIdx.x; gi < 9 * 4 * 32; gi += 256) {
+                    const int a = gi & 15, hh = (gi >> 4) & 1, ks = (gi >> 5) & 3, tap = gi >> 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&tile[a][tap][(ks * 2 + hh) * 8]);
+                    *reinterpret_cast<uint4*>(dst + ((size_t)((((kc * 9 + tap) * 4 + ks) * nfr + f) * 64 + hh * 32 + half * 16 + a) << 3)) = v;
+                }
+                return;
+            }
             // destination granule ((((cb*9 + tap)*kch + kc)*2 + ks)*64 + lane): row lane&15, b = (ks*4 + (lane>>4))*8 ..+7
             for (int gi = threadIdx.x; gi < 9 * 2 * 64; gi += 256) {
                 const int lane = gi & 63, ks = (gi >> 6) & 1, tap = gi >> 7;

@@ -27,13 +27,15 @@ extern "C" {
 #endif
 
 #define GDRN_ABI_VERSION 1
-enum { GDRN_F32 = 0, GDRN_BF16 = 1 };
-enum { GDRN_E_ARG = -1, GDRN_E_SHAPE = -2, GDRN_E_LAUNCH = -3 };
+/* `dtype` arguments */
+enum { GDRN_DT_F32 = 0, GDRN_DT_BF16 = 1 };
+/* status codes (0 = GDRN_OK) */
+enum { GDRN_OK = 0, GDRN_ERR_ARG = -1, GDRN_ERR_SHAPE = -2, GDRN_ERR_LAUNCH = -3 };
 
 int gdrn_version(void);
 /* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
  * memory, no initialisation needed unless stated): `op` selects the buffer, `params` points at the arguments that determine its
- * size.  < 0: GDRN_E_*.  (the Python engine sizes its plan buffers with the same rules.) */
+ * size.  < 0: GDRN_ERR_*.  (the Python engine sizes its plan buffers with the same rules.) */
 enum {
     GDRN_WS_CONV_STATS = 0,     /* const gdrn_conv_params*  -> p->stats of gdrn_conv_gemm */
     GDRN_WS_CONV3X3_STATS = 1,  /* const gdrn_conv_params*  -> p->stats / p->bnb_rows of gdrn_conv3x3_halo */
@@ -98,7 +100,7 @@ typedef struct gdrn_conv_params {
     const float* bnb_shift;
     float* bnb_rows;
     int bnb_cs;
-    int pad0_;
+    int w_frag;   /* gdrn_conv3x3_halo: layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments), 2: gdrn_pack_wfrag32 (see below) */
     int Hi, Wi, Cin, x_cs;
     int Ho, Wo, Cout, y_cs, add_cs;
     int KH, KW, stride, pad;
@@ -150,6 +152,17 @@ int gdrn_conv_stats_rows(const gdrn_conv_params* p);
  * Row order: for operands of more than 64 rows (128-channel tile) the two 16-row blocks of a 32-row group interleave in units of
  * 4 rows, so that an MFMA result lane holds 8 contiguous output channels and the conv's epilogue moves 16 bytes per access. */
 int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, void* stream);
+/* Second-generation halo kernel (conv3x3_v3.hip; Cin a multiple of 64, Cout of 128, W of 16, H of 8, bf16, act <= 1, bf16 output):
+ * v_mfma_f32_32x32x16_bf16, the weights stream global -> LDS by LDS-DMA and are shared by the 8 waves of a workgroup, tiles of
+ * 16x16 pixels x 256 channels (large maps) or 8x16 pixels x 128 channels with the K range split over two wave groups (small maps).
+ * Selected by p->w_frag = 2; w is then the operand of gdrn_pack_wfrag32: one contiguous 1 KiB block = the 64 lanes of a 32x32x16
+ * MFMA A operand per (128-byte chunk kc, tap, 16-deep k-substep ks, 32-row fragment f), block index ((kc*9 + tap)*4 + ks)*(rows/32) + f;
+ * lane l of a block holds fragment row l & 31, k = 16*ks + 8*(l >> 5) .. +7.  Fragment f, row r is operand row
+ * (f>>1)*64 + ((r>>2)&1)*32 + (f&1)*16 + (r>>3)*4 + (r&3): an MFMA result lane then holds 32 contiguous output channels per fragment
+ * pair (64-byte epilogue accesses).  rows must be a multiple of 64.
+ * gdrn_conv3x3_wfrag(p): operand layout the library prefers for the shape in p (p->w_frag ignored): 2, 1, or 0 = no halo tiling. */
+int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, int dtype, void* stream);
+int gdrn_conv3x3_wfrag(const gdrn_conv_params* p);
 int gdrn_conv3x3_halo(const gdrn_conv_params* p, void* stream);
 int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
@@ -358,8 +371,8 @@ int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  * Multi-tensor variants: ONE launch for all parameter tensors.  Task tables are arrays in DEVICE memory built once by
  * the host; `*_start` are int prefix arrays [ntasks + 1] (workgroups for pack/unpack: ceil(n / gdrn_pack_chunk()) per
  * task; rows for Ranger).
- * gdrn_pack_task: gdrn_pack4 semantics (dst[a1][a2][t][b] = src[a1*s1 + a2*s2 + t'*st + b*sb], zero padded); frag != 0:
- *   dst is the fragment-major permutation (gdrn_pack_wfrag) of that [A1][1][9][B] operand.  For gdrn_unpack_multi the
+ * gdrn_pack_task: gdrn_pack4 semantics (dst[a1][a2][t][b] = src[a1*s1 + a2*s2 + t'*st + b*sb], zero padded); frag = 1 / 2:
+ *   dst is the fragment-major permutation (gdrn_pack_wfrag / gdrn_pack_wfrag32) of that [A1][1][9][B] operand.  For gdrn_unpack_multi the
  *   same struct describes gdrn_unpack4 (src = packed fp32, dst = parameter-layout gradient, n = A1v*A2v*T*Bv). */
 /* Workgroups per task (blk_start prefix sums): ceil(n / gdrn_pack_chunk()) for row-major destinations; bf16 fragment-major
  * (frag = 1, T = 9) tasks take (A1/16) * (B/64) workgroups -- one per brick of 16 rows x 64 b x 9 taps. */

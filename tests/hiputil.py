@@ -78,14 +78,16 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
-              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None):
+              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None, v3=False, reps=0):
     """bnb (halo and generic kernel, bf16): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
     the second return value is then the [tiles][2][Cout] rows buffer.
-    xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging."""
+    xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging.
+    v3 (with halo): the second-generation kernel (operand of gdrn_pack_wfrag32, w_frag = 2).
+    reps > 0: also time `reps` back-to-back launches with HIP events; the average (ms) is returned as a third value."""
     lib = cabi.load()
-    if halo:  # the halo kernel takes the fragment-major permutation of the same operand
+    if halo:  # the halo kernels take a fragment-major permutation of the same operand
         wf = torch.empty_like(w)
-        check(lib.gdrn_pack_wfrag(ptr(w), ptr(wf), w.shape[0], Cin, dt, stream()), "pack_wfrag")
+        check((lib.gdrn_pack_wfrag32 if v3 else lib.gdrn_pack_wfrag)(ptr(w), ptr(wf), w.shape[0], Cin, dt, stream()), "pack_wfrag")
         w = wf
     y_cs = y_cs or ru(Cout, 4)
     ydt = torch.float32 if (out_f32 or dt == F32) else torch.bfloat16
@@ -100,6 +102,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     cp.mode, cp.act, cp.out_f32 = mode, act, out_f32
     cp.M = B * (Ho // 2) * (Wo // 2) if mode == 1 else B * Ho * Wo
     cp.w_rows, cp.dtype = w.shape[0], dt
+    cp.w_frag = 2 if (halo and v3) else 0
     stats = None
     if want_stats:
         rows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
@@ -116,8 +119,17 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
         cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
         cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
-    check((lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm)(C.byref(cp), stream()), "conv")
+    fn = lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm
+    check(fn(C.byref(cp), stream()), "conv")
     torch.cuda.synchronize()
+    if reps > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn(C.byref(cp), stream())
+        e1.record()
+        torch.cuda.synchronize()
+        return y, stats, e0.elapsed_time(e1) / reps
     return y, stats
 
 
