@@ -355,9 +355,9 @@ class GDRN(nn.Module):
                     sym, cnt = S("sym", sym), S("sym_count", cnt)
                     keep += [sym, cnt]
                     kctx.update(sym=sym.data_ptr(), sym_count=cnt.data_ptr(), Kmax=K)
+        plan = eng.plan(B, self.training, do_loss)   # (building a plan fixes the layouts of the halo operands it is the first to use)
         if staging is None:
             eng.repack()
-        plan = eng.plan(B, self.training, do_loss)
         return eng, plan, kctx
 
     def forward(
@@ -494,6 +494,7 @@ class GDRN(nn.Module):
                 return None
         st["graph"].replay()
         eng.bn_epoch += 1  # the replayed kernels moved the BatchNorm running statistics (run_forward was not called)
+        plan.generation += 1  # ... and overwrote the plan's activations: a pending loss.backward() of an earlier model(...) call must not use them
         if optimizer is not None:
             optimizer.step(grads={eng.P[n]: eng.grads[n] for n in eng.param_names})
         return plan.losses * self._loss_w  # weighted like forward()'s loss_dict

@@ -587,14 +587,16 @@ int launch_tile(const gdrn_conv_params& p, int tw, int bn, int N, hipStream_t st
 
 // second-generation kernel (conv3x3_v3.hip), selected by p->w_frag == 2
 int gdrn_v3_config(const gdrn_conv_params* p);
+int gdrn_v3_preferred(const gdrn_conv_params* p);
 int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_v3_launch(const gdrn_conv_params* p, void* stream);
 
 // operand layout the library prefers for a shape: 2 = gdrn_pack_wfrag32 (v3 kernel), 1 = gdrn_pack_wfrag, 0 = no halo tiling
 extern "C" int gdrn_conv3x3_wfrag(const gdrn_conv_params* p) {
     if (!p) return GDRN_ERR_ARG;
-    const char* off = getenv("GDRN_V3");
-    if (!(off && off[0] == '0') && gdrn_v3_config(p) > 0) return 2;
+    const char* sel = getenv("GDRN_V3");   // "0": never, "2": wherever the kernel covers the shape (A/B, tests); default: where it measured faster
+    if (sel && sel[0] == '2' && gdrn_v3_config(p) > 0) return 2;
+    if (!(sel && sel[0] == '0') && gdrn_v3_preferred(p)) return 2;
     gdrn_conv_params q = *p;
     q.w_frag = 0;
     int th, tw, bn;

@@ -55,8 +55,34 @@ __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int,
 template <int N, class F>
 __device__ __forceinline__ void static_for(F& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+#ifdef V3_DBG
+// bring-up instrumentation (tools/v3dbg.py builds this file alone with -DV3_DBG): cycle stamps per wave
+__device__ unsigned long long* g_v3_dbg;
+__device__ __forceinline__ unsigned long long v3_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+struct V3Dbg { unsigned long long wait_mem = 0, wait_bar = 0; };
+#define V3_DBG_ARG , V3Dbg& dbg_
+#define V3_DBG_PASS , dbg_
+#else
+#define V3_DBG_ARG
+#define V3_DBG_PASS
+#endif
+
 template <int N>
-__device__ __forceinline__ void wait_barrier() {
+__device__ __forceinline__ void wait_barrier(int dummy_ V3_DBG_ARG) {
+#ifdef V3_DBG
+    const unsigned long long ta = v3_clock();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    const unsigned long long tb = v3_clock();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long tc = v3_clock();
+    dbg_.wait_mem += tb - ta;
+    dbg_.wait_bar += tc - tb;
+    return;
+#endif
     // own DMAs (all but the last N loads) landed, own LDS traffic drained, then the workgroup barrier: everybody's DMA of the next unit
     // is visible and everybody has finished reading the previous unit's slot.  One asm statement with a memory clobber: neither
     // hipcc's LDS reads nor the DMA statements move across it.
@@ -75,10 +101,12 @@ struct V3 {
     static constexpr int KSW = KSU / WK;                   // ... per wave
     static constexpr int UPT = 4 / KSU;                    // units per tap (a tap of a 128-byte chunk = 4 k-substeps)
     static constexpr int UPC = 9 * UPT;                    // units per chunk
-    static constexpr int NSL = (PPIX * 8 + NT - 1) / NT;   // patch slices (NT granules of 16 bytes) per chunk
+    static constexpr int SLICE_G = 512;                    // granules (16 bytes) per patch slice
+    static constexpr int GPT = SLICE_G / NT;               // ... per thread
+    static constexpr int NSL = (PPIX * 8 + SLICE_G - 1) / SLICE_G;   // patch slices per chunk
     static constexpr int NIN = XF >= 2 ? 2 : 1;            // input tensors
     static constexpr int RAWSLOTS = UPC == 18 ? 1 : 2;
-    static constexpr int SLICE_BYTES = NT * 16;
+    static constexpr int SLICE_BYTES = SLICE_G * 16;
     static constexpr int DPW = 16 / NW;                    // DMA instructions (1 KiB) per wave and unit
     static constexpr int FBE = FB / WK;                    // B fragments a wave owns in the epilogue
     // LDS map
@@ -90,8 +118,8 @@ struct V3 {
     // prologue staging: ring slot 2 + patch 1 + raw are free until the loop starts
     static constexpr int OFF_PRO = OFF_RING + 2 * V3_UNIT;
     static constexpr int PRO_SLICES = (OFF_TAB - OFF_PRO) / (NIN * SLICE_BYTES);
-    static_assert(KSW == 2 && DPW >= 1 && 16 % NW == 0 && FA % 2 == 0 && FB >= 1 && FB % WK == 0, "tile configuration");
-    static_assert(NT % 8 == 0 && PRO_SLICES >= 1 && (UPC == 18 || UPC == 9), "tile configuration");
+    static_assert(KSW >= 2 && KSW % 2 == 0 && DPW >= 1 && 16 % NW == 0 && FA % 2 == 0 && FB >= 1 && FB % WK == 0, "tile configuration");
+    static_assert(SLICE_G % NT == 0 && PRO_SLICES >= 1 && (UPC == 18 || UPC == 9), "tile configuration");
     static_assert((UPC == 18 && NSL <= 6) || (UPC == 9 && NSL <= 3), "patch slice schedule");
     static constexpr size_t smem_bytes(int Cin) { return (size_t)OFF_TAB + (size_t)xf_nk(XF) * Cin * sizeof(float); }
 
@@ -106,7 +134,7 @@ struct V3 {
     }
     static constexpr int raw_slot(int s) { return RAWSLOTS == 1 ? 0 : (s & 1); }
     // loads issued by a wave in unit U AFTER its weight DMA (the patch DMAs; issued in every chunk, also the last, so that the count is static)
-    static constexpr int pd(int U) { return (dma_slice(U) >= 0 && dma_slice(U) < NSL) ? NIN : 0; }
+    static constexpr int pd(int U) { return (dma_slice(U) >= 0 && dma_slice(U) < NSL) ? NIN * GPT : 0; }
 };
 
 // operand row of fragment f, fragment row r (gdrn_hip.h, gdrn_pack_wfrag32)
@@ -137,6 +165,24 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef V3_DBG
+    const unsigned long long t_entry = v3_clock();
+    struct DbgOut {
+        unsigned long long te, *tp, *t0, *t1; V3Dbg* d; int slot, lane;
+        unsigned long long e1 = 0, e2 = 0;
+        __device__ ~DbgOut() {
+            const unsigned long long tend = v3_clock();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long tdrain = v3_clock();
+            if (lane == 0 && g_v3_dbg) {
+                unsigned long long* o = g_v3_dbg + (size_t)slot * 12;
+                o[0] = te; o[1] = *tp; o[2] = *t0; o[3] = *t1; o[4] = tend; o[5] = d->wait_mem; o[6] = d->wait_bar;
+                unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); o[7] = xcc;
+                o[8] = e1; o[9] = e2; o[10] = tdrain;
+            }
+        }
+    };
+#endif
     const int wn = wave % WN, wm = (wave / WN) % WM, wk = wave / (WN * WM);
     const int l5 = lane & 31, hh = lane >> 5;
 
@@ -159,8 +205,16 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     const int total_units = kch * UPC;
 
     // ---- weight stream: unit g = kc*UPC + U is KSU*NFRT blocks of 1 KiB at w + g*wstride; this wave moves DPW consecutive blocks
+#ifndef V3_VAR
+#define V3_VAR 0
+#endif
+    constexpr bool HALF_DMA = (V3_VAR & 1) && K::NW == 8;   // experiment: only waves 0..3 feed the ring
+    constexpr int DPWX = HALF_DMA ? 2 * K::DPW : K::DPW;
     const int NFRT = p.w_rows >> 5;
-    const int j0 = wave * K::DPW;  // first block of this wave inside a unit: (k-substep j0 / NFRB, fragment j0 % NFRB)
+    const int j0 = (HALF_DMA ? (wave & 3) : wave) * DPWX;  // first block of this wave inside a unit: (k-substep j0 / NFRB, fragment j0 % NFRB)
+    if constexpr ((V3_VAR & 2) != 0) {
+        if (wave >= K::NW / 2) __builtin_amdgcn_s_setprio(1);
+    }
     const unsigned wlane = (unsigned)((((j0 / NFRB) * NFRT + nt * NFRB + (j0 % NFRB)) << 10) + lane * 16);
     const size_t wstride = (size_t)K::KSU * NFRT * 1024;
     const char* wg = reinterpret_cast<const char*>(p.w);
@@ -168,30 +222,32 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     auto dma_w = [&](int g, int slot) {
         const int gc = g < total_units ? g : total_units - 1;  // past the end: a harmless reload into a free slot keeps the counts static
         const char* src = wg + (size_t)gc * wstride;
+        if (HALF_DMA && wave >= 4) return;
 #pragma unroll
-        for (int i = 0; i < K::DPW; ++i) dma16(src + i * 1024, wlane, ring_a + (unsigned)(slot * V3_UNIT + i * 1024));
+        for (int i = 0; i < DPWX; ++i) dma16(src + i * 1024, wlane, ring_a + (unsigned)(slot * V3_UNIT + i * 1024));
     };
     dma_w(0, 0);
     dma_w(1, 1);
 
     // ---- patch slice geometry of this thread: slice s covers granules [s*NT, (s+1)*NT), granule id -> pixel id>>3, 16-byte part id&7
+    constexpr int GPT = K::GPT;
     const int g8 = tid & 7;
-    unsigned poff[NSL];
-    unsigned pokm = 0, pinm = 0, ppm = 0;  // per slice: input pixel inside the image / one of the tile's own pixels / slot exists
+    unsigned poff[NSL * GPT];
+    unsigned pokm = 0, pinm = 0, ppm = 0;  // per (slice, granule of the thread): input pixel inside the image / one of the tile's own pixels / slot exists
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-        const int pp = s * (NT / 8) + (tid >> 3);
+    for (int sj = 0; sj < NSL * GPT; ++sj) {
+        const int pp = sj * (NT / 8) + (tid >> 3);            // granule (sj / GPT) * 512 + (sj % GPT) * NT + tid
         const int py = pp / V3_PW, px = pp - py * V3_PW;
         const int iy = y0 + py - 1, ix = x0 + px - 1;
         const bool inpatch = pp < K::PPIX;
         const bool ok = inpatch && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
-        poff[s] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * 2u + (unsigned)(g8 * 16);
-        pokm |= ok ? (1u << s) : 0u;
-        pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= 16) ? (1u << s) : 0u;
-        ppm |= inpatch ? (1u << s) : 0u;
+        poff[sj] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * 2u + (unsigned)(g8 * 16);
+        pokm |= ok ? (1u << sj) : 0u;
+        pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= 16) ? (1u << sj) : 0u;
+        ppm |= inpatch ? (1u << sj) : 0u;
     }
-    const int pdst0 = (tid >> 3) * V3_PITCH + g8 * 16;          // LDS slot of slice s: pdst0 + s * PDSTEP
+    const int pdst0 = (tid >> 3) * V3_PITCH + g8 * 16;          // LDS slot of granule sj: pdst0 + sj * PDSTEP
     constexpr int PDSTEP = (NT / 8) * V3_PITCH;
     const char* xg = reinterpret_cast<const char*>(p.x);
     const char* xg2 = reinterpret_cast<const char*>(p.xf_x2);
@@ -212,24 +268,31 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     // by its own vmcnt wait, no barrier needed)
     auto dma_p = [&](int kc, int s, int ra) {
         const int kcc = kc < kch ? kc : kch - 1;
-        dma16(xg + kcc * 128, poff[s], lds_addr(smem + ra) + (unsigned)(wave * 1024));
-        if constexpr (NIN == 2) dma16(xg2 + kcc * 128, poff[s], lds_addr(smem + ra + K::SLICE_BYTES) + (unsigned)(wave * 1024));
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            dma16(xg + kcc * 128, poff[s * GPT + j], lds_addr(smem + ra) + (unsigned)((j * NT + wave * 64) * 16));
+            if constexpr (NIN == 2) dma16(xg2 + kcc * 128, poff[s * GPT + j], lds_addr(smem + ra + K::SLICE_BYTES) + (unsigned)((j * NT + wave * 64) * 16));
+        }
     };
     // transform slice s of chunk kc from raw area `ra` into patch buffer pb (XF 0: zero the halo outside the image)
     auto xf_p = [&](int kc, int s, int ra, int pb) {
-        if ((ppm >> s) & 1u) {
-            const uint4 v1 = *reinterpret_cast<const uint4*>(smem + ra + tid * 16);
-            uint4 t_;
-            if constexpr (XF == 0) t_ = v1;
-            else {
-                uint4 v2 = v1;
-                if constexpr (NIN == 2) v2 = *reinterpret_cast<const uint4*>(smem + ra + K::SLICE_BYTES + tid * 16);
-                t_ = xf_apply<XF>(v1, v2, xtab + kc * 64, p.Cin, xlo);
-            }
-            t_ = ((pokm >> s) & 1u) ? t_ : make_uint4(0, 0, 0, 0);   // the padding applies to the conv's input v, and v(0) != 0
-            *reinterpret_cast<uint4*>(smem + (pb ? K::OFF_P1 : K::OFF_P0) + pdst0 + s * PDSTEP) = t_;
-            if constexpr (XF != 0) {
-                if (xo != nullptr && ((pinm >> s) & 1u)) *reinterpret_cast<uint4*>(xo + (poff[s] + (unsigned)(kc * 128))) = t_;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int sj = s * GPT + j;
+            if ((ppm >> sj) & 1u) {
+                const uint4 v1 = *reinterpret_cast<const uint4*>(smem + ra + (j * NT + tid) * 16);
+                uint4 t_;
+                if constexpr (XF == 0) t_ = v1;
+                else {
+                    uint4 v2 = v1;
+                    if constexpr (NIN == 2) v2 = *reinterpret_cast<const uint4*>(smem + ra + K::SLICE_BYTES + (j * NT + tid) * 16);
+                    t_ = xf_apply<XF>(v1, v2, xtab + kc * 64, p.Cin, xlo);
+                }
+                t_ = ((pokm >> sj) & 1u) ? t_ : make_uint4(0, 0, 0, 0);   // the padding applies to the conv's input v, and v(0) != 0
+                *reinterpret_cast<uint4*>(smem + (pb ? K::OFF_P1 : K::OFF_P0) + pdst0 + sj * PDSTEP) = t_;
+                if constexpr (XF != 0) {
+                    if (xo != nullptr && ((pinm >> sj) & 1u)) *reinterpret_cast<uint4*>(xo + (poff[sj] + (unsigned)(kc * 128))) = t_;
+                }
             }
         }
     };
@@ -286,8 +349,17 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                                                                       __builtin_bit_cast(bf16x8_t, fb_[b_]), acc[a_][b_], 0, 0, 0); \
     }
 
+#ifdef V3_DBG
+    V3Dbg dbg_;
+    const unsigned long long t_pro = v3_clock();
+#endif
     // first barrier: patch 0 complete, units 0 and 1 landed
-    wait_barrier<0>();
+    wait_barrier<0>(0 V3_DBG_PASS);
+#ifdef V3_DBG
+    unsigned long long t_loop0 = v3_clock(), t_loop1 = 0, t_pro_ = t_pro;
+    dbg_.wait_mem = dbg_.wait_bar = 0;
+    DbgOut dbg_out_{t_entry, &t_pro_, &t_loop0, &t_loop1, &dbg_, (int)blockIdx.x * K::NW + wave, lane};
+#endif
     dma_w(2, 2);
     {
         const unsigned char* pc0 = smem + K::OFF_P0 + lbase;
@@ -305,7 +377,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
             constexpr int U = decltype(Uc)::value;
             if constexpr (U > 0) {
                 // [A][B] weights of unit U+1 (issued one unit ago) landed everywhere; slot (U-1)%3 is free
-                wait_barrier<K::pd(U - 1)>();
+                wait_barrier<K::pd(U - 1)>(0 V3_DBG_PASS);
                 // [C] refill it with unit U+2
                 dma_w(gbase + U + 2, (U + 2) % V3_RING);
             }
@@ -317,29 +389,40 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                 if constexpr (K::xf_slice(U) >= 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw slot's reads are done
                 dma_p(kc + 1, K::dma_slice(U), K::OFF_RAW + K::raw_slot(K::dma_slice(U)) * NIN * K::SLICE_BYTES);
             }
-            // [E] this unit's MFMAs; the other k-substep's fragments and the next unit's first fragments load underneath
-            V3_LDA(fa1, U, 1)
-            V3_LDB(fb1, pcur, U, 1)
-            V3_MM(fa0, fb0)
-            if constexpr (U + 1 < UPC) {
-                V3_LDA(fa0, U + 1, 0)
-                V3_LDB(fb0, pcur, U + 1, 0)
-            } else {
-                V3_LDA(fa0, 0, 0)              // UPC % 3 == 0: unit 0 of the next chunk sits in slot 0
-                V3_LDB(fb0, pnxt, 0, 0)
-            }
-            V3_MM(fa1, fb1)
+            // [E] this unit's MFMAs; the next k-substep's fragments (the next unit's first ones at the end) load underneath
+            auto sub = [&](auto Sc) {
+                constexpr int SL = decltype(Sc)::value;
+                if constexpr (SL + 1 < K::KSW) {
+                    if constexpr (SL % 2 == 0) { V3_LDA(fa1, U, SL + 1) V3_LDB(fb1, pcur, U, SL + 1) }
+                    else { V3_LDA(fa0, U, SL + 1) V3_LDB(fb0, pcur, U, SL + 1) }
+                } else if constexpr (U + 1 < UPC) {
+                    V3_LDA(fa0, U + 1, 0)
+                    V3_LDB(fb0, pcur, U + 1, 0)
+                } else {
+                    V3_LDA(fa0, 0, 0)              // UPC % 3 == 0: unit 0 of the next chunk sits in slot 0
+                    V3_LDB(fb0, pnxt, 0, 0)
+                }
+                // the loads above are issued BEFORE this k-substep's MFMAs and stay there: left alone, hipcc sinks every ds_read to just in
+                // front of its first use and each group of MFMAs starts with an exposed LDS round trip (measured: 46 cycles per MFMA)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SL % 2 == 0) { V3_MM(fa0, fb0) } else { V3_MM(fa1, fb1) }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            static_for<K::KSW>(sub);
         };
         static_for<UPC>(unit);
         // chunk boundary = the barrier of the next chunk's unit 0
         if (more_p) {
-            wait_barrier<K::pd(UPC - 1)>();
+            wait_barrier<K::pd(UPC - 1)>(0 V3_DBG_PASS);
             dma_w(gbase + UPC + 2, 2);   // (UPC + 2) % 3 == 2
         }
     }
 #undef V3_LDA
 #undef V3_LDB
 #undef V3_MM
+#ifdef V3_DBG
+    t_loop1 = v3_clock();
+#endif
     // every DMA (incl. the reloads past the end) landed and every wave is done with the LDS operands: LDS is scratch from here
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -397,14 +480,19 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     float* cst = reinterpret_cast<float*>(smem);                 // [4][BN] per-channel constants of the fused BatchNorm backward
     float* part = reinterpret_cast<float*>(smem) + 4 * BN;       // [WN*WK][2][BN]
     const int grp = wn * WK + wk;
-    auto red_put = [&](int c, float v1, float v2) {              // c: channel inside the tile
-        v1 = row16_sum(v1);
-        v2 = row16_sum(v2);
-        v1 += __shfl_xor(v1, 16, 64);
-        v2 += __shfl_xor(v2, 16, 64);
-        if (l5 == 0) {
-            part[(grp * 2 + 0) * BN + c] = v1;
-            part[(grp * 2 + 1) * BN + c] = v2;
+    // sums of (v1, v2) over the 32 lanes of a half wave (= the 32 pixels of a fragment): v_permlane16_swap pairs the two 16-lane rows
+    // of the half -- afterwards the even rows hold v1(row 0) + v1(row 1), the odd rows v2(row 0) + v2(row 1) -- then four DPP adds
+    // inside the row: 6 VALU per channel (the ds_bpermute version spent 30 k cycles per workgroup here)
+    auto pair_sum = [&](float v1, float v2) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v1), __float_as_uint(v2), false, false);
+        return row16_sum(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+    };
+    const int qsel = (lane >> 4) & 1;                            // this lane's row holds sum 0 (even rows) or sum 1 (odd rows)
+    // NV consecutive channels starting at tile channel c: lane 0 of every row stores its row's totals
+    auto red_put = [&](int c, const float* w, int nv) {
+        if ((lane & 15) == 0) {
+            float* dst = part + (grp * 2 + qsel) * BN + c;
+            for (int i = 0; i < nv; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(w[i], w[i + 1], w[i + 2], w[i + 3]);
         }
     };
     auto put_rows = [&](float* rows) {
@@ -491,8 +579,10 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                     }
                     *reinterpret_cast<uint4*>(yb + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)p.y_cs + (unsigned)(cw + ap * 64)) * 2u + q * 16) = Vec16<bf16_t>::pack(v);
                 }
+                float wsum[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) red_put(cl + e, t1[e], t2[e]);
+                for (int e = 0; e < 8; ++e) wsum[e] = pair_sum(t1[e], t2[e]);
+                red_put(cl, wsum, 8);
             }
         }
         put_rows(p.bnb_rows);
@@ -501,15 +591,24 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
 
     if (p.stats != nullptr) {
 #pragma unroll
-        for (int a = 0; a < FA; ++a)
+        for (int a = 0; a < FA; ++a) {
+            float wsum[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float u = 0.f, q = 0.f;
 #pragma unroll
                 for (int be = 0; be < FBE; ++be) { const float v = acc[a][be][i]; u += v; q += v * v; }
-                red_put(cwl + (a >> 1) * 64 + (a & 1) * 16 + i, u, q);
+                wsum[i] = pair_sum(u, q);
             }
+            red_put(cwl + (a >> 1) * 64 + (a & 1) * 16, wsum, 16);
+        }
+#ifdef V3_DBG
+        dbg_out_.e1 = v3_clock();
+#endif
         put_rows(p.stats);
+#ifdef V3_DBG
+        dbg_out_.e2 = v3_clock();
+#endif
     }
     const bool relu = p.act == 1;
     const char* ab2 = LEAN ? nullptr : ab;
@@ -567,6 +666,8 @@ int launch_v3(const gdrn_conv_params& p, int N, hipStream_t st) {
 template <int XF>
 int launch_v3_cfg(const gdrn_conv_params& p, int cfg, int N, hipStream_t st) {
     if (cfg == 1) return launch_v3<16, 256, 2, 4, 1, XF>(p, N, st);
+    if (cfg == 3) return launch_v3<16, 256, 2, 2, 1, XF>(p, N, st);   // 4 waves, one per SIMD, 128 x 128 wave tiles
+    if (cfg == 4) return launch_v3<8, 128, 2, 2, 1, XF>(p, N, st);    // 4 waves, one per SIMD, 64 x 64 wave tiles
     return launch_v3<8, 128, 2, 2, 2, XF>(p, N, st);
 }
 
@@ -579,21 +680,33 @@ int gdrn_v3_config(const gdrn_conv_params* p) {
     if (p->dtype != GDRN_DT_BF16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
     if (p->act > 1 || p->out_f32) return 0;
     const int N = p->M / (p->Ho * p->Wo);
-    const char* force = getenv("GDRN_V3_CFG");
-    if (force && force[0] == '2') return 2;
+    const char* force = getenv("GDRN_V3_CFG");   // bring-up: "ab" = configuration a for the large-map choice, b for the small-map one
+    const int f_big = (force && force[0] >= '1' && force[0] <= '4') ? force[0] - '0' : 1;
+    const int f_small = (force && force[0] && force[1] >= '2' && force[1] <= '4' && force[1] != '3') ? force[1] - '0' : 2;
     // 256-channel tile when the grid still has at least one workgroup per CU: the patch (+ transform) is staged once per pixel tile
-    if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= 256) {
-        if (p->xf_mode == 4 && (size_t)V3<16, 256, 2, 4, 1, 4>::smem_bytes(p->Cin) > 160 * 1024) return 2;
-        return 1;
+    const char* mw = getenv("GDRN_V3_MINWG");   // tests: exercise the 256-channel tile on small grids
+    const long long min_wg = mw ? atoll(mw) : 256;
+    if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= min_wg) {
+        if (p->xf_mode == 4 && (size_t)V3<16, 256, 2, 4, 1, 4>::smem_bytes(p->Cin) > 160 * 1024) return f_small;
+        if (f_big == 1 || f_big == 3) return f_big;
+        return f_small;
     }
-    return 2;
+    return f_small;
+}
+
+// does the library prefer this kernel over the first halo kernel for the launch in p?  Measured (tools/v3check.py, bs = 64, profiles/r03_*):
+// the 16x16x256 tile wins where the first kernel pays for the in-loop operand transform (xf modes 1-4: x1.00-1.09) and loses on plain
+// launches (x0.85-0.90); the 8x16x128 K-split tile loses everywhere (x0.68-0.98) and only serves launches the 256-channel tile cannot take.
+int gdrn_v3_preferred(const gdrn_conv_params* p) {
+    const int cfg = gdrn_v3_config(p);
+    return (cfg == 1 || cfg == 3) && p->xf_mode != 0;
 }
 
 int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn) {
     const int cfg = gdrn_v3_config(p);
-    *th = cfg == 1 ? 16 : (cfg == 2 ? 8 : 0);
+    *th = (cfg == 1 || cfg == 3) ? 16 : (cfg ? 8 : 0);
     *tw = cfg ? 16 : 0;
-    *bn = cfg == 1 ? 256 : (cfg == 2 ? 128 : 0);
+    *bn = (cfg == 1 || cfg == 3) ? 256 : (cfg ? 128 : 0);
     return cfg;
 }
 
@@ -607,11 +720,15 @@ extern "C" int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, 
     return GDRN_OK;
 }
 
+#ifdef V3_DBG
+extern "C" int gdrn_v3_set_dbg(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_v3_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -3; }
+extern "C" int gdrn_v3_launch_c(const gdrn_conv_params* pp, void* stream);
+#endif
 int gdrn_v3_launch(const gdrn_conv_params* pp, void* stream) {
     const gdrn_conv_params& p = *pp;
     const int cfg = gdrn_v3_config(pp);
     if (cfg == 0) return GDRN_ERR_SHAPE;
-    const int bn = cfg == 1 ? 256 : 128;
+    const int bn = (cfg == 1 || cfg == 3) ? 256 : 128;
     if ((p.x_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || (p.bnb_x && (p.bnb_cs & 7))) return GDRN_ERR_SHAPE;  // 16-byte accesses
     if (p.w_rows < p.Cout || (p.w_rows & 63) || (p.Cout % bn)) return GDRN_ERR_SHAPE;
     const int hw = p.Ho * p.Wo;
@@ -639,3 +756,8 @@ int gdrn_v3_launch(const gdrn_conv_params* pp, void* stream) {
         default: return launch_v3_cfg<4>(p, cfg, N, st);
     }
 }
+
+#ifdef V3_DBG
+extern "C" int gdrn_v3_launch_c(const gdrn_conv_params* pp, void* stream) { return gdrn_v3_launch(pp, stream); }
+extern "C" int gdrn_v3_tile_c(const gdrn_conv_params* p, int* th, int* tw, int* bn) { return gdrn_v3_tile(p, th, tw, bn); }
+#endif

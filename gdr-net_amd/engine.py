@@ -126,7 +126,7 @@ class Engine:
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
     # ------------------------------------------------------------------------------------------ layers
-    def _add_conv(self, key, kind, src_names, O, I, KH, KW, in_ch=None, out_ch=None, s2=False):
+    def _add_conv(self, key, kind, src_names, O, I, KH, KW, in_ch=None, out_ch=None, s2=False, hw=0):
         """kind: conv | convT | stem | fc1 | fc.  in_ch/out_ch: channel counts of the activation buffers
         (>= I / O, padded).  Packed operands:
           wf [rows_f][KK][cin_f]  forward operand          (rows = out channels)
@@ -161,6 +161,9 @@ class Engine:
             L.wd = self._zeros(L.rows_d, KK, out_ch)
             L.dwp_shape = (O, KK, in_ch)
         L.wfF = L.wdF = None
+        # operand layouts of the two halo operands: 1 = gdrn_pack_wfrag, 2 = gdrn_pack_wfrag32 (second-generation kernel); chosen by the
+        # library per launch (gdrn_conv3x3_wfrag) when the first plan that uses the operand is built (Plan._conv)
+        L.wfmt = {"f": 0, "d": 0}
         if kind == "conv" and KK == 9 and not s2 and self.dt == BF16:  # halo-kernel operands (fragment-major)
             L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
         self.layers[key] = L
@@ -172,15 +175,17 @@ class Engine:
         for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
             for b in range(nb):
                 p = f"backbone.layer{li}.{b}"
-                self._add_conv(p + ".conv1", "conv", [p + ".conv1.weight"], pl, inpl, 3, 3, s2=(b == 0 and li > 1))
-                self._add_conv(p + ".conv2", "conv", [p + ".conv2.weight"], pl, pl, 3, 3)
+                self._add_conv(p + ".conv1", "conv", [p + ".conv1.weight"], pl, inpl, 3, 3, s2=(b == 0 and li > 1), hw=64 >> (li - 1))
+                self._add_conv(p + ".conv2", "conv", [p + ".conv2.weight"], pl, pl, 3, 3, hw=64 >> (li - 1))
                 if (p + ".downsample.0.weight") in self.P:
                     self._add_conv(p + ".downsample.0", "conv", [p + ".downsample.0.weight"], pl, inpl, 1, 1, s2=True)
                 inpl = pl
         h = "rot_head_net.features."
         self._add_conv(h + "0", "convT", [h + "0.weight"], 256, 512, 3, 3)
-        for ci, _, _ in HEAD_CONVS:
-            self._add_conv(h + str(ci), "conv", [h + f"{ci}.weight"], 256, 256, 3, 3)
+        hw = 16
+        for ci, _, up in HEAD_CONVS:
+            hw = hw * 2 if up else hw
+            self._add_conv(h + str(ci), "conv", [h + f"{ci}.weight"], 256, 256, 3, 3, hw=hw)
         self.head_c = 1 + 3 + self.nreg + 1
         self._add_conv(h + "23", "conv", [h + "23.weight"], self.head_c, 256, 1, 1, out_ch=128)
         q = "pnp_net.features."
@@ -249,7 +254,7 @@ class Engine:
                 L = f.layer
                 src = self.P[L.src[0]]
                 halo_only = self.use_halo and L.wfF is not None
-                for dst, frag in ((L.wf_e, 0), (L.wfF_e, 1)):
+                for dst, frag in ((L.wf_e, 0), (L.wfF_e, L.wfmt.get("e", 0) or 1)):
                     if dst is None or (halo_only and not frag):
                         continue
                     A1, A2, T, B, A1v, A2v, Bv, s1, s2, stt, sb, flip = self._pack_args(L, "f")
@@ -278,7 +283,7 @@ class Engine:
                 continue
             src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
             halo_only = self.use_halo and L.wfF is not None  # both conv passes read the fragment-major copies
-            for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, 1), ("d", L.wdF, 1)):
+            for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, L.wfmt["f"] or 1), ("d", L.wdF, L.wfmt["d"] or 1)):
                 if dst is None or (halo_only and not frag):
                     continue
                 A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip = self._pack_args(L, which)
@@ -298,7 +303,7 @@ class Engine:
         """(Re)build the kernel-layout operand copies of the weights after a parameter update: one multi-tensor
         launch (+ the stem's special layout) instead of ~170 per-tensor launches."""
         sig = tuple(p._version for p in self.P.values())
-        if not force and self._versions.get("sig") == sig:
+        if not force and self._versions.get("sig") == sig and not getattr(self, "_pack_dirty", False):
             return
         self._versions["sig"] = sig
         st = self._stream()
@@ -311,8 +316,9 @@ class Engine:
         check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
         if self.stem_direct:
             check(lib.gdrn_pack_stem_w32(ptr(self.P[Ls.src[0]]), ptr(self.stem_w32), self.dt, st), "pack_stem_w32")
-        if not hasattr(self, "_pack_tasks"):
+        if not hasattr(self, "_pack_tasks") or getattr(self, "_pack_dirty", False):
             self._build_pack_table()
+            self._pack_dirty = False
         check(lib.gdrn_pack_multi(ptr(self._pack_tasks), ptr(self._pack_starts), self._pack_n[0], self._pack_n[1], self.dt, st), "pack_multi")
 
     # ------------------------------------------------------------------------------------------ plans
@@ -375,8 +381,19 @@ class Plan:
         cp.M = self.B * (Ho // 2) * (Wo // 2) if mode == 1 else self.B * Ho * Wo
         cp.w_rows = rows or L.rows_f
         cp.dtype = e.dt
+        if bnb is not None and bnb[2] is not None:
+            cp.bnb_mask = ptr(bnb[2])
+        if xf is not None:
+            cp.xf_mode = xf["mode"]     # (the library's kernel choice depends on addend, stored mask and operand transform)
         self.keep.append(cp)
         ref = C.byref(cp)
+        if e.use_halo and L.kind == "conv" and L.wfF is not None:
+            which = "e" if evalw else ("f" if w is None else "d")
+            want = int(e.lib.gdrn_conv3x3_wfrag(ref))
+            if not L.wfmt.get(which):
+                L.wfmt[which] = want if want in (1, 2) else 1
+                e._pack_dirty = True    # the operand copy is (re)built in that layout by the next repack
+            cp.w_frag = L.wfmt[which]  # an operand has ONE layout: later plans (other batch sizes) follow the first one
         # 3x3 stride-1 layers (forward and data-gradient) run on the halo-tiled kernel
         th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
         e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
@@ -443,7 +460,12 @@ class Plan:
                 sp = 8 * 8  # Hin*Win*Cin*Cout*k^2
             macs = self.B * sp * L.O * L.I * L.KK
         dn = "bf16" if e.dt == BF16 else "f32"
-        kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>" if use_halo else f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
+        if use_halo and cp.w_frag == 2:
+            kname = f"conv3x3_v3_kernel<{th.value}x{tw.value}x{hbn.value},xf{cp.xf_mode}>"
+        elif use_halo:
+            kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>"
+        else:
+            kname = f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
         run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + (":dgrad" if w is not None else ""))
         return run, cp
 

@@ -85,6 +85,8 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *      weight-gradient launch / the next residual without a separate pass.  Replaces gdrn_bn_apply /
  *      gdrn_bn_bwd_apply launches between two halo convs (BasicBlock, cdpn_rot_head_region.py:103-123 and backward).
  */
+/* w_frag (gdrn_conv3x3_halo only): layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments, first halo kernel), 2: gdrn_pack_wfrag32
+ * (second-generation kernel, see gdrn_pack_wfrag32 below). */
 typedef struct gdrn_conv_params {
     const void* x;
     const void* w;
@@ -100,7 +102,7 @@ typedef struct gdrn_conv_params {
     const float* bnb_shift;
     float* bnb_rows;
     int bnb_cs;
-    int w_frag;   /* gdrn_conv3x3_halo: layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments), 2: gdrn_pack_wfrag32 (see below) */
+    int w_frag;
     int Hi, Wi, Cin, x_cs;
     int Ho, Wo, Cout, y_cs, add_cs;
     int KH, KW, stride, pad;

@@ -62,12 +62,21 @@ def test_conv_forward(H, dt, case):
 
 
 HALO_CASES = [(2, 64, 64, 16), (1, 128, 128, 32), (3, 256, 256, 16), (2, 512, 512, 8), (1, 256, 256, 64), (2, 64, 128, 24)]
+# second-generation kernel (conv3x3_v3.hip, v3=True): Cout % 128 == 0, W % 16 == 0.  The library gives the 16x16x256 tile only grids of
+# >= 256 workgroups; GDRN_V3_MINWG=1 (fixture below) lets the 256-channel cases of these lists run it on small grids, the other cases run
+# the 8x16x128 K-split tile
+V3_CASES = [(1, 128, 128, 32), (3, 256, 256, 16), (1, 128, 256, 32), (2, 512, 128, 16), (2, 256, 256, 32), (1, 512, 256, 48)]
+
+
+@pytest.fixture(autouse=True)
+def _v3_small_grids(monkeypatch):
+    monkeypatch.setenv("GDRN_V3_MINWG", "1")
 
 
 @pytest.mark.parametrize("dt", [BF16])
-@pytest.mark.parametrize("case", HALO_CASES)
-def test_conv3x3_halo_forward_and_dgrad(H, dt, case):
-    """halo-tiled 3x3 s1 kernel: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights)."""
+@pytest.mark.parametrize("v3,case", [(False, c) for c in HALO_CASES] + [(True, c) for c in V3_CASES])
+def test_conv3x3_halo_forward_and_dgrad(H, dt, case, v3):
+    """halo-tiled 3x3 s1 kernels: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights)."""
     B, I, O, Hh = case
     x = H.rounded(H.randn(1, B, I, Hh, Hh), dt).requires_grad_(True)
     w = H.rounded(H.randn(2, O, I, 3, 3) / math.sqrt(I * 9), dt)
@@ -76,16 +85,20 @@ def test_conv3x3_halo_forward_and_dgrad(H, dt, case):
     dy = H.rounded(H.randn(4, B, O, Hh, Hh), dt)
     ref.backward(dy)
     xd, wp = H.nhwc(x.detach(), dt), H.pack_fwd(w, dt)
-    y, stats = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True)
+    y, stats = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True, v3=v3)
     assert H.rel(H.nchw(y, O), ref) < TOL[dt]
     st = stats.sum(0).cpu()
     assert H.rel(st[0], ref.detach().sum((0, 2, 3))) < 1e-3 + TOL[dt]
     assert H.rel(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < 1e-3
-    y2, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), act=1, halo=True)
+    y2, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), act=1, halo=True, v3=v3)
     assert H.rel(H.nchw(y2, O), F.relu(ref.detach() + add)) < TOL[dt]
-    wd = H.pack_dgrad(w, dt, flip=1)
-    dx, _ = H.conv_gemm(H.nhwc(dy, dt), wd, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True)
-    assert H.rel(H.nchw(dx, I), x.grad) < TOL[dt]
+    bias = H.randn(5, O)
+    y3, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, bias=bias.to(H.DEV), act=1, halo=True, v3=v3)
+    assert H.rel(H.nchw(y3, O), F.relu(ref.detach() + bias.view(1, -1, 1, 1))) < TOL[dt]
+    if I % 128 == 0 or not v3:
+        wd = H.pack_dgrad(w, dt, flip=1)
+        dx, _ = H.conv_gemm(H.nhwc(dy, dt), wd, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3)
+        assert H.rel(H.nchw(dx, I), x.grad) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -312,8 +325,9 @@ def test_conv3x3_wgrad_halo_conv_transpose_and_padded_channels(H):
 
 
 @pytest.mark.parametrize("mask_kind", ["stored", "affine", "none"])
-@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8)])
-def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
+@pytest.mark.parametrize("v3,case", [(False, (2, 64, 64, 16)), (False, (1, 128, 256, 32)), (False, (3, 256, 128, 8)),
+                                     (True, (1, 128, 256, 32)), (True, (3, 256, 128, 16)), (True, (2, 256, 256, 32))])
+def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind, v3):
     """data-gradient launch with the fused BatchNorm(+ReLU) backward prologue: masked gradient + the two per-channel
     sums == conv -> mask -> gdrn_bn_bwd_reduce semantics, computed with torch."""
     B, I, O, Hh = case
@@ -341,10 +355,17 @@ def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind):
         bnb["mask"] = H.nhwc(ystored, dt)
     elif mask_kind == "affine":
         bnb["scale"], bnb["shift"] = d(scale), d(shift)
-    y, sums = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True, bnb=bnb)
+    y, sums = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True, bnb=bnb, v3=v3)
     assert H.rel(H.nchw(y, O), gm) < 1e-2
     got = sums.sum(0).cpu()
     assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
+    if v3 and mask_kind != "stored":
+        # without addend and stored mask the 256-channel tile takes the launch when the grid is large enough (the lean epilogue)
+        y, sums = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, bnb=bnb, v3=True)
+        g0 = (g - add) * m
+        assert H.rel(H.nchw(y, O), g0) < 1e-2
+        got = sums.sum(0).cpu()
+        assert H.rel(got[0], g0.sum((0, 2, 3))) < 1e-2 and H.rel(got[1], (g0 * xhat).sum((0, 2, 3))) < 1e-2
 
 
 @pytest.mark.parametrize("kind", ["out1x1", "s2_dgrad", "convT_dgrad"])
@@ -402,8 +423,9 @@ def test_conv_gemm_fused_bn_backward_stats(H, kind):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
-@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (1, 256, 256, 64), (2, 512, 512, 8)])
-def test_conv3x3_halo_operand_transform(H, case, mode):
+@pytest.mark.parametrize("v3,case", [(False, c) for c in [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (1, 256, 256, 64), (2, 512, 512, 8)]]
+                         + [(True, c) for c in [(1, 128, 256, 32), (3, 256, 128, 16), (2, 64, 128, 48), (2, 256, 256, 32), (1, 512, 256, 16)]])
+def test_conv3x3_halo_operand_transform(H, case, mode, v3):
     """xf_mode 1-4 (gdrn_hip.h): the conv consumes v(x, x2) evaluated while the patch is staged -- the BatchNorm forward apply
     (+residual, +ReLU) of the producer / the BatchNorm backward apply in front of a data gradient -- and xf_out receives v.
     Reference: v in fp32 with torch, rounded to bf16, zero padding applied to v, F.conv2d."""
@@ -440,7 +462,7 @@ def test_conv3x3_halo_operand_transform(H, case, mode):
         xf.update(x2=H.nhwc(x2, dt), b=d(b))
     if mode == 4:
         xf.update(msc=d(msc), msh=d(msh))
-    y, stats = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True, xf=xf)
+    y, stats = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, want_stats=True, halo=True, xf=xf, v3=v3)
     # v itself: identical up to fp32 association (fma) -> at most rare one-ulp bf16 flips
     got_v = H.nchw(out, I)
     assert torch.isfinite(got_v).all()
@@ -452,12 +474,13 @@ def test_conv3x3_halo_operand_transform(H, case, mode):
     # without xf_out and with NULL a / b (= 1): same conv result
     if mode == 2:
         xf2 = dict(mode=2, relu=True, x2=H.nhwc(x2, dt), c=d(c))
-        y2, _ = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, xf=xf2)
+        y2, _ = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, xf=xf2, v3=v3)
         ref2 = F.conv2d(H.rounded(F.relu(x2 + (x + V(c))), dt), w, None, 1, 1)
         assert H.rel(H.nchw(y2, O), ref2) < TOL[dt]
 
 
-def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H):
+@pytest.mark.parametrize("v3", [False, True])
+def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H, v3):
     """the launch the engine uses for a BasicBlock conv1 data gradient: xf_mode 3 prologue (bn1 backward apply) + addend
     (residual-path gradient) + the fused mask / BatchNorm-backward sums epilogue of the previous block's bn2."""
     B, I, O, Hh = 2, 128, 128, 16
@@ -478,7 +501,7 @@ def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H):
     out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
     y, sums = H.conv_gemm(H.nhwc(g, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True,
                           bnb=dict(x=H.nhwc(bx, dt), mask=H.nhwc(ystored, dt), mean=d(mean), invstd=d(invstd)),
-                          xf=dict(mode=3, relu=False, x2=H.nhwc(raw, dt), a=d(ka), b=d(kb), c=d(kc), out=out))
+                          xf=dict(mode=3, relu=False, x2=H.nhwc(raw, dt), a=d(ka), b=d(kb), c=d(kc), out=out), v3=v3)
     assert H.rel(H.nchw(out, I), v) < 2e-3
     assert H.rel(H.nchw(y, O), gg) < 1e-2
     got = sums.sum(0).cpu()

@@ -16,17 +16,20 @@ dev = "cuda"
 torch.manual_seed(0)
 
 
+G = [None]
+
+
 def mk(B, Hh, C_, scale=1.0):
-    return (torch.randn(B, Hh, Hh, C_, device=dev) * scale).to(torch.bfloat16)
+    return (torch.randn(B, Hh, Hh, C_, device=dev, generator=G[0]) * scale).to(torch.bfloat16)
 
 
 def vec(C_, lo, hi):
-    return (torch.rand(C_, device=dev) * (hi - lo) + lo).float()
+    return (torch.rand(C_, device=dev, generator=G[0]) * (hi - lo) + lo).float()
 
 
 def run(kind, B, C_, Hh, v3, reps):
     """kind: plain | stats | relu_bias | addend | xf1 | xf2 | xf3 | xf4 | bnb | bnb_mask_add | xf3_bnb"""
-    g = torch.Generator(device=dev).manual_seed(1)
+    g = G[0] = torch.Generator(device=dev).manual_seed(1)   # the same operands for both kernels
     x = (torch.randn(B, Hh, Hh, C_, device=dev, generator=g)).to(torch.bfloat16)
     w = (torch.randn(C_, 9, C_, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     kw = dict(halo=True, v3=v3, reps=reps)
@@ -71,6 +74,15 @@ def rel(a, b):
 
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    bad = 0
+    for cfgs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["12"]):
+        os.environ["GDRN_V3_CFG"] = cfgs
+        print("==== GDRN_V3_CFG=%s (large-map / small-map tile configuration)" % cfgs, flush=True)
+        bad += main1(quick)
+    return bad
+
+
+def main1(quick):
     # correctness: small batch, every mode, both tile configurations (the 256-channel tile needs >= 256 workgroups: B*H*W/256 >= 256)
     cases = []
     for kind in ("plain", "stats", "relu_bias", "xf1", "xf2", "xf3", "xf4", "bnb", "xf3_bnb"):
