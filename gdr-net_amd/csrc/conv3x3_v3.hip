@@ -687,7 +687,9 @@ int gdrn_v3_config(const gdrn_conv_params* p) {
     const char* mw = getenv("GDRN_V3_MINWG");   // tests: exercise the 256-channel tile on small grids
     const long long min_wg = mw ? atoll(mw) : 256;
     if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= min_wg) {
-        if (p->xf_mode == 4 && (size_t)V3<16, 256, 2, 4, 1, 4>::smem_bytes(p->Cin) > 160 * 1024) return f_small;
+        // LDS of the 16x16x256 tile: two patches + ring + raw staging (one or two inputs) + the transform's per-channel table
+        const size_t need = (p->xf_mode >= 2 ? V3<16, 256, 2, 4, 1, 2>::OFF_TAB : V3<16, 256, 2, 4, 1, 0>::OFF_TAB) + (size_t)xf_nk(p->xf_mode) * p->Cin * sizeof(float);
+        if (need > 160 * 1024) return f_small;
         if (f_big == 1 || f_big == 3) return f_big;
         return f_small;
     }

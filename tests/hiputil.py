@@ -103,6 +103,13 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     cp.M = B * (Ho // 2) * (Wo // 2) if mode == 1 else B * Ho * Wo
     cp.w_rows, cp.dtype = w.shape[0], dt
     cp.w_frag = 2 if (halo and v3) else 0
+    # (every operand goes in before the tile / statistics-row queries: the second-generation kernel's tile depends on them)
+    if bnb is not None:
+        cp.bnb_mask = ptr(bnb.get("mask"))
+    if xf is not None:
+        cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
+        cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
+        cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
     stats = None
     if want_stats:
         rows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
@@ -115,10 +122,6 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
         cp.bnb_rows = ptr(rows_t)
         stats = rows_t  # per-tile rows [nrows][2][Cout]: callers sum over dim 0
-    if xf is not None:
-        cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
-        cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
-        cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
     fn = lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm
     check(fn(C.byref(cp), stream()), "conv")
     torch.cuda.synchronize()
