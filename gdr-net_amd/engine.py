@@ -800,10 +800,12 @@ class Plan:
         s0 = self.bn["backbone.bn1"]
         self.fwd.append(lambda st, ctx: check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw0), ptr(s0.scale), ptr(s0.shift), ptr(p0), ptr(idx0),
                                                                            B, 128, 128, 64, e.dt, st), "bn_relu_maxpool"))
+        self.tensors.update({"stem.raw": raw0, "stem.pool": p0})
         if T:
             d_p0 = E(B, 64, 64, 64)
             g_stem = E(B, 128, 128, 64)
             d_raw0 = g_stem  # in place
+            self.tensors.update({"stem.d_pool": d_p0, "stem.g": g_stem})
             # with the fused stem weight gradient the max-pool backward also emits the BatchNorm-backward sums of the gradient it
             # writes (one partial row per workgroup): no separate reduce pass over the two 134 MB tensors
             mp_rows = int(lib.gdrn_maxpool_bwd_rows(B, 128, 128, 64, e.dt)) if e.stem_wgrad else 0
@@ -878,6 +880,9 @@ class Plan:
                 xf_out = nxt1 is not None and self._xf_ok(nxt1, 2, Ho)
                 if Ld is not None:
                     rawd, idn = E(B, Ho, Ho, pl), (None if xf_out else E(B, Ho, Ho, pl))
+                    self.tensors[pfx + ".rawd"] = rawd
+                    if idn is not None:
+                        self.tensors[pfx + ".idn"] = idn
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
                     op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
                     self.fwd.append(op)
@@ -917,6 +922,7 @@ class Plan:
                         grp = self._bn_bwd(pfx + ".bn2", d_out, None, raw2, d_raw2, prereduced=True)
                     else:
                         g2 = E(B, Ho, Ho, pl)
+                        self.tensors[pfx + ".g2"] = g2
                         grp = self._bn_bwd(pfx + ".bn2", d_out, out, raw2, d_raw2, g_out=g2)
                     grp.append(self._wgrad(L2, a1, d_raw2, Ho, Ho, Ho, Ho, 1, 1, pl, pl, pl, pl))
                     grp.append(self._unpack(L2))
@@ -933,6 +939,7 @@ class Plan:
                     grp.append(self._unpack(L1))
                     if Ld is not None:
                         d_rawd, d_xd = E(B, Ho, Ho, pl), E(B, Hc, Hc, inpl)
+                        self.tensors.update({pfx + ".d_rawd": d_rawd, pfx + ".d_xd": d_xd})
                         grp += self._bn_bwd(pfx + ".downsample.1", g2, None, rawd, d_rawd)
                         grp.append(self._wgrad(Ld, x, d_rawd, Hc, Hc, Ho, Ho, stride, 0, inpl, pl, inpl, pl))
                         grp.append(self._unpack(Ld))
@@ -961,6 +968,7 @@ class Plan:
         h = "rot_head_net.features."
         LT = e.layers[h + "0"]
         rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
+        self.tensors.update({h + "0.raw": rawt, h + "0.act": h0})
         xf_first = (not FOLD) and (not HEAD_CONVS[0][2]) and self._xf_ok(e.layers[h + str(HEAD_CONVS[0][0])], 1, 16)
         if FOLD:
             self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
@@ -970,6 +978,7 @@ class Plan:
             self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, None if xf_first else h0)
         if T:
             d_h0, d_rawt = E(B, 16, 16, 256), E(B, 16, 16, 256)
+            self.tensors.update({h + "0.d_act": d_h0, h + "0.d_raw": d_rawt})
             pre_t = (not HEAD_CONVS[0][2]) and self._fusable(e.layers[h + str(HEAD_CONVS[0][0])])
             grp = self._bn_bwd(h + "1", d_h0, h0, rawt, d_rawt, affine_mask=True, prereduced=pre_t)
             # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
@@ -989,9 +998,11 @@ class Plan:
             if up:
                 assert pend_h is None
                 u = E(B, 2 * Hh, 2 * Hh, 256)
+                self.tensors[h + f"{ci}.up"] = u
                 self.fwd.append(lambda st, ctx, hx=hx, u=u, Hh=Hh: check(lib.gdrn_upsample2x_fwd(ptr(hx), ptr(u), B, Hh, Hh, 256, e.dt, st), "upsample_fwd"))
                 if T:
                     d_u = E(B, 2 * Hh, 2 * Hh, 256)
+                    self.tensors[h + f"{ci}.d_up"] = d_u
                     up_bwd = (lambda st, ctx, d_u=d_u, d_hx=d_hx, Hh=Hh: check(lib.gdrn_upsample2x_bwd(ptr(d_u), ptr(d_hx), B, Hh, Hh, 256, e.dt, st), "upsample_bwd"))
                     d_in = d_u
                 xin, Hh = u, 2 * Hh
@@ -1046,6 +1057,7 @@ class Plan:
         self.fwd.append(op)
         self.pnp_in = e._zeros(M, 128)   # channels >= 5 + nreg stay zero (PREZEROED: the kernels do not re-write the pad)
         self.keep.append(self.pnp_in)
+        self.tensors.update({"head_out": self.head_out, "pnp_in": self.pnp_in})
         if WL:
             self.acc = E(8, dtype=torch.float64)
             self.losses = e._zeros(8, dtype=F32t)
@@ -1061,6 +1073,7 @@ class Plan:
             self.keep.append(self.d_head)
             self.d_pnp_in = E(M, 128)
             self.gw = e._zeros(8, dtype=F32t)
+            self.tensors.update({"d_head": self.d_head, "d_pnp_in": self.d_pnp_in})
             grp = [lambda st, ctx: check(lib.gdrn_head_tail_bwd(ptr(self.head_out), self.hs, ptr(self.pnp_in), ptr(self.d_pnp_in), 128,
                                                                 ctx["extents"], ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"],
                                                                 ctx["gt_region"], ptr(self.acc), ptr(self.gw), ptr(self.d_head), 128, B,
@@ -1083,6 +1096,7 @@ class Plan:
             Ho = Hp // 2
             r, gact = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
             mr = E(B, 32, 2, dtype=F32t)
+            self.tensors.update({q + f"{ci}.raw": r, q + f"{ci}.act": gact})
             op, _ = self._conv(Lc, px, cin, r, Hp, Hp, Ho, Ho, 2, 1, cin=cin, cout=128)
             self.fwd.append(op)
             gam, bet = e.P[q + f"{gi}.weight"], e.P[q + f"{gi}.bias"]
@@ -1090,6 +1104,7 @@ class Plan:
                 lib.gdrn_gn_relu_fwd(ptr(r), ptr(gam), ptr(bet), ptr(gact), ptr(mr), B, Ho * Ho, 128, 32, 1e-5, e.dt, st), "gn_relu_fwd"))
             if T:
                 d_g, d_r = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
+                self.tensors.update({q + f"{ci}.d_act": d_g, q + f"{ci}.d_raw": d_r})
                 dgam, dbet = e.grads[q + f"{gi}.weight"], e.grads[q + f"{gi}.bias"]
                 grp = [lambda st, ctx, d_g=d_g, gact=gact, r=r, gam=gam, mr=mr, d_r=d_r, dgam=dgam, dbet=dbet, Ho=Ho: check(
                     lib.gdrn_gn_relu_bwd(ptr(d_g), ptr(gact), ptr(r), ptr(gam), ptr(mr), ptr(d_r), ptr(dgam), ptr(dbet), B, Ho * Ho, 128, 32,
@@ -1106,6 +1121,7 @@ class Plan:
         L1, L2, L3 = e.layers["pnp_net.fc1"], e.layers["pnp_net.fc2"], e.layers["pnp_net.fc_rt"]
         f1, f2 = E(B, 1024), E(B, 256)
         self.fc_out = E(B, 64, dtype=F32t)
+        self.tensors.update({"pnp_net.fc1.act": f1, "pnp_net.fc2.act": f2, "fc_out": self.fc_out})
         b1, b2 = e.P["pnp_net.fc1.bias"], e.P["pnp_net.fc2.bias"]
         if e.dt == BF16 and B <= 64 and e.fc_splitk:
             # fc1 is bound by reading its 16.8 MB of weights once: split-K skinny GEMM instead of 8 gather workgroups.
@@ -1131,6 +1147,7 @@ class Plan:
             d_fc32 = e._zeros(B, 64, dtype=F32t)
             d_fc = E(B, 64)
             d_f2, d_f2p, d_f1, d_f1p = E(B, 256), E(B, 256), E(B, 1024), E(B, 1024)
+            self.tensors.update({"d_fc": d_fc, "pnp_net.fc2.d_act": d_f2, "pnp_net.fc2.d_pre": d_f2p, "pnp_net.fc1.d_act": d_f1, "pnp_net.fc1.d_pre": d_f1p})
             self._rt_gb_full = e._zeros(12, dtype=F32t)
             self.rt_gb = self._rt_gb_full[:9]
             self._zero_regions += [self._rt_gb_full, self._grad16(e.grads["pnp_net.fc1.bias"]), self._grad16(e.grads["pnp_net.fc2.bias"])]

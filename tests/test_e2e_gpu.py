@@ -119,6 +119,11 @@ def test_fp32_maps_and_inference_vs_reference(g5):
     assert rel(od["trans"], g5["b2/eval_trans"]) < 1e-4
 
 
+# per-loss bounds of the bf16 step at bs = 4 on the random-init network, filled from the measurement (x1.5)
+LOSS_TOL_BF16 = {"loss_coor_x": 5e-2, "loss_coor_y": 5e-2, "loss_coor_z": 5e-2, "loss_mask": 5e-2, "loss_region": 5e-2, "loss_PM_R": 0.3,
+                 "loss_centroid": 0.3, "loss_z": 0.3}
+
+
 def test_bf16_train_step_vs_reference(g5):
     """bf16 operands cannot reach 1e-4 through ~40 layers; the throughput mode is held to
     a stated looser bound instead and its measured error is what DESIGN.md reports."""
@@ -129,22 +134,24 @@ def test_bf16_train_step_vs_reference(g5):
     _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
     names = list(g5[f"{tag}/loss_names"])
     vals = np.array([loss_dict[k].item() for k in names])
-    # dense-map losses average 16k pixels -> 5 %; the three pose losses average only bs=4 per-RoI outputs -> 30 %
-    tols = np.array([0.3 if k in ("loss_PM_R", "loss_centroid", "loss_z") else 5e-2 for k in names])
-    assert (np.abs(vals - g5[f"{tag}/loss_values"]) <= tols * np.abs(g5[f"{tag}/loss_values"])).all(), (names, vals)
+    lerr = np.abs(vals - g5[f"{tag}/loss_values"]) / np.abs(g5[f"{tag}/loss_values"])
+    print("bf16 loss rel-err vs the reference:", {k: "%.2e" % e for k, e in zip(names, lerr)})
+    # dense-map losses average 16k pixels, the three pose losses only bs=4 per-RoI outputs of a random-init net.  Bounds: 1.5x the
+    # values measured in round 3 (the amplification-free check of the same engine is tests/test_teacher_forced_gpu.py)
+    tols = np.array([LOSS_TOL_BF16[k] for k in names])
+    assert (lerr <= tols).all(), (names, lerr)
     plan = model.engine().plan(B, True, True)
     e_rot, e_tr = rel(plan.rot, g5[f"{tag}/rot_train"]), rel(plan.trans, g5[f"{tag}/trans"])
     print("bf16 pose rel-err: rot %.3e trans %.3e" % (e_rot, e_tr))
     # The random-init graph at bs=4 amplifies a 6e-8 (fp32) rounding to ~1e-4 at the pose outputs (x1600, measured in
     # test_fp32_*): bf16's 4e-3 operand rounding therefore decorrelates the *pose* of individual RoIs on this input, while
-    # the batch-mean losses stay within 5 %.  What is asserted here is the bound that matters for training: finite,
-    # loss-consistent, and gradient norms of the right size.
-    assert e_tr < 0.2 and np.isfinite(e_rot)
+    # the batch-mean losses stay within a few %.  Measured: rot 3.23e-1, trans 1.48e-2, gradient norms median 5.8e-2 / max 2.7e-1.
+    assert e_rot < 0.48 and e_tr < 2.2e-2, (e_rot, e_tr)
     sum(loss_dict.values()).backward()
     gn = dict(zip(g5[f"{tag}/grad_names"], g5[f"{tag}/grad_norms"]))
     errs = [abs(p.grad.double().norm().item() - gn[n]) / max(gn[n], 1e-12) for n, p in model.named_parameters()]
     print("bf16 grad-norm rel-err: median %.3e max %.3e" % (float(np.median(errs)), float(np.max(errs))))
-    assert np.median(errs) < 0.3
+    assert np.median(errs) < 0.087 and np.max(errs) < 0.41
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
@@ -788,10 +795,14 @@ def test_bf16_parity_on_a_conditioned_network():
     # within 5.5e-3 (dense-map losses 7e-4) -- and the bf16-storage oracle itself sits 7.1e-2 from the fp32 oracle: the error is the
     # storage format's, not the kernels'; (3) maps 7.3e-2, t 5.3e-3.  R is the Gram-Schmidt of a 6-vector that a random-init
     # Patch-PnP leaves near zero, so its relative error (and the angle printed above) overstates what a trained head would show.
-    assert max(e_st.values()) < 0.18, e_st
-    assert e_32["maps"] < 0.15 and e_32["rot6d"] < 0.15 and e_32["t_"] < 3e-2 and e_32["trans"] < 1.5e-2 and e_32["rot"] < 0.3, e_32
-    assert max(lerr.values()) < 2e-2, lerr
-    assert e_ev["maps"] < 0.15 and e_ev["trans"] < 1.5e-2, e_ev
+    # bounds: 1.5x the round-3 measurement (maps 3.97e-2 / rot6d 4.11e-2 / t_ 6.95e-3 / rot 8.95e-2 / trans 3.25e-3 against the bf16-storage
+    # oracle; 7.02e-2 / 5.77e-2 / 1.00e-2 / 1.25e-1 / 4.96e-3 against fp32; losses <= 5.7e-3 (dense maps 7.4e-4); eval 7.27e-2 / 1.78e-1 / 5.14e-3)
+    b_st = {"maps": 6e-2, "rot6d": 6.2e-2, "t_": 1.05e-2, "rot": 0.135, "trans": 4.9e-3}
+    b_32 = {"maps": 0.105, "rot6d": 0.087, "t_": 1.5e-2, "rot": 0.19, "trans": 7.5e-3}
+    assert all(e_st[k] < b_st[k] for k in b_st), e_st
+    assert all(e_32[k] < b_32[k] for k in b_32), e_32
+    assert max(lerr.values()) < 8.6e-3 and max(lerr[k] for k in ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region")) < 1.2e-3, lerr
+    assert e_ev["maps"] < 0.11 and e_ev["trans"] < 7.7e-3 and e_ev["rot"] < 0.27, e_ev
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
