@@ -11,6 +11,8 @@ gradients (``GradReducer.grad_scale`` -> ``Ranger.step(grad_scale=)``); callers 
 stock optimizers) get the scaled buffer from ``finish()``.  Works with any torch.distributed backend
 ("nccl" == RCCL on ROCm; "gloo" for the CPU tests of the protocol).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -30,7 +32,8 @@ class GradReducer:
         self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if comm_dtype == "bf16" else None
         self.defer_scale = bool(defer_scale)
         self.active = self.world > 1 or self.force
-        self.started = []  # per bucket: event recorded on the side stream when its collective was enqueued (tests / tracing)
+        self.trace = os.environ.get("GDRN_DIST_TRACE", "0") == "1" or force   # record a timing event per bucket (tests / tools/bucket_timeline.py)
+        self.started = []  # per bucket: event recorded on the side stream when its collective was enqueued (trace mode only)
 
     @property
     def grad_scale(self):
@@ -59,11 +62,12 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                if i == 0:
-                    self.started = []
-                se = torch.cuda.Event(enable_timing=True)
-                se.record(self.stream)
-                self.started.append(se)
+                if self.trace:
+                    if i == 0:
+                        self.started = []
+                    se = torch.cuda.Event(enable_timing=True)
+                    se.record(self.stream)
+                    self.started.append(se)
                 self._exchange(lo, hi)
         else:
             self._exchange(lo, hi)
@@ -86,6 +90,11 @@ def attach(model, group=None, average=True, force=False, comm_dtype="fp32"):
     """Overlap the gradient all-reduce with the model's backward; returns the GradReducer.  The 1/world factor is deferred
     to the consumer: ``GDRN.train_step`` hands it to the fused Ranger step, the autograd path applies it in ``finish()``."""
     eng = model.engine()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if not eng.buckets_from_env:
+        # an engine built before init_process_group picked the one-GPU layout (4 buckets): data-parallel runs want the 5-bucket one
+        # (the 52 MB layer4 exchange starts nine blocks before the end of backward); plans are rebuilt on a change
+        eng.set_bucket_layout(5 if world > 1 else 4)
     red = GradReducer(eng.grad_flat, eng.bucket_bounds, group=group, average=average, force=force, comm_dtype=comm_dtype, defer_scale=True)
     model._on_bucket = red.on_bucket
     model._reducer = red

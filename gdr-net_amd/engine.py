@@ -74,10 +74,13 @@ class Engine:
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1536"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step (non-multiples of 512 lose a partial round)
         nb = _os.environ.get("GDRN_BUCKETS")
+        self.buckets_from_env = nb is not None
         if nb is None:
             import torch.distributed as _dist
 
             nb = 5 if (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) else 4
+        if str(nb) not in ("4", "5"):
+            raise ValueError(f"GDRN_BUCKETS={nb!r}: the gradient bucket layouts are 4 (one GPU) and 5 (data parallel)")
         self.bucket_first_group, self.bucket_marks = BUCKET_LAYOUTS[int(nb)]
         self.layers = OrderedDict()
         self._versions = {}
@@ -98,6 +101,19 @@ class Engine:
         self.grads = {n: self.grad_flat[self.grad_offsets[n]: self.grad_offsets[n] + self.P[n].numel()].view(self.P[n].shape)
                       for n in self.param_names}
         self.bucket_bounds = self._bucket_bounds()
+
+    def set_bucket_layout(self, nb):
+        """switch the gradient bucket layout (4: one GPU, 5: data parallel -- the layer4 exchange starts earlier) after construction:
+        dist.attach() calls this when the process group was created after the engine.  Plans are rebuilt (the grouped weight-gradient
+        launches follow the buckets)."""
+        if nb not in BUCKET_LAYOUTS:
+            raise ValueError(f"bucket layout {nb!r}: choose 4 or 5")
+        if (self.bucket_first_group, self.bucket_marks) == BUCKET_LAYOUTS[nb]:
+            return False
+        self.bucket_first_group, self.bucket_marks = BUCKET_LAYOUTS[nb]
+        self.bucket_bounds = self._bucket_bounds()
+        self.plans.clear()
+        return True
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -353,6 +369,7 @@ class Plan:
         self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
         self._zero_regions = []    # fp32 tensors the backward accumulates into with atomics: cleared by ONE gdrn_zero_multi launch
         self.generation = 0        # bumped by every run_forward: a backward checks its activations are still the plan's
+        self.grad_group = {}       # parameter name -> forward index of the backward group that completes its gradient
         self._build()
         if self.has_backward:
             self._finish_unpack()
@@ -542,6 +559,8 @@ class Plan:
         e = self.e
         lib = e.lib
         O, I, KK = L.O, L.I, L.KK
+        for n_ in L.src:
+            self.grad_group[n_] = len(self.bwd_groups)
         if L.kind == "stem":
             g = e.grads[L.src[0]]
             return lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w")
@@ -588,6 +607,7 @@ class Plan:
             s.ka, s.kb, s.kc = (e._empty(s.C, dtype=torch.float32) for _ in range(3))
         g = e.P[bnkey + ".weight"]
         dg, db = e.grads[bnkey + ".weight"], e.grads[bnkey + ".bias"]
+        self.grad_group[bnkey + ".weight"] = self.grad_group[bnkey + ".bias"] = len(self.bwd_groups)
         return lambda st, ctx: check(lib.gdrn_bn_bwd_coef(ptr(rows), nrows, s.C, s.npix, ptr(g), ptr(s.mean), ptr(s.invstd), ptr(s.ka), ptr(s.kb),
                                                           ptr(s.kc), ptr(dg), ptr(db), st), "bn_bwd_coef")
 
@@ -831,6 +851,7 @@ class Plan:
 
                 self._zero_regions.append(self._grad16(gw))
 
+                self.grad_group["backbone.conv1.weight"] = len(self.bwd_groups)
                 stem_wgrad.meta = dict(kernel="stem_wgrad_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1:wgrad")
                 grp.append(stem_wgrad)
             else:
@@ -1081,6 +1102,7 @@ class Plan:
             grp.append(self._wgrad(LO, hx, self.d_head, 64, 64, 64, 64, 1, 0, 256, e.head_c, 256, 128))
             grp.append(self._unpack(LO))
             gb = e.grads[h + "23.bias"]
+            self.grad_group[h + "23.bias"] = len(self.bwd_groups)
             self._zero_regions.append(self._grad16(gb))
             grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad"))
             op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256,
@@ -1106,6 +1128,7 @@ class Plan:
                 d_g, d_r = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
                 self.tensors.update({q + f"{ci}.d_act": d_g, q + f"{ci}.d_raw": d_r})
                 dgam, dbet = e.grads[q + f"{gi}.weight"], e.grads[q + f"{gi}.bias"]
+                self.grad_group[q + f"{gi}.weight"] = self.grad_group[q + f"{gi}.bias"] = len(self.bwd_groups)
                 grp = [lambda st, ctx, d_g=d_g, gact=gact, r=r, gam=gam, mr=mr, d_r=d_r, dgam=dgam, dbet=dbet, Ho=Ho: check(
                     lib.gdrn_gn_relu_bwd(ptr(d_g), ptr(gact), ptr(r), ptr(gam), ptr(mr), ptr(d_r), ptr(dgam), ptr(dbet), B, Ho * Ho, 128, 32,
                                          e.dt | PREZEROED, st), "gn_relu_bwd")]
@@ -1152,6 +1175,8 @@ class Plan:
             self.rt_gb = self._rt_gb_full[:9]
             self._zero_regions += [self._rt_gb_full, self._grad16(e.grads["pnp_net.fc1.bias"]), self._grad16(e.grads["pnp_net.fc2.bias"])]
             g_b1, g_b2 = e.grads["pnp_net.fc1.bias"], e.grads["pnp_net.fc2.bias"]
+            for n_ in ("pnp_net.fc1.bias", "pnp_net.fc2.bias", "pnp_net.fc_r.bias", "pnp_net.fc_t.bias"):
+                self.grad_group[n_] = len(self.bwd_groups)
             grp = [
                 lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3"),
                 lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
@@ -1250,6 +1275,20 @@ class Plan:
                     on_bucket(marks[i])
         if used_side:
             main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
+
+    def walk_backward(self, on_bucket, before_bucket=None):
+        """The backward launch list WITHOUT launching (works on a dry engine): calls before_bucket(i) / on_bucket(i) where
+        run_backward calls on_bucket(i), i.e. behind the last op of gradient bucket i.  Returns [(op index, bucket)] in call order.
+        For the CPU tests of the data-parallel protocol (tests/test_dist_cpu.py)."""
+        marks = self._bucket_marks()
+        fired = []
+        for i, op in enumerate(self.bwd):
+            if i in marks:
+                if before_bucket is not None:
+                    before_bucket(marks[i])
+                on_bucket(marks[i])
+                fired.append((i, marks[i]))
+        return fired
 
     def _bucket_marks(self):
         """index of the last backward op of each gradient bucket (pnp | head | layer4 | layer3 | rest)."""

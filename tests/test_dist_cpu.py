@@ -5,6 +5,8 @@ core/utils/my_comm.py:8)."""
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -164,3 +166,95 @@ def test_single_process_reducer_is_a_noop():
     assert torch.equal(flat, torch.ones(10))
     ld = {"a": torch.tensor(1.0)}
     assert reduce_loss_dict(ld) is ld
+
+
+# ---------------------------------------------------------------------------------------------- the REAL plan's bucket protocol
+def _worker_real_plan(rank, world, port, q):
+    """Two gloo ranks drive the bucket marks of the real backward launch list (dry engine on host tensors, no launches): every
+    element of the flat gradient buffer is all-reduced exactly once, the buckets fire in order 0..n-1 behind the last op that
+    writes one of their gradients, and the mean lands in every parameter's gradient view."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdrnet_amd import GDRN as G
+        from gdrnet_amd.cfg import lm13_cfg
+        from gdrnet_amd.dist import GradReducer
+        from gdrnet_amd.engine import Engine
+
+        torch.manual_seed(0)
+        model, _ = G.build_model_optimizer(lm13_cfg(device="cpu"))
+        eng = Engine(dict(model.named_parameters()), dict(model.named_buffers()), dtype="bf16", dry=True)
+        assert len(eng.bucket_bounds) == 5, eng.bucket_bounds   # world > 1 -> the data-parallel layout
+        plan = eng.plan(2, True, True)
+        flat, bounds = eng.grad_flat, eng.bucket_bounds
+        # the bounds partition the buffer
+        assert bounds[0][0] == 0 and bounds[-1][1] == flat.numel() and all(bounds[i][1] == bounds[i + 1][0] for i in range(len(bounds) - 1))
+        # every parameter's gradient is complete when its bucket fires: the backward group that writes it belongs to the same bucket or to
+        # an EARLIER one (the BatchNorm-backward sums of a layer's last block come out of the next layer's stride-2 data gradient, one
+        # bucket earlier); groups run in reverse forward order, buckets fire in order 0, 1, ...
+        first = eng.bucket_first_group
+        bucket_of_group = lambda gi: next(i for i, g0 in enumerate(first) if gi >= g0)
+        bucket_of_off = lambda off: next(i for i, (lo, hi) in enumerate(bounds) if lo <= off < hi)
+        assert set(plan.grad_group) == set(eng.param_names), set(eng.param_names) ^ set(plan.grad_group)
+        for n in eng.param_names:
+            assert bucket_of_group(plan.grad_group[n]) <= bucket_of_off(eng.grad_offsets[n]), n
+        assert sum(bucket_of_group(plan.grad_group[n]) < bucket_of_off(eng.grad_offsets[n]) for n in eng.param_names) <= 8
+        red = GradReducer(flat, bounds, average=True, defer_scale=True)
+        seen = []
+
+        def before(i):
+            # "the kernels of bucket i have just finished": its gradients appear, later buckets are still untouched
+            lo, hi = bounds[i]
+            assert float(flat[hi:].abs().sum()) == 0.0, i
+            flat[lo:hi] = (rank + 1) * (torch.arange(lo, hi) % 97 + 1).float()
+            seen.append(i)
+
+        flat.zero_()
+        fired = plan.walk_backward(red.on_bucket, before)
+        red.finish()
+        assert seen == list(range(len(bounds))) and [b for _, b in fired] == seen
+        ops = [i for i, _ in fired]
+        assert ops == sorted(ops) and ops[-1] == len(plan.bwd) - 1      # the last bucket closes behind the last backward op
+        mean = sum(r + 1 for r in range(world)) / world
+        exp = mean * (torch.arange(flat.numel()) % 97 + 1).float()
+        assert torch.allclose(flat, exp, rtol=1e-6), float((flat - exp).abs().max())   # reduced exactly once, mean applied once
+        for n in eng.param_names:
+            o = eng.grad_offsets[n]
+            assert torch.equal(eng.grads[n].reshape(-1), flat[o:o + eng.P[n].numel()]), n
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_plan_bucket_marks_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_plan, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bucket_layout_follows_the_process_group_and_rejects_bad_values(monkeypatch):
+    from gdrnet_amd import GDRN as G
+    from gdrnet_amd.cfg import lm13_cfg
+    from gdrnet_amd.engine import Engine
+
+    model, _ = G.build_model_optimizer(lm13_cfg(device="cpu"))
+    eng = Engine(dict(model.named_parameters()), dict(model.named_buffers()), dtype="bf16", dry=True)
+    assert len(eng.bucket_bounds) == 4 and not eng.buckets_from_env
+    eng.plan(2, True, True)
+    assert eng.set_bucket_layout(5) and len(eng.bucket_bounds) == 5 and not eng.plans   # plans are rebuilt for the new grouping
+    assert not eng.set_bucket_layout(5)
+    monkeypatch.setenv("GDRN_BUCKETS", "3")
+    with pytest.raises(ValueError, match="GDRN_BUCKETS"):
+        Engine(dict(model.named_parameters()), dict(model.named_buffers()), dtype="bf16", dry=True)

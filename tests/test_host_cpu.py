@@ -179,3 +179,24 @@ def test_workspace_bytes_query_matches_the_per_op_rules():
     a = (C.c_longlong * 3)(64 * 4096, 256, cabi.BF16)
     assert lib.gdrn_workspace_bytes(6, a) == lib.gdrn_bn_bwd_reduce_rows(64 * 4096, 256, cabi.BF16) * 2 * 256 * 4
     assert lib.gdrn_workspace_bytes(99, a) == -1 and lib.gdrn_workspace_bytes(0, None) == -1
+
+
+def test_c_client_compiles_links_and_runs(tmp_path):
+    """include/gdrn_hip.h is a C header whose documented names (GDRN_ERR_*, GDRN_DT_*) are the ones it defines: a pure-C client is
+    compiled with gcc, linked against libgdrn_hip.so and run (host-only queries: no GPU needed)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    lib = cabi.lib_path()
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.dirname(lib)
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_client.c"),
+                           "-L", libdir, "-lgdrn_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "gdrn C client ok" in out.stdout
