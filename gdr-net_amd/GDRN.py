@@ -568,18 +568,35 @@ def build_model_optimizer(cfg):
         pre = cfg.MODEL.CDPN.BACKBONE.get("PRETRAINED", "")
         if pre == "":
             logger.warning("Randomly initialize weights for backbone!")
-        elif os.path.exists(pre):
-            sd = torch.load(pre, map_location="cpu")
+        elif os.path.exists(pre) or _resolve_pretrained(pre) is not None:
+            sd = torch.load(pre if os.path.exists(pre) else _resolve_pretrained(pre), map_location="cpu")
             sd = sd.get("state_dict", sd)
             sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}  # as mmcv's load_checkpoint (GDRN.py:721)
             model.backbone.load_state_dict(sd, strict=False)
         else:
             # the reference resolves "torchvision://resnet34" / http(s) URLs through mmcv's load_checkpoint; silently training
             # from the std=0.001 random init instead would change convergence -- ask for a local file (as checkpoint.py does)
-            raise FileNotFoundError(f"cfg.MODEL.CDPN.BACKBONE.PRETRAINED={pre!r} is not a local file (URL schemes need network access): "
-                                    "download the weights and point PRETRAINED at the file, or set it to '' for random init")
+            raise FileNotFoundError(f"cfg.MODEL.CDPN.BACKBONE.PRETRAINED={pre!r} is neither a local file nor in the torch hub cache "
+                                    f"({os.path.join(_hub_dir(), 'checkpoints')}; URL schemes need network access): download the weights and point "
+                                    "PRETRAINED at the file, or set it to '' for random init")
     model.to(torch.device(cfg.MODEL.DEVICE))
     return model, optimizer
+
+
+def _hub_dir():
+    return os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")), "hub")
+
+
+def _resolve_pretrained(pre):
+    """"torchvision://resnet34" / "open-mmlab://resnet34" (configs/_base_/gdrn_base.py:21) -> the file torch hub / mmcv would have downloaded,
+    if it is in the local hub cache ($TORCH_HOME/hub/checkpoints/resnet34-*.pth); None otherwise (no network access here)."""
+    import glob
+
+    for scheme in ("torchvision://", "open-mmlab://", "modelzoo://"):
+        if pre.startswith(scheme):
+            hits = sorted(glob.glob(os.path.join(_hub_dir(), "checkpoints", pre[len(scheme):] + "-*.pth")))
+            return hits[0] if hits else None
+    return None
 
 
 def build_optimizer_with_params(cfg, params):

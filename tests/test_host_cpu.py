@@ -200,3 +200,21 @@ def test_c_client_compiles_links_and_runs(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "gdrn C client ok" in out.stdout
+
+
+def test_pretrained_backbone_is_resolved_from_the_hub_cache_or_refused(tmp_path, monkeypatch):
+    """configs/_base_/gdrn_base.py:21 names "torchvision://resnet34": found in $TORCH_HOME/hub/checkpoints it is loaded (strict=False, as
+    mmcv's load_checkpoint at GDRN.py:721); absent, the build refuses instead of silently training from the random init."""
+    from gdrnet_amd import GDRN
+
+    cfg = lm13_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="hub"):
+        GDRN.build_model_optimizer(cfg)
+    ref, _ = GDRN.build_model_optimizer(lm13_cfg(device="cpu"))
+    sd = {k: torch.full_like(v, 0.25) for k, v in ref.backbone.state_dict().items() if k.startswith("layer1.0.conv1")}
+    os.makedirs(tmp_path / "hub" / "checkpoints")
+    torch.save(sd, tmp_path / "hub" / "checkpoints" / "resnet34-b627a593.pth")
+    m, _ = GDRN.build_model_optimizer(cfg)
+    assert float(m.backbone.layer1[0].conv1.weight.mean()) == 0.25
