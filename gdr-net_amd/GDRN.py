@@ -289,6 +289,27 @@ class GDRN(nn.Module):
     def _f32(t, dev):
         return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
+    @staticmethod
+    def padded_batch(B):
+        """inference batch size of B RoIs: next power of two up to 64, multiples of 64 beyond"""
+        if B <= 1:
+            return 1
+        return 1 << (B - 1).bit_length() if B <= 64 else (B + 63) // 64 * 64
+
+    def _pad_rows(self, name, t, Bp):
+        """t ([B, ...] fp32 on the device) in the first rows of a persistent [Bp, ...] buffer; the other rows hold an inert RoI
+        (zero image, unit extents / sizes / ratios / intrinsics) or what an earlier, larger batch left there -- finite either way."""
+        bufs = self.__dict__.setdefault("_pad_bufs", {})
+        key = (name, Bp, tuple(t.shape[1:]))
+        buf = bufs.get(key)
+        if buf is None:
+            fill = 0.0 if name in ("img", "coord2d", "centers") else 1.0
+            buf = bufs[key] = torch.full((Bp,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
+            if name == "cams":
+                buf.copy_(torch.eye(3, dtype=t.dtype, device=t.device).expand(Bp, 3, 3))
+        buf[: t.shape[0]].copy_(t, non_blocking=True)
+        return buf
+
     def _pack_sym(self, sym_infos, B, dev):
         """list of (K,3,3) / None (pm_loss.py:91-92) -> fp32 [B][Kmax][9] + int32 counts."""
         mats = [None if s is None else torch.as_tensor(s).detach().cpu().to(torch.float32).reshape(-1, 9) for s in sym_infos]
@@ -333,8 +354,17 @@ class GDRN(nn.Module):
         cams = f32(roi_cams)
         if cams.dim() == 2:
             cams = cams.unsqueeze(0).expand(B, 3, 3).contiguous()
-        keep = [S("img", f32(x)), S("coord2d", f32(roi_coord_2d)), S("extents", f32(roi_extents)), S("cams", cams),
-                S("centers", f32(roi_centers)), S("whs", f32(roi_whs)), S("ratios", f32(resize_ratios).reshape(B))]
+        ins = [("img", f32(x)), ("coord2d", f32(roi_coord_2d)), ("extents", f32(roi_extents)), ("cams", cams),
+               ("centers", f32(roi_centers)), ("whs", f32(roi_whs)), ("ratios", f32(resize_ratios).reshape(B))]
+        Bp = B
+        if not self.training and not do_loss and staging is None:
+            # Inference: the reference's test loop feeds "all detections of one image" (gdrn_evaluator.py:549-578, data_loader.py:707-765),
+            # so B changes with every call.  Eval-mode RoIs are independent (running statistics), hence the batch is rounded up to the next
+            # power of two (multiples of 64 beyond) with inert RoIs in persistent buffers: at most 7 plans instead of one per B.
+            Bp = self.padded_batch(B)
+            if Bp != B:
+                ins = [(n, self._pad_rows(n, t, Bp)) for n, t in ins]
+        keep = [S(n, t) for n, t in ins]
         kctx = dict(img=keep[0].data_ptr(), coord2d=keep[1].data_ptr(), extents=keep[2].data_ptr(), cams=keep[3].data_ptr(),
                     centers=keep[4].data_ptr(), whs=keep[5].data_ptr(), ratios=keep[6].data_ptr(), _keep=keep)
         if do_loss:
@@ -355,7 +385,7 @@ class GDRN(nn.Module):
                     sym, cnt = S("sym", sym), S("sym_count", cnt)
                     keep += [sym, cnt]
                     kctx.update(sym=sym.data_ptr(), sym_count=cnt.data_ptr(), Kmax=K)
-        plan = eng.plan(B, self.training, do_loss)   # (building a plan fixes the layouts of the halo operands it is the first to use)
+        plan = eng.plan(Bp, self.training, do_loss)   # (building a plan fixes the layouts of the halo operands it is the first to use)
         if staging is None:
             eng.repack()
         return eng, plan, kctx
@@ -397,7 +427,7 @@ class GDRN(nn.Module):
         if not do_loss:  # test
             with torch.no_grad():
                 plan.run_forward(kctx)
-            out_dict = {"rot": plan.rot.clone(), "trans": plan.trans.clone()}
+            out_dict = {"rot": plan.rot[:B].clone(), "trans": plan.trans[:B].clone()}   # (plan.B >= B: padded inference batch)
             if cfg.TEST.USE_PNP:
                 out_dict.update(self._maps(plan, B))
             return out_dict

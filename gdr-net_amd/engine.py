@@ -88,7 +88,9 @@ class Engine:
         self.fold_bn = _os.environ.get("GDRN_FOLD_BN", "1") != "0"  # A/B switch: conv + bn_apply launches in eval mode
         self.bn_epoch = 0  # bumped by every training forward (running statistics changed)
         self._build_layers()
-        self.plans = {}
+        self.plans = OrderedDict()   # (batch size, train-mode BatchNorm, losses) -> Plan, least recently used first
+        self.max_plans = int(_os.environ.get("GDRN_MAX_PLANS", "8"))
+        self.plan_builds = 0
         self.param_names = list(self.P.keys())
         # flat fp32 gradient buffer, ordered by backward completion (reverse of forward order)
         order = list(reversed(self.param_names))
@@ -342,9 +344,18 @@ class Engine:
         """bn_train: BatchNorm uses batch statistics (module.training); with_loss: train-mode pose
         decode + losses (do_loss=True).  The backward graph exists when both are set."""
         key = (B, bool(bn_train), bool(with_loss))
-        if key not in self.plans:
-            self.plans[key] = Plan(self, B, bool(bn_train), bool(with_loss))
-        return self.plans[key]
+        p = self.plans.get(key)
+        if p is None:
+            p = self.plans[key] = Plan(self, B, bool(bn_train), bool(with_loss))
+            self.plan_builds += 1
+            # bounded cache (least recently used out): a plan owns every activation / gradient buffer of its batch size -- ~11 GB for a
+            # bs = 64 training plan.  Inference rounds its batch up to a power of two (GDRN._prepare), so a stream of changing
+            # detection counts (gdrn_evaluator.py:549-578) lives in <= 7 plans; an evicted plan is freed once no autograd node holds it.
+            while len(self.plans) > self.max_plans:
+                self.plans.pop(next(iter(self.plans)))
+        else:
+            self.plans.move_to_end(key)
+        return p
 
 
 class Plan:

@@ -906,3 +906,55 @@ def test_training_on_one_batch_reduces_the_loss_in_both_precisions():
         assert min(tot[1:]) == min(tot), (dtype, tot)          # ... and never beats the start only by noise
     assert abs(traj["bf16"][-1] - traj["fp32"][-1]) < 0.1 * traj["fp32"][0], traj
     print("total loss every 10 steps: bf16", [round(t, 3) for t in traj["bf16"]], "fp32", [round(t, 3) for t in traj["fp32"]])
+
+
+def test_inference_over_a_stream_of_changing_batch_sizes(monkeypatch):
+    """The reference's test loop feeds "all detections of one image" as the batch (gdrn_evaluator.py:549-601, data_loader.py:707-765):
+    B changes with every call.  Eval-mode inference pads B to the next power of two (inert RoIs in persistent buffers), so the
+    stream B = 1..17 in random order needs five plans (1, 2, 4, 8, 16, 32 minus the unused ones), builds none after the warm-up pass,
+    keeps the device memory flat, and every RoI's pose / maps equal the oracle's whatever batch it travelled in (fp32 mode, 1e-4)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from oracle import gdrn_oracle as O
+
+    model, _ = build("fp32")
+    model.eval()
+    model.cfg.TEST.USE_PNP = True
+    N = 17
+    cpu_batch = synth.make_batch(N, seed=21)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = O.gdrn_forward(sd, cpu_batch, do_loss=False, training=False)
+    batch = to_dev(cpu_batch)
+    kw_all = synth.model_kwargs(batch, do_loss=False)
+    rng = np.random.RandomState(0)
+
+    def run(B, off):
+        sl = slice(off, off + B)
+        kw = {k: (v[sl] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == N else v) for k, v in kw_all.items()}
+        with torch.no_grad():
+            od = model(batch["roi_img"][sl], **kw)
+        assert od["rot"].shape[0] == B and od["mask"].shape[0] == B
+        assert rel(od["rot"], ref["rot"][sl]) < 1e-4 and rel(od["trans"], ref["trans"][sl]) < 1e-4, (B, off)
+        assert rel(od["coor_x"], ref["coor_x"][sl]) < 1e-4 and rel(od["region"], ref["region"][sl]) < 1e-4, (B, off)
+
+    eng = None
+    for B in rng.permutation(np.arange(1, N + 1)):     # warm-up pass: every bucket is built once
+        run(int(B), int(rng.randint(0, N - B + 1)))
+    eng = model.engine()
+    sizes = sorted(k[0] for k in eng.plans)
+    assert sizes == [1, 2, 4, 8, 16, 32], sizes
+    builds = eng.plan_builds
+    torch.cuda.synchronize()
+    mem = torch.cuda.memory_allocated()
+    for _ in range(2):
+        for B in rng.permutation(np.arange(1, N + 1)):
+            run(int(B), int(rng.randint(0, N - B + 1)))
+    torch.cuda.synchronize()
+    assert eng.plan_builds == builds                  # no plan construction after the warm-up
+    assert torch.cuda.memory_allocated() <= mem + (1 << 20), (torch.cuda.memory_allocated(), mem)
+    # the cache is bounded: least recently used plans go first
+    monkeypatch.setattr(eng, "max_plans", 3)
+    run(3, 0)
+    eng.plan(64, False, False)
+    assert len(eng.plans) == 3 and (64, False, False) in eng.plans and (4, False, False) in eng.plans

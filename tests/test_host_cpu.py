@@ -216,5 +216,7 @@ def test_pretrained_backbone_is_resolved_from_the_hub_cache_or_refused(tmp_path,
     sd = {k: torch.full_like(v, 0.25) for k, v in ref.backbone.state_dict().items() if k.startswith("layer1.0.conv1")}
     os.makedirs(tmp_path / "hub" / "checkpoints")
     torch.save(sd, tmp_path / "hub" / "checkpoints" / "resnet34-b627a593.pth")
-    m, _ = GDRN.build_model_optimizer(cfg)
+    cfg2 = lm13_cfg(device="cpu")
+    cfg2.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
+    m, _ = GDRN.build_model_optimizer(cfg2)
     assert float(m.backbone.layer1[0].conv1.weight.mean()) == 0.25
