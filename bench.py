@@ -187,18 +187,20 @@ def measure_roofline(model, plan, kctx, dtype):
     flops = sum(m["flops"] for _, _, m in ev)
     achieved = flops / (tot_ms * 1e-3) / 1e12
     peak = (PEAK_BF16 if dtype == "bf16" else PEAK_F32) / 1e12
-    # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs; FETCH_SIZE doubled
-    # as MI355X_MICROARCH.md prescribes for gfx950) cannot be collected from inside this process.  The committed summary
-    # (tools/pmc_traffic.py) carries the hash of the kernel sources it was measured on: any other build reports null
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic_bs64_bf16.json")
+    # HBM-side bytes per launch, MFMA utilisation and HBM GB/s of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, SQ/GRBM in
+    # separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) cannot be collected from inside this process.  The
+    # committed summary (tools/pmc_util.py, tools/gpu_runs/r3_util.sh) carries the hash of the kernel sources it was measured on: any
+    # other build reports null
+    traffic, traffic_src, pmc = None, None, {}
+    tpath = os.path.join(ROOT, "profiles", "r03_mfma_util_hbm_bs64_bf16.json")
     if dtype == "bf16" and plan.B == 64 and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("__kernel_source_sha256_16__") == kernel_source_hash():
+            pmc = tj
             traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
             traffic = round(traffic) if traffic else None
-            traffic_src = "profiles/r02_hbm_traffic_bs64_bf16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build)"
+            traffic_src = "profiles/r03_mfma_util_hbm_bs64_bf16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes of this build)"
         else:
             traffic_src = "null: the committed PMC summary belongs to another build of the kernels"
     # every conv / GEMM instantiation of the step, largest first (the dominant kernel above is row 0): the operand-transform variants of
@@ -208,12 +210,19 @@ def measure_roofline(model, plan, kctx, dtype):
         kev = [x for x in allev if x[2]["kernel"] == kname]
         kms = sum(max(a.elapsed_time(b) - ovh_ms, 1e-6) for a, b, _ in kev)
         kfl = sum(m["flops"] for _, _, m in kev)
-        table.append({"kernel": kname, "launches_per_step": len(kev), "ms_per_step": round(kms, 3), "achieved": round(kfl / (kms * 1e-3) / 1e12, 1),
-                      "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 3)})
+        row = {"kernel": kname, "launches_per_step": len(kev), "ms_per_step": round(kms, 3), "achieved": round(kfl / (kms * 1e-3) / 1e12, 1),
+               "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 3)}
+        pk = pmc.get(kname.replace("_kernel<", "_kernel<").replace(" ", ""), {})
+        if pk:   # rocprofv3-reported: MFMA-pipe busy cycles / (SIMDs x active cycles), HBM-side GB/s (tools/pmc_util.py)
+            row["mfma_util"] = round(pk["mfma_util"], 3) if "mfma_util" in pk else None
+            row["hbm_gbps"] = round(pk["hbm_gbps"])
+        table.append(row)
     best = max(allev, key=lambda x: x[2]["flops"] / max(x[0].elapsed_time(x[1]) - ovh_ms, 1e-6))
     return {"bound": "mfma", "kernel": dom, "launches_per_step": len(ev), "avg_launch_us": round(tot_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_launch": round(flops / max(len(ev), 1) / 1e9, 3), "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "mfma_util": (round(pmc[dom]["mfma_util"], 3) if dom in pmc and "mfma_util" in pmc[dom] else None),
+            "hbm_gbps": (round(pmc[dom]["hbm_gbps"]) if dom in pmc else None),
             "event_overhead_us": round(ovh_ms * 1e3, 2), "conv_kernels": table,
             "best_launch": {"kernel": best[2]["kernel"], "layer": best[2]["layer"],
                             "achieved": round(best[2]["flops"] / ((best[0].elapsed_time(best[1]) - ovh_ms) * 1e-3) / 1e12, 1)}}

@@ -489,7 +489,7 @@ class Plan:
             macs = self.B * sp * L.O * L.I * L.KK
         dn = "bf16" if e.dt == BF16 else "f32"
         if use_halo and cp.w_frag == 2:
-            kname = f"conv3x3_v3_kernel<{th.value}x{tw.value}x{hbn.value},xf{cp.xf_mode}>"
+            kname = f"conv3x3_v3_kernel<{th.value},{hbn.value},{'2,4,1' if hbn.value == 256 else '2,2,2'},{cp.xf_mode}>"  # (the template's name in a trace)
         elif use_halo:
             kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>"
         else:
