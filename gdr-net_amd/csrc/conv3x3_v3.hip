@@ -223,6 +223,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
         const int gc = g < total_units ? g : total_units - 1;  // past the end: a harmless reload into a free slot keeps the counts static
         const char* src = wg + (size_t)gc * wstride;
         if (HALF_DMA && wave >= 4) return;
+        if ((V3_VAR & 8) && g > 2) return;   // knock-out experiment (wrong results): the ring is never refilled
 #pragma unroll
         for (int i = 0; i < DPWX; ++i) dma16(src + i * 1024, wlane, ring_a + (unsigned)(slot * V3_UNIT + i * 1024));
     };
@@ -382,9 +383,13 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                 dma_w(gbase + U + 2, (U + 2) % V3_RING);
             }
             // [D] next chunk's patch: transform a landed slice, send the next DMA (always issued: static load counts)
+            if constexpr ((V3_VAR & 4) != 0) {   // knock-out experiment (wrong results): no patch traffic inside the loop
+            } else
             if constexpr (K::xf_slice(U) >= 0 && K::xf_slice(U) < NSL) {
                 if (more_p) xf_p(kc + 1, K::xf_slice(U), K::OFF_RAW + K::raw_slot(K::xf_slice(U)) * NIN * K::SLICE_BYTES, pb ^ 1);
             }
+            if constexpr ((V3_VAR & 4) != 0) {
+            } else
             if constexpr (K::dma_slice(U) >= 0 && K::dma_slice(U) < NSL) {
                 if constexpr (K::xf_slice(U) >= 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw slot's reads are done
                 dma_p(kc + 1, K::dma_slice(U), K::OFF_RAW + K::raw_slot(K::dma_slice(U)) * NIN * K::SLICE_BYTES);
@@ -479,6 +484,26 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     // (wn, wk) wave groups through LDS, added in a fixed order: one plain row [2][Cout] per pixel tile (deterministic)
     float* cst = reinterpret_cast<float*>(smem);                 // [4][BN] per-channel constants of the fused BatchNorm backward
     float* part = reinterpret_cast<float*>(smem) + 4 * BN;       // [WN*WK][2][BN]
+    // The output tile goes through LDS: a result lane holds 64 bytes of ONE pixel, so its direct stores are 64 different lines per
+    // instruction and the epilogue was store-issue bound (measured 17.5 k cycles for 16 store instructions per wave); written to LDS as
+    // [pixel][BN channels + 16 B pad] and read back row-wise, a wave stores 1 KiB of consecutive addresses per instruction.
+    constexpr int OT_OFF = (4 + 2 * WN * WK) * BN * 4;           // behind cst / part
+    constexpr int OT_PITCH = BN * 2 + 16;
+    unsigned char* otile = smem + OT_OFF;
+    static_assert(OT_OFF + TH * 16 * OT_PITCH <= 160 * 1024, "output tile in LDS");
+    const int opix = (brow0 * 16 + fx) * OT_PITCH + cwl * 2;     // lane's pixel and first channel inside the tile (+ fragment / pair / quarter)
+    auto put_tile = [&](int ap, int be, int q, uint4 v) { *reinterpret_cast<uint4*>(otile + opix + be * 32 * OT_PITCH + ap * 128 + q * 16) = v; };
+    auto flush_tile = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        constexpr int GPP = BN / 8;                              // 16-byte granules per pixel
+#pragma unroll
+        for (int i = 0; i < TH * 16 * GPP / NT; ++i) {
+            const int gid = i * NT + tid, pl = gid / GPP, cg = gid - pl * GPP;
+            const uint4 v = *reinterpret_cast<const uint4*>(otile + pl * OT_PITCH + cg * 16);
+            const unsigned pr = (unsigned)((n * p.Ho + y0 + (pl >> 4)) * p.Wo + x0 + (pl & 15));
+            *reinterpret_cast<uint4*>(yb + (size_t)(pr * (unsigned)p.y_cs + (unsigned)co0) * 2u + cg * 16) = v;
+        }
+    };
     const int grp = wn * WK + wk;
     // sums of (v1, v2) over the 32 lanes of a half wave (= the 32 pixels of a fragment): v_permlane16_swap pairs the two 16-lane rows
     // of the half -- afterwards the even rows hold v1(row 0) + v1(row 1), the odd rows v2(row 0) + v2(row 1) -- then four DPP adds
@@ -577,7 +602,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                         t1[e] += gv;
                         t2[e] += gv * (xv[e] - kmu[e]) * kis[e];
                     }
-                    *reinterpret_cast<uint4*>(yb + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)p.y_cs + (unsigned)(cw + ap * 64)) * 2u + q * 16) = Vec16<bf16_t>::pack(v);
+                    put_tile(ap, be, q, Vec16<bf16_t>::pack(v));
                 }
                 float wsum[8];
 #pragma unroll
@@ -586,6 +611,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
             }
         }
         put_rows(p.bnb_rows);
+        flush_tile();
         return;
     }
 
@@ -639,10 +665,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                     }
                     v[e] = relu ? fmaxf(r, 0.f) : r;
                 }
-                *reinterpret_cast<uint4*>(yb + (size_t)((pix0 + (unsigned)be * pstep) * (unsigned)p.y_cs + (unsigned)(cw + ap * 64)) * 2u + q * 16) = Vec16<bf16_t>::pack(v);
+                put_tile(ap, be, q, Vec16<bf16_t>::pack(v));
             }
         }
     }
+    flush_tile();
 }
 
 template <int TH, int BN, int WM, int WN, int WK, int XF>
@@ -696,11 +723,14 @@ int gdrn_v3_config(const gdrn_conv_params* p) {
     return f_small;
 }
 
-// does the library prefer this kernel over the first halo kernel for the launch in p?  Measured (tools/v3check.py, bs = 64, profiles/r03_*):
-// the 16x16x256 tile wins where the first kernel pays for the in-loop operand transform (xf modes 1-4: x1.00-1.09) and loses on plain
-// launches (x0.85-0.90); the 8x16x128 K-split tile loses everywhere (x0.68-0.98) and only serves launches the 256-channel tile cannot take.
+// does the library prefer this kernel over the first halo kernel for the launch in p?  Measured (tools/v3check.py, bs = 64,
+// profiles/r03_v3_vs_halo_bs64.txt): the 16x16x256 tile wins where the first kernel pays for its in-loop operand transform (xf modes 1-4:
+// x1.04-1.12) and loses on plain launches (x0.85-0.97); the 8x16x128 K-split tile loses on 128 and 512 channels (x0.66-0.88) and serves
+// the launches the 256-channel tile cannot take.
 int gdrn_v3_preferred(const gdrn_conv_params* p) {
     const int cfg = gdrn_v3_config(p);
+    // (the K-split tile's isolated x1.07-1.11 on the 256-channel 16x16 maps did not survive in the step: with the addend / stored-mask
+    //  epilogue of the BasicBlock data gradients it ran 39 us against 32 us, +0.2 ms per step -- it is not preferred anywhere)
     return (cfg == 1 || cfg == 3) && p->xf_mode != 0;
 }
 

@@ -340,7 +340,9 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
                    plan.head_out.cpu().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
     l0, t0, g0, h0, r0 = res["0"]
     l1, t1, g1, h1, r1 = res["1"]
-    bad = [(k, rel(t1[k], t0[k])) for k in t0 if not torch.equal(t0[k], t1[k])]
+    common = [k for k in t0 if k in t1]   # (tensors only one plan materialises -- e.g. the normalised downsample branch -- have no twin)
+    assert len(common) >= 190, len(common)
+    bad = [(k, rel(t1[k], t0[k])) for k in common if not torch.equal(t0[k], t1[k])]
     assert not bad, bad[:12]
     assert torch.equal(h0[:, :69], h1[:, :69])  # (columns 69..71 of the 72-wide rows are never written)
     torch.testing.assert_close(l1, l0, rtol=1e-6, atol=1e-9)  # the three pose losses are accumulated with float atomics
