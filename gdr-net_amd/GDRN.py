@@ -469,8 +469,30 @@ class GDRN(nn.Module):
         elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version):
             plan.gw.copy_(self._loss_w)  # dL/dloss_k = the config's loss weights: written once, not every step
             plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version)
-        plan.run_backward(kctx, on_bucket=self._on_bucket)
         red = getattr(self, "_reducer", None)
+        eng = plan.e
+        # one GPU: the optimizer update of a gradient bucket goes out on the side stream right behind the bucket's reduction, under the
+        # rest of the backward pass (Ranger.step_buckets_*), instead of behind the whole pass
+        early = (optimizer is not None and red is None and self._on_bucket is None and eng.wgrad_stream and hasattr(optimizer, "step_buckets_begin")
+                 and os.environ.get("GDRN_EARLY_OPT", "1") != "0")
+        if early:
+            if getattr(eng, "_bucket_of", None) is None:
+                off = {id(eng.P[n]): eng.grad_offsets[n] for n in eng.param_names}
+                eng._bucket_of = lambda p_, off=off, bb=eng.bucket_bounds: next(i for i, (lo, hi) in enumerate(bb) if lo <= off[id(p_)] < hi)
+            early = optimizer.step_buckets_begin({eng.P[n]: eng.grads[n] for n in eng.param_names}, eng._bucket_of, len(eng.bucket_bounds))
+        if early:
+            packed = []
+
+            def bucket_done(b):   # called on the side stream behind the bucket's weight-gradient reduction
+                optimizer.step_bucket(b)
+                packed.append(eng.repack_bucket(b))   # ... and the bucket's operand copies for the next step
+
+            plan.run_backward(kctx, on_bucket=bucket_done)
+            optimizer.step_buckets_end()
+            if packed and all(packed):
+                eng.mark_packed()
+            return plan.losses * self._loss_w
+        plan.run_backward(kctx, on_bucket=self._on_bucket)
         gs = 1.0
         if red is not None:
             red.wait()

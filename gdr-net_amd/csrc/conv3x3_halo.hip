@@ -78,6 +78,30 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ s
     }
 }
 
+#ifdef HALO_DBG
+__device__ unsigned long long* g_halo_dbg;
+__device__ __forceinline__ unsigned long long halo_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+struct HaloDbg {
+    unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
+    int slot, lane;
+    __device__ ~HaloDbg() {
+        t[4] = halo_clock();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t[5] = halo_clock();
+        if (lane == 0 && g_halo_dbg)
+            for (int i = 0; i < 6; ++i) g_halo_dbg[(size_t)slot * 8 + i] = t[i];
+    }
+};
+extern "C" int gdrn_halo_set_dbg(unsigned long long* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -3; }
+#define HALO_STAMP(i_) hdbg_.t[i_] = halo_clock();
+#else
+#define HALO_STAMP(i_)
+#endif
+
 template <typename T, int TH, int TW, int BN, int XF>
 __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);
@@ -96,6 +120,12 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
+#ifdef HALO_DBG
+    HaloDbg hdbg_;
+    hdbg_.slot = (int)blockIdx.x * 4 + wave;
+    hdbg_.lane = lane;
+#endif
+    HALO_STAMP(0)
 
     const int NTn = (p.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
@@ -234,7 +264,9 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
         WRITEP(q0, u0, 0, 0, 0) WRITEP(q1, u1, 0, 1, 0) WRITEP(q2, u2, 0, 2, 0) WRITEP(q3, u3, 0, 3, 0) WRITEP(q4, u4, 0, 4, 0)
         WRITEP(q5, u5, 0, 5, 0) WRITEP(q6, u6, 0, 6, 0) WRITEP(q7, u7, 0, 7, 0) WRITEP(q8, u8, 0, 8, 0)
     }
+    HALO_STAMP(1)
     __syncthreads();
+    HALO_STAMP(2)
 
     // One tap stage = 2 k-steps x (FN weight frags in registers) x (FM pixel frags from LDS at immediate offsets), software
     // pipelined over the k-steps: the LDS reads of k-step 1 are issued before the MFMAs of k-step 0, and the reads of the
@@ -286,6 +318,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
         if (more_p) { WRITEP(rp1, rq1, pb ^ 1, 7, kc + 1) WRITEP(rp2, rq2, pb ^ 1, 8, kc + 1) }
         __syncthreads();
     }
+    HALO_STAMP(3)
 #undef LOADW
 #undef LOADP
 #undef WRITEP

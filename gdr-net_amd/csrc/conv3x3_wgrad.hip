@@ -368,20 +368,30 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     return GDRN_OK;
 }
 
-extern "C" int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
+// lds_bytes > the kernel's own 64 KiB: the launch requests that much dynamic LDS, i.e. limits itself to ONE workgroup per CU and leaves the
+// rest of the CU (LDS, one wave slot per SIMD, half the register file) to another stream's kernels -- the engine runs a bucket's grouped
+// weight gradient on a side stream under the next bucket's chain of small-map data-gradient kernels (one workgroup per CU, MFMA pipe 20 % busy).
+extern "C" int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int lds_bytes,
+                                            void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    constexpr size_t smem = 2 * (size_t)STAGEB;
-    static bool attr_set = false;
-    if (!attr_set) {
+    constexpr size_t smem0 = 2 * (size_t)STAGEB;
+    const size_t smem = std::max(smem0, (size_t)std::max(lds_bytes, 0));
+    if (smem > 160 * 1024) return GDRN_ERR_ARG;
+    static size_t attr_set = 0;
+    if (attr_set < smem) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return GDRN_ERR_LAUNCH;
-        attr_set = true;
+        attr_set = smem;
     }
     hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(nblocks), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev,
                        blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
+}
+
+extern "C" int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
+    return gdrn_conv3x3_wgrad_multi_lds(tasks_dev, blk_start_dev, ntasks, nblocks, 0, stream);
 }
 
 extern "C" int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {

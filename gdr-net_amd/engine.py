@@ -58,7 +58,11 @@ class Engine:
         import os as _os
 
         self.use_halo = self.dt == BF16  # 3x3 stride-1 convs on the halo-tiled kernel (bf16); the fp32 parity mode keeps the generic one
-        self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "0") == "1"  # bucket-end work on a 2nd stream (measured: no gain on one GPU)
+        # bucket-end work (grouped weight gradients, their reduction, gradient unpack) on a 2nd stream: it runs under the next bucket's chain of
+        # small-map data-gradient kernels (one workgroup per CU, matrix pipe ~20 % busy); same-box A/B: 8.05 -> 7.85 ms/step with the LDS request
+        # below, 7.77 with the optimizer update of a bucket behind its reduction on that stream (GDRN.train_step, GDRN_EARLY_OPT)
+        self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "1") == "1"
+        self.wgrad_side_lds = int(_os.environ.get("GDRN_WGRAD_SIDE_LDS", str(84 * 1024)))  # LDS request of a side-stream weight-gradient launch
         self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
         self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
         self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
@@ -78,6 +82,8 @@ class Engine:
         if nb is None:
             import torch.distributed as _dist
 
+            # (a fifth bucket layer2 | layer1 + stem, to expose less of the last bucket's weight gradient behind the side stream, measured
+            #  +0.12 ms: three more launches and a weight gradient of layer2 that runs at one workgroup per CU under too short a chain)
             nb = 5 if (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) else 4
         if str(nb) not in ("4", "5"):
             raise ValueError(f"GDRN_BUCKETS={nb!r}: the gradient bucket layouts are 4 (one GPU) and 5 (data parallel)")
@@ -114,6 +120,7 @@ class Engine:
             return False
         self.bucket_first_group, self.bucket_marks = BUCKET_LAYOUTS[nb]
         self.bucket_bounds = self._bucket_bounds()
+        self._bucket_of = None
         self.plans.clear()
         return True
 
@@ -316,6 +323,22 @@ class Engine:
         self._pack_tasks = to_device_table(tasks, self.dev)
         self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.dev)
         self._pack_n = (len(tasks), starts[-1])
+        # the same tasks per gradient bucket (repack_bucket): the fused train step rebuilds a bucket's operands right behind its optimizer update
+        off_of = lambda t: self.grad_offsets[names_of[t.src]]
+        names_of = {}
+        for key, L in self.layers.items():
+            if L.kind != "stem":
+                names_of[(self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]).data_ptr()] = L.src[0]
+        self._pack_buckets = []
+        for lo, hi in self.bucket_bounds:
+            sel = [(t, n) for t, n in zip(tasks, [starts[i + 1] - starts[i] for i in range(len(tasks))]) if lo <= off_of(t) < hi]
+            if not sel:
+                self._pack_buckets.append(None)
+                continue
+            st_ = [0]
+            for _, n in sel:
+                st_.append(st_[-1] + n)
+            self._pack_buckets.append((to_device_table([t for t, _ in sel], self.dev), torch.tensor(st_, dtype=torch.int32, device=self.dev), len(sel), st_[-1]))
 
     def repack(self, force=False):
         """(Re)build the kernel-layout operand copies of the weights after a parameter update: one multi-tensor
@@ -338,6 +361,32 @@ class Engine:
             self._build_pack_table()
             self._pack_dirty = False
         check(lib.gdrn_pack_multi(ptr(self._pack_tasks), ptr(self._pack_starts), self._pack_n[0], self._pack_n[1], self.dt, st), "pack_multi")
+
+    def repack_bucket(self, b):
+        """rebuild the operand copies of the layers whose parameters lie in gradient bucket b, on the current stream (the fused train step
+        calls this behind the bucket's optimizer update on the side stream; mark_packed() afterwards)."""
+        if not hasattr(self, "_pack_tasks") or getattr(self, "_pack_dirty", False):
+            return False
+        lib, st = self.lib, self._stream()
+        nb = len(self.bucket_bounds)
+        if b == 0:
+            with torch.no_grad():  # fc_r | fc_t as one 9-row layer (pnp parameters: first bucket)
+                torch._foreach_copy_([self.rt_w[:6], self.rt_w[6:], self.rt_b[:6], self.rt_b[6:]],
+                                     [self.P["pnp_net.fc_r.weight"].detach(), self.P["pnp_net.fc_t.weight"].detach(), self.P["pnp_net.fc_r.bias"].detach(),
+                                      self.P["pnp_net.fc_t.bias"].detach()])
+        if b == nb - 1:
+            Ls = self.layers["backbone.conv1"]
+            check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
+            if self.stem_direct:
+                check(lib.gdrn_pack_stem_w32(ptr(self.P[Ls.src[0]]), ptr(self.stem_w32), self.dt, st), "pack_stem_w32")
+        pb = self._pack_buckets[b]
+        if pb is not None:
+            check(lib.gdrn_pack_multi(ptr(pb[0]), ptr(pb[1]), pb[2], pb[3], self.dt, st), "pack_multi(bucket)")
+        return True
+
+    def mark_packed(self):
+        """the operand copies match the parameters' current versions (every bucket went through repack_bucket)"""
+        self._versions["sig"] = tuple(p._version for p in self.P.values())
 
     # ------------------------------------------------------------------------------------------ plans
     def plan(self, B, bn_train, with_loss):
@@ -731,8 +780,12 @@ class Plan:
             self._wgrad_tables.append((tab, stt))
             nt, nb = len(tasks), starts[-1]
 
-            def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb):
-                check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab), ptr(stt), nt, nb, st), "conv3x3_wgrad_multi")
+            last_bucket = bkt == len(first_group) - 1
+
+            def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
+                # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
+                # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
+                check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if e.wgrad_stream else 0, st), "conv3x3_wgrad_multi")
 
             run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
             run.side = True

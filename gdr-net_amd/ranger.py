@@ -99,6 +99,56 @@ class Ranger(Optimizer):
         cache[gi] = (key, tab, stt, len(tasks), starts[-1], lr)
         return cache[gi][1:5]
 
+    # ---- per-bucket stepping: the fused train step (GDRN.train_step) launches the update of a gradient bucket on the side stream as soon
+    # as that bucket's gradients are complete, under the rest of the backward pass, instead of three launches behind it
+    @torch.no_grad()
+    def step_buckets_begin(self, grads, bucket_of, nbuckets, grad_scale=1.0):
+        """grads: dict param -> fp32 gradient; bucket_of(param) -> bucket index.  Advances the step counters and prepares one
+        gdrn_ranger_multi launch per (param group, bucket).  False: the per-bucket path does not apply (mixed step counts, CPU
+        parameters, ...) and nothing was changed -- call step()."""
+        plan = []
+        for gi, group in enumerate(self.param_groups):
+            items = [(p, grads[p].detach()) for p in group["params"] if grads.get(p) is not None]
+            if not items:
+                continue
+            if any(p.device.type != "cuda" or p.dtype != torch.float32 or g.dtype != torch.float32 or not g.is_contiguous() for p, g in items):
+                return False
+            states = [self._init_state(p) for p, _ in items]
+            if len({s["step"] for s in states}) != 1:
+                return False
+            plan.append((gi, group, items, states))
+        lib = cabi.load()
+        self._bucket_launches = [[] for _ in range(nbuckets)]
+        self._bucket_params = []
+        for gi, group, items, states in plan:
+            for s in states:
+                s["step"] += 1
+            step = states[0]["step"]
+            beta1, beta2 = group["betas"]
+            n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
+            by_b = {}
+            for it in items:
+                by_b.setdefault(bucket_of(it[0]), []).append(it)
+            for b, its in by_b.items():
+                tab, stt, nt, nrows = self._multi_table((gi, b), its, float(group["lr"]))
+                self._bucket_launches[b].append((tab, stt, nt, nrows, beta1, beta2, group["eps"], group["weight_decay"], step_size,
+                                                 1 if n_sma > self.N_sma_threshhold else 0, 1 if step % group["k"] == 0 else 0, float(grad_scale)))
+            self._bucket_params += [p for p, _ in items]
+        self._bucket_lib = lib
+        return True
+
+    def step_bucket(self, b):
+        """launch the updates of bucket b on the current stream"""
+        st = torch.cuda.current_stream().cuda_stream
+        for (tab, stt, nt, nrows, beta1, beta2, eps, wd, step_size, adaptive, lookahead, gs) in self._bucket_launches[b]:
+            cabi.check(self._bucket_lib.gdrn_ranger_multi(tab.data_ptr(), stt.data_ptr(), nt, nrows, beta1, beta2, eps, wd, step_size, adaptive, lookahead,
+                                                          self.alpha, gs, st), "ranger_multi")
+
+    def step_buckets_end(self):
+        for p in self._bucket_params:
+            _bump_version(p)  # updated in place behind autograd's back: tell repack() the weights changed
+        self._bucket_launches, self._bucket_params = [], []
+
     @torch.no_grad()
     def step(self, closure=None, grads=None, grad_scale=1.0):
         """grads: optional dict param -> fp32 gradient tensor (used by the fused train step to read the

@@ -201,6 +201,8 @@ int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* p);
  * ws != NULL and splits = gdrn_conv3x3_wgrad_splits() of an explicit request (no empty split);
  * blk_start[i] = sum_{j<i} (Cout_j/64)*(Cin_j/64)*splits_j, nblocks = blk_start[ntasks]. */
 int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+/* the same with an LDS request of lds_bytes (> 64 KiB: one workgroup per CU, the rest of the CU stays free for another stream's kernels) */
+int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int lds_bytes, void* stream);
 /* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
 typedef struct gdrn_wreduce_task {
     const float* ws;
