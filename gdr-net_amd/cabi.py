@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgdrn_hip.so")
+LIB_PATH = os.environ.get("GDRN_HIP_LIB") or os.path.join(_HERE, "lib", "libgdrn_hip.so")   # (GDRN_HIP_LIB: A/B runs of two builds on one box)
 
 F32, BF16 = 0, 1
 PREZEROED = 0x100  # GDRN_PREZEROED

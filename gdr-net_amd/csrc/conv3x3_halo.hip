@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
     hdbg_.lane = lane;
 #endif
     HALO_STAMP(0)
+    // the data-gradient chain shares its CUs with a side-stream weight-gradient launch (engine: wgrad_stream): its waves go first
+    __builtin_amdgcn_s_setprio(2);
 
     const int NTn = (p.Cout + BN - 1) / BN;
     int bid = blockIdx.x;

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
     unsigned char* sW = smem + 512;                              // 2 stages x BN rows x 128 B
     unsigned char* sX = sW + 2 * BN * ROWB;                      // 2 stages x BM rows x 128 B
 
+    __builtin_amdgcn_s_setprio(2);  // (the chain shares its CUs with a side-stream weight-gradient launch: its waves go first)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;

@@ -62,6 +62,8 @@ class Engine:
         # small-map data-gradient kernels (one workgroup per CU, matrix pipe ~20 % busy); same-box A/B: 8.05 -> 7.85 ms/step with the LDS request
         # below, 7.77 with the optimizer update of a bucket behind its reduction on that stream (GDRN.train_step, GDRN_EARLY_OPT)
         self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "1") == "1"
+        self.tail_overlap = _os.environ.get("GDRN_TAIL_OVERLAP", "1") == "1"  # last bucket's weight gradients under the stem's backward
+        self.side_small = _os.environ.get("GDRN_SIDE_SMALL", "1") == "1"  # generic weight gradients / bias gradients on the side stream too
         self.wgrad_side_lds = int(_os.environ.get("GDRN_WGRAD_SIDE_LDS", str(84 * 1024)))  # LDS request of a side-stream weight-gradient launch
         self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
         self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
@@ -584,7 +586,13 @@ class Plan:
         bco, bci = (64 if cout <= 64 else 128), (128 if cin % 128 == 0 else 64)
         kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>"
         run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + ":wgrad")
+        run.side = e.side_small  # feeds only the optimizer: off the data-gradient chain (side stream, see run_backward)
         return run
+
+    def _side(self, op):
+        """mark a backward op whose result only the optimizer reads: it may run on the side stream (Engine.side_small)"""
+        op.side = self.e.side_small
+        return op
 
     @staticmethod
     def _pad16(t, flat):
@@ -623,7 +631,8 @@ class Plan:
             self.grad_group[n_] = len(self.bwd_groups)
         if L.kind == "stem":
             g = e.grads[L.src[0]]
-            return lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w")
+            # (side like the weight-gradient launch whose result it reads: the two stay in order on one stream)
+            return self._side(lambda st, ctx: check(lib.gdrn_unpack_stem_w(ptr(L.dwp), ptr(g), st), "unpack_stem_w"))
         self._unpack_pending.append((len(self.bwd_groups), L))
         return None  # marker, dropped when the groups are flattened
 
@@ -728,6 +737,20 @@ class Plan:
         return PackTask(src=packed_ptr, dst=grad.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=0, s1=s1, s2=s2,
                         st=st, sb=sb, n=A1v * A2v * T * Bv, frag=0, pad_=0)
 
+    def _bucket_end(self, bkt, op):
+        """place a bucket-end op (grouped weight gradient, its reduction, gradient unpack).  Behind the bucket's last group -- except for the
+        LAST bucket with the side stream on: its ops only need the layers' data gradients, which exist before the stem's backward (max-pool
+        backward, BatchNorm coefficients, stem weight gradient: ~0.2 ms on the main stream), so they go in FRONT of the stem group and run
+        under it instead of behind it."""
+        e = self.e
+        g = self.bwd_groups[e.bucket_first_group[bkt]]
+        if e.wgrad_stream and e.tail_overlap and bkt == len(e.bucket_first_group) - 1 and e.bucket_first_group[bkt] == 0:
+            n = getattr(self, "_front_n", 0)
+            g.insert(n, op)
+            self._front_n = n + 1
+        else:
+            g.append(op)
+
     def _finish_unpack(self):
         """One gdrn_unpack_multi per gradient bucket (pnp | head | layer4 | layer3 | rest), appended to the backward group that
         completes the bucket, so the RCCL exchange of a bucket still starts as soon as its gradients exist."""
@@ -789,7 +812,7 @@ class Plan:
 
             run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
             run.side = True
-            self.bwd_groups[first_group[bkt]].append(run)
+            self._bucket_end(bkt, run)
 
         per_bucket = {i: [] for i in range(len(first_group))}
         red_bucket = {i: [] for i in range(len(first_group))}
@@ -821,7 +844,7 @@ class Plan:
                 check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi")
 
             unpack.side = True
-            self.bwd_groups[first_group[bkt]].append(unpack)
+            self._bucket_end(bkt, unpack)
         for bkt, tasks in red_bucket.items():
             if not tasks:
                 continue
@@ -836,7 +859,7 @@ class Plan:
                 check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi")
 
             wreduce.side = True
-            self.bwd_groups[first_group[bkt]].append(wreduce)
+            self._bucket_end(bkt, wreduce)
 
     # ---- graph -------------------------------------------------------------------------------
     def _build(self):
@@ -1168,7 +1191,7 @@ class Plan:
             gb = e.grads[h + "23.bias"]
             self.grad_group[h + "23.bias"] = len(self.bwd_groups)
             self._zero_regions.append(self._grad16(gb))
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad"))
+            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad")))
             op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256,
                                bnb=(prev_bn, prev_raw, None, True) if e.gemm_bnb else None)
             grp.append(op)
@@ -1254,13 +1277,13 @@ class Plan:
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f2), ptr(f2), ptr(d_f2p), B * 256, e.dt, st), "leaky_bwd"))
             grp.append(self._wgrad(L2, f1, d_f2p, 1, 1, 1, 1, 1, 0, 1024, 256, 1024, 256))
             grp.append(self._unpack(L2))
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt | PREZEROED, st), "bias_grad"))
+            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt | PREZEROED, st), "bias_grad")))
             op, _ = self._conv(L2, d_f2p, 256, d_f1, 1, 1, 1, 1, 1, 0, w=L2.wd, rows=L2.rows_d, cin=256, cout=1024)
             grp.append(op)
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f1), ptr(f1), ptr(d_f1p), B * 1024, e.dt, st), "leaky_bwd"))
             grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024))
             grp.append(self._unpack(L1))
-            grp.append(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad"))
+            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad")))
             op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
             grp.append(op)
             self.bwd_groups.append(grp)
@@ -1336,7 +1359,12 @@ class Plan:
                 in_side = False
                 op(st, ctx)
                 if i in marks:
-                    on_bucket(marks[i])
+                    if used_side:     # the bucket's side-stream work (weight-gradient reduction) is part of the bucket
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            on_bucket(marks[i])
+                    else:
+                        on_bucket(marks[i])
         if used_side:
             main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
 

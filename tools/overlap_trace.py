@@ -3,7 +3,7 @@ import csv
 import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "pack_multi_kernel" in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "pack_image_kernel" in r["Kernel_Name"]]
 a, b = marks[-2], marks[-1]
 seg = rows[a:b]
 t0 = int(seg[0]["Start_Timestamp"])

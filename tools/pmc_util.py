@@ -37,9 +37,9 @@ def counters(path):
     return tot, cnt
 
 
-def durations(path, marks="pack_multi_kernel", last=4):
+def durations(path, marks="pack_image_kernel", last=4):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-    m = [i for i, r in enumerate(rows) if marks in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]
+    m = [i for i, r in enumerate(rows) if marks in r["Kernel_Name"]]
     seg = rows[m[-last - 1]:m[-1]] if len(m) > last else rows
     d, c = defaultdict(float), defaultdict(int)
     for r in seg:

@@ -1,5 +1,5 @@
 """rocprofv3 --kernel-trace CSV -> steady-state per-step kernel table.
-A training step starts with the operand repack (`pack_multi_kernel`); the last N complete steps of the trace are averaged, so one-time
+A step starts with the image repack of its forward pass (`pack_image_kernel`); the last N complete steps of the trace are averaged, so one-time
 work (plan construction, optimizer-state initialisation, warm-up allocations) is not attributed to the step.
 Usage: python tools/trace_steps.py <kernel_trace.csv> [N=5] [header ...] > profiles/<name>.txt"""
 import collections
@@ -17,7 +17,7 @@ def main():
     for h in sys.argv[3:]:
         print("# " + h)
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "pack_multi_kernel" in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "pack_image_kernel" in r["Kernel_Name"]]
     if len(marks) < n + 1:
         raise SystemExit("only %d step marks in the trace" % len(marks))
     a, b = marks[-n - 1], marks[-1]
