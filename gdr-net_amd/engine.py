@@ -84,8 +84,8 @@ class Engine:
         if nb is None:
             import torch.distributed as _dist
 
-            # (a fifth bucket layer2 | layer1 + stem, to expose less of the last bucket's weight gradient behind the side stream, measured
-            #  +0.12 ms: three more launches and a weight gradient of layer2 that runs at one workgroup per CU under too short a chain)
+            # (with the side stream: a fifth bucket layer2 | layer1 + stem measured +0.12 ms, layer2 moved into the layer4 + layer3 bucket
+            #  +0.11 ms -- a weight gradient at one workgroup per CU wants a chain at least 1.7x its stand-alone time to hide under)
             nb = 5 if (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) else 4
         if str(nb) not in ("4", "5"):
             raise ValueError(f"GDRN_BUCKETS={nb!r}: the gradient bucket layouts are 4 (one GPU) and 5 (data parallel)")
