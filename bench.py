@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads-sweep", action="store_true",
+                    help="only the cpu_baseline leg, for several torch thread counts (the measurement behind cpu_baseline.cores; no GPU work)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra no-optimizer / inference loops")
     ap.add_argument("--fwd-only", action="store_true", help="inference throughput (eval BN, test-mode pose decode)")
     ap.add_argument("--dist-force", action="store_true",
@@ -129,6 +131,43 @@ def cpu_baseline():
                       "steps after 2 warm-ups, %d threads" % cores,
             "train_step_bs4_roi_s": round(4 / t4, 3), "fwd_bwd_without_optimizer_bs4_roi_s": round(4 / n4, 3),
             "inference_fwd_bs64_roi_s": round(64 / i64, 3), "inference_fwd_bs4_roi_s": round(4 / i4, 3)}
+
+
+def cpu_threads_sweep():
+    """the cpu_baseline leg's training step at bs = 64 for several thread counts: one line per count (profiles/r03_cpu_threads_sweep.txt)"""
+    import torch
+
+    from gdrnet_amd import synth
+    from oracle import gdrn_oracle as O
+    from oracle import ranger_oracle as R
+
+    sd = synth.make_state_dict(0)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    batch = synth.make_batch(64, seed=1)
+    state = [dict() for _ in names]
+
+    def step():
+        out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})
+        sum(out["loss_dict"].values()).backward()
+        R.ranger_step([sd[k] for k in names], [sd[k].grad for k in names], state, lr=1e-4)
+        for k in names:
+            sd[k].grad = None
+
+    ncpu = os.cpu_count() or 1
+    print("# %s, %d logical CPUs; oracle training step (fwd + 8 losses + bwd + Ranger) at bs = 64, 1 warm-up, best of 2" % (_cpu_model(), ncpu))
+    for nt in (8, 16, 32, 48, 64, 96, 128, 192):
+        if nt > ncpu:
+            break
+        torch.set_num_threads(nt)
+        step()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        print("threads %3d: %6.2f s per step -> %5.2f RoI/s" % (nt, min(ts), 64 / min(ts)), flush=True)
 
 
 def measure_roofline(model, plan, kctx, dtype):
@@ -252,6 +291,8 @@ def roi_cropper_extras(B, dev, timed):
 
 def main():
     args = parse()
+    if args.cpu_threads_sweep:
+        return cpu_threads_sweep()
     import torch
     import torch.distributed as dist
 

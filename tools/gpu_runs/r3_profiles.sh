@@ -49,7 +49,7 @@ timeout 300 python tools/v3check.py full 12 2>&1 | grep -v "amdgpu.ids" > $O/r03
 timeout 200 python tools/v3dbg.py 12 2>&1 | grep -v "amdgpu.ids\|start spread" > $O/r03_v3_cycle_stamps_bs64.txt
 timeout 200 python tools/halodbg.py 2>&1 | grep -v "amdgpu.ids" | sed 's/ | first workgroup.*//' > $O/r03_halo_cycle_stamps_bs64.txt
 timeout 100 python tools/ubench/mfma_rate.py 2>&1 | grep -v "amdgpu.ids" > $O/r03_mfma_rate_ubench.txt
-timeout 400 python tools/cpu_threads_sweep.py > $O/r03_cpu_threads_sweep.txt 2>&1
+timeout 500 python bench.py --cpu-threads-sweep > $O/r03_cpu_threads_sweep.txt 2>&1
 # the driver-sized bench line last (it reports roofline.traffic / mfma_util from the PMC summary above only if that summary sits in profiles/)
 cp $O/r03_mfma_util_hbm_bs64_bf16.json $O/r03_mfma_util_hbm_bs64_bf16.txt profiles/
 GDRN_LAYER_TABLE=$O/r03_layer_table_bs64_bf16.txt timeout 900 python bench.py > $O/r03_bench_bs64_bf16.json 2> $O/bench.err
