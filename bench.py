@@ -257,12 +257,31 @@ def measure_roofline(model, plan, kctx, dtype):
             row["hbm_gbps"] = round(pk["hbm_gbps"])
         table.append(row)
     best = max(allev, key=lambda x: x[2]["flops"] / max(x[0].elapsed_time(x[1]) - ovh_ms, 1e-6))
+    # the same kernel INSIDE the step as the timed region runs it (two streams: bucket-end work shares the CUs with the gradient chain):
+    # events on the stream each launch goes to, over three real backward passes; this is the duration rocprofv3 --kernel-trace --stats
+    # of the default command reports for it
+    in_step = None
+    if getattr(plan.e, "wgrad_stream", False):
+        plan.op_events = sink = []
+        for _ in range(3):
+            plan.run_forward(kctx)
+            plan.run_backward(kctx)
+        torch.cuda.synchronize()
+        plan.op_events = None
+        dev_ = [(a.elapsed_time(b) - ovh_ms, m) for a, b, m, _ in sink if m["kernel"] == dom]
+        if dev_:
+            ms_ = sum(max(t, 1e-6) for t, _ in dev_)
+            tf_ = sum(m["flops"] for _, m in dev_) / (ms_ * 1e-3) / 1e12
+            in_step = {"avg_launch_us": round(ms_ * 1e3 / len(dev_), 2), "achieved": round(tf_, 1), "frac": round(tf_ / peak, 3),
+                       "note": "the launch as the timed step runs it: on the side stream at one workgroup per CU, sharing the CUs with the chain kernels"}
     return {"bound": "mfma", "kernel": dom, "launches_per_step": len(ev), "avg_launch_us": round(tot_ms * 1e3 / max(len(ev), 1), 2),
             "algorithmic_gflop_per_launch": round(flops / max(len(ev), 1) / 1e9, 3), "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "mfma_util": (round(pmc[dom]["mfma_util"], 3) if dom in pmc and "mfma_util" in pmc[dom] else None),
             "hbm_gbps": (round(pmc[dom]["hbm_gbps"]) if dom in pmc else None),
-            "event_overhead_us": round(ovh_ms * 1e3, 2), "conv_kernels": table,
+            "event_overhead_us": round(ovh_ms * 1e3, 2),
+            "bracket": "every launch of the step issued alone on one stream, in the step's own launch configuration, between two HIP events",
+            "in_step": in_step, "conv_kernels": table,
             "best_launch": {"kernel": best[2]["kernel"], "layer": best[2]["layer"],
                             "achieved": round(best[2]["flops"] / ((best[0].elapsed_time(best[1]) - ovh_ms) * 1e-3) / 1e12, 1)}}
 

@@ -409,6 +409,22 @@ class Engine:
         return p
 
 
+def _probed(op, sink):
+    """op wrapped in a pair of timing events recorded on the stream it is launched on (bench.py's in-step roofline bracket)"""
+    def run(st, ctx):
+        s = torch.cuda.ExternalStream(st) if st else torch.cuda.default_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parts = getattr(op, "parts", None)   # conv launch + the BatchNorm-coefficient launch behind it: the conv alone is bracketed
+        a.record(s)
+        (parts[0] if parts else op)(st, ctx)
+        b.record(s)
+        if parts:
+            parts[1](st, ctx)
+        sink.append((a, b, op.meta, bool(getattr(op, "side", False))))
+    run.side = getattr(op, "side", False)
+    return run
+
+
 class Plan:
     """Static buffers + pre-bound call lists for one (batch size, train/eval) configuration."""
 
@@ -1346,7 +1362,10 @@ class Plan:
         # data-gradient / BatchNorm kernels (one workgroup per CU on the small feature maps) shares the CUs with it.
         side = e.side_stream() if e.wgrad_stream else None
         used_side = in_side = False
+        probe = getattr(self, "op_events", None)   # bench.py: [(start, end, meta, on_side)] HIP events around the conv launches of THIS pass
         for i, op in enumerate(self.bwd):
+            if probe is not None and getattr(op, "meta", None) is not None:
+                op = _probed(op, probe)
             if side is not None and getattr(op, "side", False):
                 if not in_side:
                     side.wait_stream(main)  # everything enqueued so far on the main stream
