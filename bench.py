@@ -25,6 +25,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises (gdr-net_amd/__init__.py explains)
 
 FLOP_PER_ROI_TRAIN = 68.16e9  # 34.08 GMAC fwd+bwd per 256x256 RoI
 PEAK_BF16 = 2.5e15            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)

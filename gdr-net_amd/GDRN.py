@@ -471,23 +471,36 @@ class GDRN(nn.Module):
             plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version)
         red = getattr(self, "_reducer", None)
         eng = plan.e
-        # one GPU: the optimizer update of a gradient bucket goes out on the side stream right behind the bucket's reduction, under the
-        # rest of the backward pass (Ranger.step_buckets_*), instead of behind the whole pass
-        early = (optimizer is not None and red is None and self._on_bucket is None and eng.wgrad_stream and hasattr(optimizer, "step_buckets_begin")
-                 and os.environ.get("GDRN_EARLY_OPT", "1") != "0")
+        # The optimizer update of a gradient bucket goes out as soon as the bucket is final, under the rest of the backward pass
+        # (Ranger.step_buckets_*), instead of behind the whole pass: on one GPU on the engine's side stream right behind the bucket's
+        # weight-gradient reduction; with a GradReducer attached (dist.attach) on the reducer's stream right behind the bucket's all-reduce,
+        # with the 1/world factor folded into the update.  The bucket's operand copies for the next step follow on the same stream.
+        mine = red is not None and self._on_bucket == red.on_bucket and red.defer_scale and (red.cuda or not red.active)
+        early = (optimizer is not None and (mine or (red is None and self._on_bucket is None)) and eng.wgrad_stream
+                 and hasattr(optimizer, "step_buckets_begin") and os.environ.get("GDRN_EARLY_OPT", "1") != "0")
         if early:
-            if getattr(eng, "_bucket_of", None) is None:
+            if getattr(eng, "_bucket_of", None) is None or getattr(eng, "_bucket_of_bounds", None) != tuple(eng.bucket_bounds):
                 off = {id(eng.P[n]): eng.grad_offsets[n] for n in eng.param_names}
                 eng._bucket_of = lambda p_, off=off, bb=eng.bucket_bounds: next(i for i, (lo, hi) in enumerate(bb) if lo <= off[id(p_)] < hi)
-            early = optimizer.step_buckets_begin({eng.P[n]: eng.grads[n] for n in eng.param_names}, eng._bucket_of, len(eng.bucket_bounds))
+                eng._bucket_of_bounds = tuple(eng.bucket_bounds)
+            early = optimizer.step_buckets_begin({eng.P[n]: eng.grads[n] for n in eng.param_names}, eng._bucket_of, len(eng.bucket_bounds),
+                                                 grad_scale=(red.grad_scale if red is not None else 1.0))
         if early:
             packed = []
 
             def bucket_done(b):   # called on the side stream behind the bucket's weight-gradient reduction
+                if red is not None and red.active:
+                    red.on_bucket(b)                       # all-reduce on the reducer's stream behind an event of this stream
+                    with torch.cuda.stream(red.stream):    # ... and behind it, in stream order, the update + the operand copies
+                        optimizer.step_bucket(b)
+                        packed.append(eng.repack_bucket(b))
+                    return
                 optimizer.step_bucket(b)
-                packed.append(eng.repack_bucket(b))   # ... and the bucket's operand copies for the next step
+                packed.append(eng.repack_bucket(b))
 
             plan.run_backward(kctx, on_bucket=bucket_done)
+            if red is not None:
+                red.wait()   # the main stream (next forward, the caller) behind every bucket's exchange + update
             optimizer.step_buckets_end()
             if packed and all(packed):
                 eng.mark_packed()

@@ -27,7 +27,12 @@ class GradReducer:
         self.flat, self.bounds, self.group, self.average, self.force = flat, bounds, group, average, force
         self.world = world_size or (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        if self.cuda:
+            from .engine import make_stream
+
+            self.stream = make_stream(flat.device, os.environ.get("GDRN_RED_PRIO", "low"))
+        else:
+            self.stream = None
         self.comm_dtype = comm_dtype
         self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if comm_dtype == "bf16" else None
         self.defer_scale = bool(defer_scale)

@@ -12,6 +12,7 @@ op touches activations.
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 from types import SimpleNamespace as NS
 
@@ -123,6 +124,8 @@ class Engine:
         self.bucket_first_group, self.bucket_marks = BUCKET_LAYOUTS[nb]
         self.bucket_bounds = self._bucket_bounds()
         self._bucket_of = None
+        if hasattr(self, "_pack_tasks"):
+            self._pack_dirty = True   # the per-bucket operand-copy tables (repack_bucket) follow the buckets: rebuilt by the next repack()
         self.plans.clear()
         return True
 
@@ -132,7 +135,7 @@ class Engine:
 
     def side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = make_stream(self.dev, os.environ.get("GDRN_SIDE_PRIO", "low"))
         return self._side
 
     def _empty(self, *shape, dtype=None):
@@ -407,6 +410,30 @@ class Engine:
         else:
             self.plans.move_to_end(key)
         return p
+
+
+_hip_rt = None
+
+
+def make_stream(dev, prio="normal"):
+    """a HIP stream of the given priority class as a torch stream object.  "low": below torch's default streams (torch itself only hands out
+    default- and higher-priority streams): created with hipStreamCreateWithPriority and wrapped; its kernels are dispatched behind those
+    of default-priority streams and it never shares a hardware queue with them."""
+    global _hip_rt
+    if prio == "high":
+        return torch.cuda.Stream(device=dev, priority=-1)
+    if prio != "low":
+        return torch.cuda.Stream(device=dev)
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+    least, greatest = C.c_int(0), C.c_int(0)
+    _hip_rt.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        err = _hip_rt.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(max(least.value, 1)))   # hipStreamNonBlocking
+    if err != 0 or not h.value:
+        raise cabi.GdrnHipError(f"hipStreamCreateWithPriority failed ({err})")
+    return torch.cuda.ExternalStream(h.value, device=dev)
 
 
 def _probed(op, sink):

@@ -459,6 +459,62 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
             dist.destroy_process_group()
 
 
+def test_per_bucket_optimizer_behind_the_allreduce_one_rank_rccl():
+    """The data-parallel train step updates a gradient bucket on the reducer's stream right behind that bucket's all-reduce (and rebuilds the
+    bucket's operand copies there), under the rest of the backward pass.  One-rank RCCL group with force=True: the exchange is the identity
+    and 1/world = 1, so three attached steps must leave the same parameters, optimizer state and losses as three un-attached steps -- a
+    missing stream dependency (update before the exchange, next forward before the operand copies) shows up as a different trajectory."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.distributed as dist
+
+    from gdrnet_amd import dist as gdist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B = 8
+        batch = to_dev(synth.make_batch(B, seed=23))
+        kw = synth.model_kwargs(batch, do_loss=True)
+        kw.pop("do_loss")
+        out = {}
+        for mode in ("plain", "attached", "attached-bf16-wire"):
+            os.environ["GDRN_BUCKETS"] = "5"   # the same bucket layout (= the same grouped weight-gradient launches) on both sides
+            try:
+                model, opt = build("bf16")
+                model.train()
+                red = None
+                if mode != "plain":
+                    red = gdist.attach(model, force=True, comm_dtype="bf16" if mode.endswith("wire") else "fp32")
+                    launched = []
+                    inner = opt.step_bucket
+                    opt.step_bucket = lambda b, inner=inner, launched=launched: (launched.append((b, torch.cuda.current_stream().cuda_stream)), inner(b))[1]
+                losses = [model.train_step(batch["roi_img"], optimizer=opt, **kw).clone() for _ in range(3)]
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("GDRN_BUCKETS", None)
+            if red is not None:
+                assert [b for b, _ in launched] == [0, 1, 2, 3, 4] * 3      # one update per bucket and step ...
+                assert all(s == red.stream.cuda_stream for _, s in launched)   # ... on the reducer's stream, behind the bucket's exchange
+                assert model.engine()._versions["sig"] == tuple(p._version for p in model.engine().P.values())  # operand copies current
+            out[mode] = (torch.stack(losses).cpu(), {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
+                         {i: {k: (v.cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in enumerate(opt.state.values())})
+        la, sa, oa = out["plain"]
+        for mode, tol in (("attached", 2e-5), ("attached-bf16-wire", 2e-2)):   # bf16 wire: gradients rounded to 8 bits on the way
+            lb, sb, ob = out[mode]
+            assert float((la - lb).abs().max() / la.abs().max()) < (1e-5 if mode == "attached" else 5e-3), (mode, la, lb)
+            worst = max(float((sa[k] - sb[k]).abs().max() / (sa[k].abs().max() + 1e-12)) for k in sa if sa[k].numel() > 1)
+            assert worst < tol, (mode, worst)
+            assert all(oa[i]["step"] == ob[i]["step"] == 3 for i in oa)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_postproc_correspondences_vs_reference_golden(golden_dir):
     """N2 on the device: gdrn_correspondences (one launch for the batch) == the reference's get_out_coor / get_out_mask /
     get_img_model_points_with_coords2d chain (golden G7), bit for bit, and == the oracle on a bs=64 batch."""
