@@ -79,7 +79,10 @@ class Engine:
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
-        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "1536"))  # target workgroups of a grouped launch: 2 per CU resident = 512 per round; measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step (non-multiples of 512 lose a partial round)
+        # target workgroups of a grouped weight-gradient launch = three rounds of what is resident: one stream, 2 per CU = 512 per round
+        # (measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step); side stream, 1 per CU = 256 per round (r3: 512: 8.02, 768: 7.575,
+        # 1024: 7.54, 1280: 7.615, 1536: 7.58 -- 768 writes half the partial tiles of 1536 for the same step time)
+        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "768" if self.wgrad_stream else "1536"))
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
