@@ -83,6 +83,9 @@ class Engine:
         # (measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step); side stream, 1 per CU = 256 per round (r3: 512: 8.02, 768: 7.575,
         # 1024: 7.54, 1280: 7.615, 1536: 7.58 -- 768 writes half the partial tiles of 1536 for the same step time)
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "768" if self.wgrad_stream else "1536"))
+        # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
+        # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
+        self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
@@ -854,7 +857,7 @@ class Plan:
             def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
                 # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
                 # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
-                check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if e.wgrad_stream else 0, st), "conv3x3_wgrad_multi")
+                check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
 
             run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
             run.side = True

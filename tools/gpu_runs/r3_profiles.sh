@@ -11,16 +11,16 @@ f() { if ls $O/$1/*/p_$2.csv >/dev/null 2>&1; then ls $O/$1/*/p_$2.csv | head -1
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-roofline --no-extras"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o p -- $B --steps 8 --warmup 3 > $O/trace.log 2>&1
-GDRN_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o p -- $B --steps 8 --warmup 3 > $O/serial.log 2>&1
+GDRN_WGRAD_STREAM=0 GDRN_WGRAD_BLOCKS=768 GDRN_WGRAD_FORCE_LDS=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o p -- $B --steps 8 --warmup 3 > $O/serial.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/infer -o p -- $B --fwd-only --steps 12 --warmup 3 > $O/infer.log 2>&1
 B2="$B --steps 2 --warmup 2"
-GDRN_WGRAD_STREAM=0 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -o p -- $B2 > $O/sq.log 2>&1
-GDRN_WGRAD_STREAM=0 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- $B2 > $O/fetch.log 2>&1
-GDRN_WGRAD_STREAM=0 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- $B2 > $O/write.log 2>&1
+GDRN_WGRAD_STREAM=0 GDRN_WGRAD_BLOCKS=768 GDRN_WGRAD_FORCE_LDS=1 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -o p -- $B2 > $O/sq.log 2>&1
+GDRN_WGRAD_STREAM=0 GDRN_WGRAD_BLOCKS=768 GDRN_WGRAD_FORCE_LDS=1 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- $B2 > $O/fetch.log 2>&1
+GDRN_WGRAD_STREAM=0 GDRN_WGRAD_BLOCKS=768 GDRN_WGRAD_FORCE_LDS=1 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- $B2 > $O/write.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/cal -o p -- python $R/tools/ubench/mfma_rate.py > $O/cal.log 2>&1
 cd $R
 python tools/trace_steps.py $(f trace kernel_trace) 5 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-extras (round 3; bs=64 bf16 train step, default = bucket-end work on the side stream: durations of overlapped kernels include the sharing)" > $O/r03_kernel_steps_bs64_bf16.txt 2>&1
-python tools/trace_steps.py $(f serial kernel_trace) 5 "GDRN_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 ... (round 3; the same step on ONE stream: stand-alone kernel durations, the ones bench.py's roofline brackets measure)" > $O/r03_kernel_steps_serial_bs64_bf16.txt 2>&1
+python tools/trace_steps.py $(f serial kernel_trace) 5 "GDRN_WGRAD_STREAM=0 GDRN_WGRAD_BLOCKS=768 GDRN_WGRAD_FORCE_LDS=1 rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 ... (round 3; the launches of the default step on ONE stream: stand-alone kernel durations, the ones bench.py's roofline brackets measure)" > $O/r03_kernel_steps_serial_bs64_bf16.txt 2>&1
 python tools/overlap_trace.py $(f trace kernel_trace) > $O/r03_side_stream_overlap_bs64_bf16.txt 2>&1
 python tools/pmc_util.py $(f sq counter_collection) $(f fetch counter_collection) $(f write counter_collection) $(f serial kernel_trace) $(f cal counter_collection) $O/r03_mfma_util_hbm_bs64_bf16 > /dev/null 2>&1
 python - <<PY > $O/r03_inference_steps_bs64_bf16.txt 2>&1
@@ -44,12 +44,16 @@ for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
 PY
 cp $(f trace kernel_stats) $O/r03_kernel_stats_bs64_bf16.csv 2>/dev/null
 cp $(f serial kernel_stats) $O/r03_kernel_stats_serial_bs64_bf16.csv 2>/dev/null
-rm -rf $O/trace $O/serial $O/infer $O/sq $O/fetch $O/write $O/cal
+cd /tmp
+GDRN_BUCKETS=5 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/dp -o p -- python $R/bench.py --no-cpu-baseline --no-roofline --no-extras --steps 8 --warmup 3 --dist-force > $O/dp.log 2>&1
+cd $R
+python tools/bucket_timeline.py $(f dp kernel_trace) > $O/r03_bucket_timeline_bs64_bf16.txt 2>&1
+rm -rf $O/trace $O/serial $O/infer $O/sq $O/fetch $O/write $O/cal $O/dp
 timeout 300 python tools/v3check.py full 12 2>&1 | grep -v "amdgpu.ids" > $O/r03_v3_vs_halo_bs64.txt
 timeout 200 python tools/v3dbg.py 12 2>&1 | grep -v "amdgpu.ids\|start spread" > $O/r03_v3_cycle_stamps_bs64.txt
 timeout 200 python tools/halodbg.py 2>&1 | grep -v "amdgpu.ids" | sed 's/ | first workgroup.*//' > $O/r03_halo_cycle_stamps_bs64.txt
 timeout 100 python tools/ubench/mfma_rate.py 2>&1 | grep -v "amdgpu.ids" > $O/r03_mfma_rate_ubench.txt
-timeout 500 python bench.py --cpu-threads-sweep > $O/r03_cpu_threads_sweep.txt 2>&1
+[ "$SWEEP" = "1" ] && timeout 500 python bench.py --cpu-threads-sweep > $O/r03_cpu_threads_sweep.txt 2>&1   # ~4 minutes of host time: only on request
 # the driver-sized bench line last (it reports roofline.traffic / mfma_util from the PMC summary above only if that summary sits in profiles/)
 cp $O/r03_mfma_util_hbm_bs64_bf16.json $O/r03_mfma_util_hbm_bs64_bf16.txt profiles/
 GDRN_LAYER_TABLE=$O/r03_layer_table_bs64_bf16.txt timeout 900 python bench.py > $O/r03_bench_bs64_bf16.json 2> $O/bench.err
