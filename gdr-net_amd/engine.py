@@ -83,6 +83,11 @@ class Engine:
         # (measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step); side stream, 1 per CU = 256 per round (r3: 512: 8.02, 768: 7.575,
         # 1024: 7.54, 1280: 7.615, 1536: 7.58 -- 768 writes half the partial tiles of 1536 for the same step time)
         self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "768" if self.wgrad_stream else "1536"))
+        # extra cuts of the grouped weight-gradient launches inside a bucket (backward group indices in forward order; "22" = the two 64x64
+        # head layers get their own launch 1 ms before the head bucket is complete).  Measured r3: none 7.48-7.50, "22" 7.53, "23,22" 7.56-7.59,
+        # "22,14" 7.48-7.49, five cuts 7.62-7.64 ms/step: starting the side stream's work earlier only moves the sharing onto the dense
+        # 64x64 data gradients -- off by default
+        self.wgrad_cuts = tuple(int(c) for c in _os.environ.get("GDRN_WGRAD_CUTS", "").split(",") if c.strip())
         # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
         # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
         self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
@@ -817,13 +822,18 @@ class Plan:
         bucket_of = lambda gi: next(i for i, g0 in enumerate(first_group) if gi >= g0)
         # ---- grouped halo weight gradients: a common number of 8x8 pixel patches per workgroup within a bucket, chosen so
         # that the bucket's grid has ~wgrad_blocks workgroups (2 per CU resident); longest-running tasks first
-        wg_bucket = {i: [] for i in range(len(first_group))}
+        # launch groups = the buckets, optionally cut further at e.wgrad_cuts (side stream only): a cut launches the layers in front of it as
+        # soon as THEIR data gradients exist instead of behind the bucket's last one
+        cuts = sorted(set(first_group) | (set(e.wgrad_cuts) if e.wgrad_stream else set()), reverse=True)
+        cut_of = lambda gi: next(c for c in cuts if gi >= c)
+        wg_bucket = {c: [] for c in cuts}
         for gi, L, wp, flops in self._wgrad_deferred:
-            wg_bucket[bucket_of(gi)].append((L, wp, flops))
+            wg_bucket[cut_of(gi)].append((L, wp, flops))
         self._wgrad_tables = []
-        for bkt, items in wg_bucket.items():
+        for cut, items in wg_bucket.items():
             if not items:
                 continue
+            bkt = bucket_of(cut)
             # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
             geo = []
             for L, wp, flops in items:
@@ -859,9 +869,12 @@ class Plan:
                 # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
                 check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
 
-            run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}:wgrad x{nt} ({nb} wg)")
+            run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
             run.side = True
-            self._bucket_end(bkt, run)
+            if cut in first_group:
+                self._bucket_end(bkt, run)
+            else:
+                self.bwd_groups[cut].append(run)   # behind the data gradients of group `cut`, the last-executed one of this launch
 
         per_bucket = {i: [] for i in range(len(first_group))}
         red_bucket = {i: [] for i in range(len(first_group))}
