@@ -435,15 +435,29 @@ def make_stream(dev, prio="normal"):
         return torch.cuda.Stream(device=dev, priority=-1)
     if prio != "low":
         return torch.cuda.Stream(device=dev)
-    if _hip_rt is None:
-        _hip_rt = C.CDLL("libamdhip64.so")
-    least, greatest = C.c_int(0), C.c_int(0)
-    _hip_rt.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
-    h = C.c_void_p()
-    with torch.cuda.device(dev):
-        err = _hip_rt.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(max(least.value, 1)))   # hipStreamNonBlocking
-    if err != 0 or not h.value:
-        raise cabi.GdrnHipError(f"hipStreamCreateWithPriority failed ({err})")
+    try:
+        if _hip_rt is None:
+            # the HIP runtime this process already runs on (torch ships its own copy): opened by the path it was mapped from, so that the
+            # stream belongs to the same runtime instance as torch's streams and this library's launches
+            path = "libamdhip64.so"
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64" in line:
+                        path = line.split()[-1]
+                        break
+            _hip_rt = C.CDLL(path)
+        least, greatest = C.c_int(0), C.c_int(0)
+        _hip_rt.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest))
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            err = _hip_rt.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(max(least.value, 1)))   # hipStreamNonBlocking
+        if err != 0 or not h.value:
+            raise OSError(f"hipStreamCreateWithPriority returned {err}")
+    except (OSError, AttributeError) as ex:   # an optimisation, not a requirement: a default-priority stream computes the same
+        import logging
+
+        logging.getLogger(__name__).warning("low-priority HIP stream unavailable (%s): using a default-priority stream", ex)
+        return torch.cuda.Stream(device=dev)
     return torch.cuda.ExternalStream(h.value, device=dev)
 
 

@@ -459,6 +459,33 @@ def test_bucketed_allreduce_protocol_one_rank_rccl():
             dist.destroy_process_group()
 
 
+def test_low_priority_side_stream_is_a_real_stream_of_lower_priority():
+    """engine.make_stream("low"): a stream created with hipStreamCreateWithPriority below torch's default priority, usable through
+    torch's stream API (events, wait_stream) -- the engine's side stream and the reducer's stream are of this kind."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import ctypes as C
+
+    from gdrnet_amd import engine as E
+
+    s = E.make_stream(torch.device(DEV), "low")
+    assert isinstance(s, torch.cuda.ExternalStream), type(s)   # (a plain torch stream is the logged fallback)
+    prio = C.c_int(-99)
+    assert E._hip_rt.hipStreamGetPriority(C.c_void_p(s.cuda_stream), C.byref(prio)) == 0
+    assert prio.value > 0, prio.value                           # torch's default streams are priority 0, its "high" ones -1
+    main = torch.cuda.current_stream()
+    x = torch.arange(1 << 20, device=DEV, dtype=torch.float32)
+    s.wait_stream(main)
+    with torch.cuda.stream(s):
+        y = x * 2 + 1
+        ev = torch.cuda.Event()
+        ev.record(s)
+    main.wait_event(ev)
+    z = y.sum()
+    torch.cuda.synchronize()
+    assert float(z) == float((torch.arange(1 << 20, dtype=torch.float64) * 2 + 1).sum())
+
+
 def test_per_bucket_optimizer_behind_the_allreduce_one_rank_rccl():
     """The data-parallel train step updates a gradient bucket on the reducer's stream right behind that bucket's all-reduce (and rebuilds the
     bucket's operand copies there), under the rest of the backward pass.  One-rank RCCL group with force=True: the exchange is the identity
