@@ -279,6 +279,44 @@ def test_ranger_follows_an_lr_schedule_without_rebuilding_its_table():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("path", ["multi", "per_tensor", "buckets"])
+def test_ranger_grad_scale_is_the_mean_of_a_sum_allreduce(path):
+    """The data-parallel step hands the 1/world of its SUM all-reduce to the optimizer (Ranger.step(grad_scale=) /
+    step_buckets_begin(grad_scale=)): the kernel multiplies while it reads the gradient.  With 1/world = 1/8 (a power of two: the product
+    is exact) the parameters after four steps on gradients g with grad_scale 1/8 must equal, bit for bit, four steps on g/8 -- for the
+    multi-tensor launch, the per-tensor launches and the per-bucket launches the train step uses behind each bucket's exchange."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.ranger import Ranger
+
+    shapes = ((8, 4, 3, 3), (16, 8), (16,), (6, 5, 3, 3))
+
+    def run(gs):
+        ps = [torch.nn.Parameter(torch.from_numpy(synth.hash_normal(51, f"p{i}", s).astype(np.float32)).to(DEV)) for i, s in enumerate(shapes)]
+        opt = Ranger([{"params": [p]} for p in ps] if path == "per_tensor" else ps, lr=1e-2, weight_decay=1e-3)
+        gbuf = [torch.zeros_like(p) for p in ps]
+        for step in range(4):
+            for i, p in enumerate(ps):
+                g = torch.from_numpy(synth.hash_normal(52 + step, f"g{i}", tuple(p.shape)).astype(np.float32)).to(DEV)
+                gbuf[i].copy_(g if gs != 1.0 else g * 0.125)
+            grads = {p: gbuf[i] for i, p in enumerate(ps)}
+            if path == "buckets":
+                assert opt.step_buckets_begin(grads, lambda p_: 0 if p_ is ps[0] or p_ is ps[1] else 1, 2, grad_scale=gs)
+                opt.step_bucket(0)
+                opt.step_bucket(1)
+                opt.step_buckets_end()
+            else:
+                opt.step(grads=grads, grad_scale=gs)
+        torch.cuda.synchronize()
+        return [p.detach().cpu() for p in ps], [opt.state[p]["step"] for p in ps]
+
+    scaled, steps = run(0.125)
+    plain, _ = run(1.0)
+    assert steps == [4, 4, 4, 4]
+    for a, b in zip(scaled, plain):
+        assert torch.equal(a, b)
+
+
 def test_full_size_properties_bs64():
     """BASELINE config 2 (bs=64, bf16): size-independent properties instead of an oracle run --
     finite losses / gradients, R in SO(3), losses invariant to the order of the RoIs in the batch
