@@ -44,14 +44,6 @@ template <>
 __device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-template <>
-__device__ __forceinline__ f32x4_t mma_step<float>(uint4 a, uint4 b, f32x4_t c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-    return c;
-}
 
 // fragment-major weight packing: granule (16 B) permutation of the row-major [rows][9][Cin] operand
 template <typename T>
