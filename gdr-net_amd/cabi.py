@@ -119,6 +119,7 @@ _SIGS = {
     "gdrn_conv3x3_wgrad_splits": [C.POINTER(WgradParams)],
     "gdrn_conv3x3_wgrad_multi": [P, P, I, I, P],
     "gdrn_conv3x3_wgrad_multi_lds": [P, P, I, I, I, P],
+    "gdrn_conv3x3_wgrad_multi_w128": [P, P, I, I, I, P],
     "gdrn_wgrad_reduce_multi": [P, P, I, I, P],
     "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
     "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],

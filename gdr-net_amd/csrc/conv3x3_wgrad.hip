@@ -16,6 +16,9 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "../../include/gdrn_hip.h"
@@ -23,7 +26,9 @@
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
-constexpr int PITCH = 160;               // bytes per LDS pixel row (64 ch * 2 B + 32 pad)
+// bytes per LDS pixel row of the dY patch: NA fragments of 16 output channels * 2 B + 32 pad.  160 B = 40 banks and 288 B = 72 banks = 8 mod 64
+// both spread the 8 pixels x 32 B a 32-lane transposed read touches over the 64 banks without a conflict
+template <int NA> struct DyGeo { static constexpr int PITCH = NA * 32 + 32, DYB = 64 * PITCH; };
 // per-stage geometry.  Stride 1: an 8x8 patch of output pixels (two 32-pixel k-steps) against the 10x10 input halo patch.
 // Stride 2 (the three ResNet stage-entry convs, the three Patch-PnP convs, and the head's ConvTranspose with the roles of
 // input and output gradient swapped): a 4x8 patch of output pixels (one k-step) against the (2*4+1) x (2*8+1) = 9x17 input
@@ -35,9 +40,14 @@ template <int S> struct Geo;
 // (8 * 160 B = 0 mod 256 B): a 2-way conflict on every X read.
 template <> struct Geo<1> { static constexpr int TH = 8, KS = 2, PW = 10, PH = 10, NX = 4, ND = 2, XP = 160; };
 template <> struct Geo<2> { static constexpr int TH = 4, KS = 1, PW = 17, PH = 9, NX = 5, ND = 1, XP = 144; };
-constexpr int DYB = 64 * PITCH;          // dY patch: up to 8x8 pixels
 constexpr int XB = 153 * 144;            // X patch: 10x10 pixels x 160 B or 9x17 pixels x 144 B
-constexpr int STAGEB = DYB + XB;
+template <int NA> constexpr int stage_bytes() { return DyGeo<NA>::DYB + XB; }   // dY patch (up to 8x8 pixels) | X patch
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p0, const unsigned char* p1) {
     bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p0);
@@ -51,19 +61,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + j;
 }
 
-// one workgroup: tile `bid % ntile`, pixel-range split `bid / ntile` of the layer described by p
-template <int S>
+// one workgroup: tile `bid % ntile`, pixel-range split `bid / ntile` of the layer described by p.  NA = 16-channel output fragments per
+// wave = the workgroup tile's output channels / 16: 4 (64 x 64 tile, 144 accumulator registers, two workgroups per CU) or 8 (128 x 64 tile,
+// 288 accumulator registers: one wave per SIMD with the accumulators in the AGPR half of the register file; every transposed X fragment
+// feeds 8 MFMAs instead of 4 -- 34 instead of 2 x 52 transposed LDS reads per 144 MFMAs -- and the X patch is staged once per 128 channels)
+template <int S, int NA>
 __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, int npatch, int nsplit, unsigned char* smem) {
     using G_ = Geo<S>;
     constexpr int PW = G_::PW, NPIX = G_::PW * G_::PH, NSEG = NPIX * 8, XP = G_::XP;
+    constexpr int PITCH = DyGeo<NA>::PITCH, DYB = DyGeo<NA>::DYB, STAGEB = stage_bytes<NA>();
+    constexpr int DSEGS = 2 * NA;                  // 16-byte granules per dY pixel
+    constexpr int NDL = G_::ND * NA / 4;           // dY granules per thread and stage
+    constexpr int DPSTEP = 256 / DSEGS;            // pixels between a thread's dY granules (a multiple of the patch width 8)
     static_assert(NPIX * XP <= XB, "X patch fits its LDS slot");
+    static_assert(NA == 4 || NA == 8, "64- or 128-channel tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int g = lane >> 4, q = lane & 15;
 
-    const int ncot = p.Cout / 64, ncit = p.Cin / 64, ntile = ncot * ncit;
+    const int ncot = p.Cout / (16 * NA), ncit = p.Cin / 64, ntile = ncot * ncit;
     const int split = bid / ntile, tile = bid - split * ntile;
-    const int co0 = (tile % ncot) * 64, ci0 = (tile / ncot) * 64;
+    const int co0 = (tile % ncot) * (16 * NA), ci0 = (tile / ncot) * 64;
     const int per = (npatch + nsplit - 1) / nsplit;
     const int p_begin = split * per, p_end = min(npatch, p_begin + per);
     if (p_begin >= p_end) return;
@@ -71,7 +89,8 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 
     // ---- staging geometry (constant per thread)
     // dY: TH*8 px x 8 segs -> ids tid (, tid+256) ; X: NPIX px x 8 segs -> ids tid + 256*i, i < NX
-    const int dseg = tid & 7, dpix0 = tid >> 3;                       // pixels dpix0, dpix0 + 32
+    const int xseg = tid & 7;                                              // X granule of this thread (8 per pixel)
+    const int dseg = tid & (DSEGS - 1), dpix0 = tid / DSEGS;              // dY granule; pixels dpix0 + DPSTEP * i
     // global address space stated explicitly: in the grouped kernel the task's pointers come out of a table in memory, and hipcc then
     // emits FLAT loads -- which count on lgkmcnt as well, so every LDS wait in the MFMA loop became lgkmcnt(0) and also waited for the
     // next patch's global loads (the prefetch overlapped nothing)
@@ -82,8 +101,8 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     const gptr_t dyg = (gptr_t)(reinterpret_cast<const char*>(p.dy) + (size_t)co0 * 2 + dseg * 16);
     const gptr_t xg = (gptr_t)(reinterpret_cast<const char*>(p.x) + (size_t)ci0 * 2);
 
-    uint4 d0, d1, x0, x1, x2, x3, x4;
-    d0 = d1 = x0 = x1 = x2 = x3 = x4 = make_uint4(0, 0, 0, 0);
+    uint4 d0, d1, d2, d3, x0, x1, x2, x3, x4;
+    d0 = d1 = d2 = d3 = x0 = x1 = x2 = x3 = x4 = make_uint4(0, 0, 0, 0);
 
     // The next patch's addresses are computed branch-free in pieces (the dY pair, one X slot each) that sit INSIDE the MFMA groups of
     // the current stage, so their ~100 VALU instructions issue in the MFMAs' shadow; as a block in front of the MFMA loop they cost a
@@ -109,15 +128,20 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     {                                                                                                 \
         const int y0_ = pn_y * G_::TH, x0_ = pn_x << 3;                                               \
         const unsigned ra_ = (unsigned)((pn_n * p.Ho + y0_ + (dpix0 >> 3)) * p.Wo + x0_ + (dpix0 & 7)); \
+        constexpr unsigned RS_ = DPSTEP / 8;   /* image rows between a thread's granules */              \
         d0 = GLD16(dyg + ra_ * drow);                                                                 \
-        if constexpr (G_::ND == 2) d1 = GLD16(dyg + (ra_ + 4u * (unsigned)p.Wo) * drow);              \
+        if constexpr (NDL >= 2) d1 = GLD16(dyg + (ra_ + RS_ * (unsigned)p.Wo) * drow);                \
+        if constexpr (NDL == 4) {                                                                     \
+            d2 = GLD16(dyg + (ra_ + 2u * RS_ * (unsigned)p.Wo) * drow);                               \
+            d3 = GLD16(dyg + (ra_ + 3u * RS_ * (unsigned)p.Wo) * drow);                               \
+        }                                                                                             \
     }
 #define LDX(i, dst)                                                                                   \
     {                                                                                                 \
         const int iy_ = S * pn_y * G_::TH + (int)(cpp[i] & 255u) - 1, ix_ = S * (pn_x << 3) + (int)(cpp[i] >> 8) - 1; \
         const bool ok_ = (unsigned)iy_ < (unsigned)p.Hi && (unsigned)ix_ < (unsigned)p.Wi;            \
         const int iyc_ = min(max(iy_, 0), p.Hi - 1), ixc_ = min(max(ix_, 0), p.Wi - 1);               \
-        dst = GLD16(xg + ((unsigned)((pn_n * p.Hi + iyc_) * p.Wi + ixc_) * xrow + dseg * 16));        \
+        dst = GLD16(xg + ((unsigned)((pn_n * p.Hi + iyc_) * p.Wi + ixc_) * xrow + xseg * 16));        \
         okm = (okm & ~(1u << (i))) | (ok_ ? (1u << (i)) : 0u);                                        \
     }
 #define STX(i, src)                                                                                   \
@@ -129,7 +153,11 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     {                                                                                                 \
         unsigned char* sb_ = smem + (buf) * STAGEB;                                                   \
         *reinterpret_cast<uint4*>(sb_ + dpix0 * PITCH + dseg * 16) = d0;                              \
-        if constexpr (G_::ND == 2) *reinterpret_cast<uint4*>(sb_ + (dpix0 + 32) * PITCH + dseg * 16) = d1; \
+        if constexpr (NDL >= 2) *reinterpret_cast<uint4*>(sb_ + (dpix0 + DPSTEP) * PITCH + dseg * 16) = d1; \
+        if constexpr (NDL == 4) {                                                                     \
+            *reinterpret_cast<uint4*>(sb_ + (dpix0 + 2 * DPSTEP) * PITCH + dseg * 16) = d2;           \
+            *reinterpret_cast<uint4*>(sb_ + (dpix0 + 3 * DPSTEP) * PITCH + dseg * 16) = d3;           \
+        }                                                                                             \
         STX(0, x0) STX(1, x1) STX(2, x2) STX(3, x3)                                                   \
         if constexpr (G_::NX == 5) STX(4, x4)                                                         \
     }
@@ -137,11 +165,20 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     // wave tile: ALL 64 output channels (4 fragments) x 16 input channels (wave w: ci block w).  The X fragments are re-read for
     // every tap (9 x 2 k-steps), the dY fragments once per k-step: a 64 x 16 wave tile needs 16 + 36 = 52 transposed LDS reads per
     // stage where the 32 x 32 one needed 8 + 72 = 80, for the same 72 MFMAs
-    f32x4_t acc[9][4];
+    // NA = 8: 128 x 16 per wave, 8 + 8 + 18 = 34 reads for 144 MFMAs.  Its 72 accumulator tuples: taps 0..7 are the 256 AGPRs, named
+    // literally (tuple t*8 + a = a[4*(t*8+a) .. +3]) -- as C++ values hipcc gives the loop-carried accumulators VGPR homes and copies all
+    // of them into and out of the AGPRs every stage -- and tap 8's eight tuples are ordinary VGPR values.  Nothing else of this kernel
+    // may live in an AGPR: the build asserts that the compiler emitted no v_accvgpr_* of its own and spilled nothing (tools/check_isa.py)
+    f32x4_t acc[9][NA];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < NA; ++a) acc[t][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NA == 8) {
+        asm volatile("v_accvgpr_write_b32 a0, 0" ::: "a0", "a255");   // the clobbers make the kernel descriptor cover all 256 AGPRs
+#pragma unroll
+        for (int i = 1; i < 256; ++i) asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(i));
+    }
     (void)wa; (void)wb;
 
     // transpose-read lane bases.  k (pixel) map of one 32-pixel k-step (4 image rows x 8): read r of lane group g
@@ -172,24 +209,36 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
         // the reads of a tap right before its MFMAs and waits out the LDS latency seven times per stage.
         constexpr int J = 9 * G_::KS, RD = 3;
         constexpr int PSTEP = (G_::KS == 2) ? 2 : 1;  // address pieces go into groups 1, 1 + PSTEP, ...
-        bf16x8_t fa[G_::KS][4], fb[RD + 1];
+        constexpr int APG = NA / 4;                   // dY fragments of the second k-step read per group
+        bf16x8_t fa[G_::KS][NA], fb[RD + 1];
 #define FA_(ks_, a_) tr_pair(sa + ((ks_) * 4) * 8 * PITCH + (a_) * 32, sa + ((ks_) * 4 + 2) * 8 * PITCH + (a_) * 32)
 #define FB_(j_) tr_pair(sx + ((S * ((j_) / 9) * 4 + ((j_) % 9) / 3) * PW + (((j_) % 9) % 3)) * XP,                               \
                         sx + ((S * ((j_) / 9) * 4 + ((j_) % 9) / 3) * PW + (((j_) % 9) % 3)) * XP + 2 * S * PW * XP)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) fa[0][a] = FA_(0, a);
+        for (int a = 0; a < NA; ++a) fa[0][a] = FA_(0, a);
 #pragma unroll
         for (int j = 0; j < RD; ++j) fb[j] = FB_(j);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             if (j + RD < J) fb[(j + RD) % (RD + 1)] = FB_(j + RD);
             if constexpr (G_::KS == 2) {
-                if (j >= 9 - 4 - RD && j < 9 - RD) fa[1][j - (9 - 4 - RD)] = FA_(1, j - (9 - 4 - RD));
+                if (j >= 9 - 4 - RD && j < 9 - RD) {
+#pragma unroll
+                    for (int u = 0; u < APG; ++u) fa[1][(j - (9 - 4 - RD)) * APG + u] = FA_(1, (j - (9 - 4 - RD)) * APG + u);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                acc[j % 9][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a], 0, 0, 0);
+            for (int a = 0; a < NA; ++a) {
+                if constexpr (NA == 4) {
+                    acc[j % 9][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a], 0, 0, 0);
+                } else if (j % 9 < 8) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]),
+                                 "i"(4 * ((j % 9) * 8 + a)), "i"(4 * ((j % 9) * 8 + a) + 3));
+                } else {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[j % 9][a]) : "v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]));
+                }
+            }
             // next patch: one address piece + its loads per group (same scheduling region as the MFMAs above)
             if (j == 0) LDD()
             if (j == 1) LDX(0, x0)
@@ -212,28 +261,52 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #undef STX
 #undef WRITE_PATCH
 
+    // accumulator tuple (t, a) -> registers: for the 128-channel tile taps 0..7 are read out of the AGPRs one tuple at a time, right in
+    // front of their store (a block of 256 reads would need 256 VGPRs at once)
+    auto tuple = [&](auto T_, auto A_) -> f32x4_t {
+        constexpr int t = decltype(T_)::value, a = decltype(A_)::value;
+        if constexpr (NA == 8 && t < 8) {
+            float r0, r1, r2, r3;
+            asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)
+                         : "i"(4 * (t * 8 + a)), "i"(4 * (t * 8 + a) + 1), "i"(4 * (t * 8 + a) + 2), "i"(4 * (t * 8 + a) + 3));
+            return f32x4_t{r0, r1, r2, r3};
+        } else {
+            return acc[t][a];
+        }
+    };
+    // the last MFMAs have to leave the matrix pipe before their AGPRs are read (the compiler pads nothing around asm statements)
+    if constexpr (NA == 8) asm volatile("s_nop 15\n\ts_nop 15");
     if (p.ws != nullptr) {
-        // workspace order (read by wgrad_reduce_multi): [36 fragments (t, a', b')][4 tile quadrants (wa', wb')][64 lanes][4] with the
-        // 16 x 16 block (co16 = wa'*2 + a', ci16 = wb'*2 + b'): this wave holds co16 = a (0..3), ci16 = wave
-        float* wsb = p.ws + ((size_t)split * ntile + tile) * 36864 + (size_t)lane * 4;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                *reinterpret_cast<f32x4_t*>(wsb + ((t * 2 + (a & 1)) * 2 + (wave & 1)) * 1024 + ((a >> 1) * 2 + (wave >> 1)) * 256) = acc[t][a];
+        // workspace order (read by wgrad_reduce_multi): per 64 x 64 tile [36 fragments (t, a', b')][4 tile quadrants (wa', wb')][64 lanes][4]
+        // with the 16 x 16 block (co16 = wa'*2 + a', ci16 = wb'*2 + b'): this wave holds co16 = a (0..3), ci16 = wave.  A 128-channel
+        // workgroup tile is stored as its two 64 x 64 halves (a >> 2), which sit next to each other in the slab order
+        // [split][ci tile][co tile of 64]
+        constexpr int HT = NA / 4;
+        const int ntile64 = ntile * HT, tile64 = (tile / ncot) * (ncot * HT) + (tile % ncot) * HT;
+        float* wsb = p.ws + ((size_t)split * ntile64 + tile64) * 36864 + (size_t)lane * 4;
+        static_for<9>([&](auto T_) {
+            static_for<NA>([&](auto A_) {
+                constexpr int t = decltype(T_)::value, a = decltype(A_)::value;
+                *reinterpret_cast<f32x4_t*>(wsb + (size_t)(a >> 2) * 36864 + ((t * 2 + (a & 1)) * 2 + (wave & 1)) * 1024 +
+                                            (((a & 3) >> 1) * 2 + (wave >> 1)) * 256) = tuple(T_, A_);
+            });
+        });
         return;
     }
     // D[i = g*4 + j (co)][col = q (ci)]
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
+    static_for<9>([&](auto T_) {
+        static_for<NA>([&](auto A_) {
+            constexpr int t = decltype(T_)::value, a = decltype(A_)::value;
+            const f32x4_t v = tuple(T_, A_);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = co0 + a * 16 + g * 4 + j;
                 const int ci = ci0 + wave * 16 + q;
-                unsafeAtomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, acc[t][a][j]);
+                unsafeAtomicAdd(p.dw + ((size_t)co * 9 + t) * p.Cin + ci, v[j]);
             }
+        });
+    });
 }
 
 // pixel patches of a layer: 8x8 output pixels per stage for stride 1, 4x8 for stride 2
@@ -243,8 +316,8 @@ __host__ __device__ __forceinline__ int wgrad_npatch(const gdrn_wgrad_params& p)
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (dY patch | X patch)
-    if (p.stride == 2) wgrad_tile<2>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
-    else wgrad_tile<1>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+    if (p.stride == 2) wgrad_tile<2, 4>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+    else wgrad_tile<1, 4>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
 }
 
 // Grouped launch: the weight gradients of several layers (one gradient bucket) in one grid.  Weight gradients are off
@@ -263,8 +336,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const gdrn_
     lo = __builtin_amdgcn_readfirstlane(lo);
     const gdrn_wgrad_params p = tasks[lo];
     const int npatch = wgrad_npatch(p);
-    if (p.stride == 2) wgrad_tile<2>(p, bid - blk_start[lo], npatch, p.splits, smem);
-    else wgrad_tile<1>(p, bid - blk_start[lo], npatch, p.splits, smem);
+    if (p.stride == 2) wgrad_tile<2, 4>(p, bid - blk_start[lo], npatch, p.splits, smem);
+    else wgrad_tile<1, 4>(p, bid - blk_start[lo], npatch, p.splits, smem);
+}
+
+__device__ __forceinline__ void w128_logical_block(const gdrn_wgrad_params* __restrict__ tasks, const int* __restrict__ blk_start, int ntasks,
+                                                   int bid, unsigned char* smem) {
+    int lo = 0, hi = ntasks;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (blk_start[mid] <= bid) lo = mid; else hi = mid;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const gdrn_wgrad_params p = tasks[lo];
+    const int npatch = wgrad_npatch(p);
+    if (p.stride == 2) wgrad_tile<2, 8>(p, bid - blk_start[lo], npatch, p.splits, smem);
+    else wgrad_tile<1, 8>(p, bid - blk_start[lo], npatch, p.splits, smem);
+}
+
+// The same grouped launch on 128(co) x 64(ci) workgroup tiles (layers with Cout % 128 == 0): one workgroup = one wave per SIMD with the
+// whole register file (288 accumulator registers per lane), blk_start counts (Cout/128)*(Cin/64)*splits workgroups per task.
+// The grid may be SMALLER than the table's blk_start[ntasks] logical workgroups: a resident workgroup then walks the logical ids blockIdx.x,
+// blockIdx.x + gridDim.x, ... -- a launch of G workgroups keeps G compute units and leaves the others to another stream's kernels (this
+// kernel shares a CU with nothing: its four waves own the register file).
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_w128_multi_kernel(const gdrn_wgrad_params* __restrict__ tasks,
+                                                                         const int* __restrict__ blk_start, int ntasks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nlog = blk_start[ntasks];
+    for (int lb = blockIdx.x; lb < nlog; lb += gridDim.x) w128_logical_block(tasks, blk_start, ntasks, xcd_remap(lb, nlog), smem);
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_w128_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.stride == 2) wgrad_tile<2, 8>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
+    else wgrad_tile<1, 8>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
 }
 
 // Sum the workspace partials of one 16(co) x 16(ci) x 9(tap) unit per workgroup and write it in the parameter's layout
@@ -322,10 +427,14 @@ extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
     if (!(p->dtype == GDRN_DT_BF16 && p->KH == 3 && p->KW == 3 && p->pad == 1 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
           (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0 && (p->Wo % 8) == 0))
         return 0;
+    if (p->variant != 0 && !(p->variant == GDRN_WGRAD_W128 && (p->Cout % 128) == 0)) return 0;
     if (p->stride == 1) return p->Hi == p->Ho && p->Wi == p->Wo && (p->Ho % 8) == 0;
     if (p->stride == 2) return p->Hi == 2 * p->Ho && p->Wi == 2 * p->Wo && (p->Ho % 4) == 0;
     return 0;
 }
+
+// workgroup tiles of a layer: 64 x 64, or 128(co) x 64(ci) for variant GDRN_WGRAD_W128
+static inline int wgrad_tiles(const gdrn_wgrad_params& p) { return (p.Cout / (p.variant == GDRN_WGRAD_W128 ? 128 : 64)) * (p.Cin / 64); }
 
 // number of pixel-range splits the launcher uses for these params (p->splits <= 0: automatic); the workspace of the
 // p->ws path holds splits * Cout * Cin * 9 floats
@@ -335,10 +444,10 @@ extern "C" int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* pp) {
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw) return 0;
     const int npatch = wgrad_npatch(p);
-    const int tiles = (p.Cout / 64) * (p.Cin / 64);
+    const int tiles = wgrad_tiles(p);
     int splits = p.splits;
-    // one partial tile per workgroup either way: target one workgroup per CU (two when the partials are plain stores)
-    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(p.ws ? 512 : 256, tiles)));
+    // one partial tile per workgroup either way: target one workgroup per CU (two when the partials are plain stores and two fit a CU)
+    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(p.ws && p.variant == 0 ? 512 : 256, tiles)));
     splits = std::min(splits, npatch);
     const int per = cdiv(npatch, splits);
     return cdiv(npatch, per);  // no empty split: every workspace slab gets written
@@ -351,17 +460,28 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw) return GDRN_ERR_SHAPE;
     const int npatch = wgrad_npatch(p);
-    const int tiles = (p.Cout / 64) * (p.Cin / 64);
+    const int tiles = wgrad_tiles(p);
     const int splits = gdrn_conv3x3_wgrad_splits(pp);
     if (splits <= 0) return GDRN_ERR_SHAPE;
-    constexpr size_t smem = 2 * (size_t)STAGEB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return GDRN_ERR_LAUNCH;
-        attr_set = true;
+    if (p.variant == GDRN_WGRAD_W128) {
+        constexpr size_t smem = 2 * (size_t)stage_bytes<8>();
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_w128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
+        if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_wgrad_w128_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch, splits);
+        GDRN_CHECK_LAUNCH();
+        return GDRN_OK;
     }
+    constexpr size_t smem = 2 * (size_t)stage_bytes<4>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch,
                        splits);
     GDRN_CHECK_LAUNCH();
@@ -374,15 +494,19 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
 extern "C" int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int lds_bytes,
                                             void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    constexpr size_t smem0 = 2 * (size_t)STAGEB;
+    constexpr size_t smem0 = 2 * (size_t)stage_bytes<4>();
     const size_t smem = std::max(smem0, (size_t)std::max(lds_bytes, 0));
     if (smem > 160 * 1024) return GDRN_ERR_ARG;
-    static size_t attr_set = 0;
-    if (attr_set < smem) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return GDRN_ERR_LAUNCH;
-        attr_set = smem;
+    {   // the attribute only ever grows, under a lock (the unguarded static was a race between host threads)
+        static std::mutex mu;
+        static size_t attr_set = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (attr_set < smem) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem) != hipSuccess)
+                return GDRN_ERR_LAUNCH;
+            attr_set = smem;
+        }
     }
     hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(nblocks), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev,
                        blk_start_dev, ntasks);
@@ -392,6 +516,26 @@ extern "C" int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, 
 
 extern "C" int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     return gdrn_conv3x3_wgrad_multi_lds(tasks_dev, blk_start_dev, ntasks, nblocks, 0, stream);
+}
+
+// Grouped launch on the 128 x 64 tiles (every task variant GDRN_WGRAD_W128): nblocks = blk_start[ntasks] logical workgroups walked by
+// `grid` resident ones (grid <= 0 or > nblocks: nblocks; rounded down to a multiple of 8 so that a resident workgroup stays on its XCD's ids)
+extern "C" int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int grid,
+                                             void* stream) {
+    if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
+    constexpr size_t smem = 2 * (size_t)stage_bytes<8>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_w128_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (grid <= 0 || grid > nblocks) grid = nblocks;
+    if (grid < nblocks && grid >= 8) grid &= ~7;
+    hipLaunchKernelGGL(conv3x3_wgrad_w128_multi_kernel, dim3(grid), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev, blk_start_dev,
+                       ntasks);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
 }
 
 extern "C" int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {

@@ -91,6 +91,11 @@ class Engine:
         # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
         # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
         self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
+        # 128 x 64 weight-gradient tile (conv3x3_wgrad.hip, GDRN_WGRAD_W128): 0 off, 1 stride-1 layers with Cout % 128 == 0, 2 stride-2 / ConvT too
+        self.wgrad_w128 = int(_os.environ.get("GDRN_WGRAD_W128", "0"))
+        self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
+        self.wgrad_w128_grid = int(_os.environ.get("GDRN_W128_GRID", "128"))           # resident workgroups of a launch that runs under a chain
+        self.wgrad_w128_grid_last = int(_os.environ.get("GDRN_W128_GRID_LAST", "0"))   # ... of the last bucket's launch (0: all)
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
@@ -844,51 +849,72 @@ class Plan:
         for gi, L, wp, flops in self._wgrad_deferred:
             wg_bucket[cut_of(gi)].append((L, wp, flops))
         self._wgrad_tables = []
-        for cut, items in wg_bucket.items():
-            if not items:
+        for cut, items_all in wg_bucket.items():
+            if not items_all:
                 continue
             bkt = bucket_of(cut)
-            # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
-            geo = []
-            for L, wp, flops in items:
-                s2 = wp.stride == 2
-                npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
-                geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // 64) * (wp.Cin // 64)))
-            per = max(16, sum(u * t for _, u, t in geo) // e.wgrad_blocks)   # k-steps per workgroup
-            tasks = []
-            for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
-                wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
-                wp.splits = max(1, units // per)
-                wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
-                ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
-                self.keep.append(ws)
-                wp.ws, wp.dw = ptr(ws), None
-                # the kernel's "Cin" role = the parameter's input channels for a conv (69 real of 128 for Patch-PnP's first conv), its
-                # second dimension for the ConvTranspose (weight [Cin_w][Cout_w][3][3] with x = output gradient, dy = input)
-                self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin, L.O if L.kind == "convT" else L.I)
-                tasks.append((-(units // wp.splits), len(tasks), wp, tiles, flops))
-            tasks.sort(key=lambda t: t[:2])
-            starts = [0]
-            for _, _, wp, tiles, _ in tasks:
-                starts.append(starts[-1] + tiles * wp.splits)
-            tab = to_device_table([t[2] for t in tasks], e.dev)
-            stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
-            self._wgrad_tables.append((tab, stt))
-            nt, nb = len(tasks), starts[-1]
-
             last_bucket = bkt == len(first_group) - 1
+            # two kernels: layers with Cout % 128 == 0 can take the 128 x 64 tile (one wave per SIMD, accumulators in the AGPRs: a resident
+            # workgroup owns its CU), the others the 64 x 64 tile; one grouped launch per kind and bucket
+            wide = [it for it in items_all if e.wgrad_w128 and it[1].Cout % 128 == 0 and (e.wgrad_w128 > 1 or it[1].stride == 1)]
+            for kind, items in ((1, wide), (0, [it for it in items_all if it not in wide])):
+                if not items:
+                    continue
+                cot = 128 if kind else 64
+                nblocks_target = e.wgrad_w128_blocks if kind else e.wgrad_blocks
+                # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
+                geo = []
+                for L, wp, flops in items:
+                    s2 = wp.stride == 2
+                    npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
+                    geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // cot) * (wp.Cin // 64)))
+                per = max(16, sum(u * t for _, u, t in geo) // nblocks_target)   # k-steps per workgroup
+                tasks = []
+                for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
+                    wp.variant = kind
+                    wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
+                    wp.splits = max(1, units // per)
+                    wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
+                    assert wp.splits >= 1, (L.key, kind)
+                    ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
+                    self.keep.append(ws)
+                    wp.ws, wp.dw = ptr(ws), None
+                    # the kernel's "Cin" role = the parameter's input channels for a conv (69 real of 128 for Patch-PnP's first conv), its
+                    # second dimension for the ConvTranspose (weight [Cin_w][Cout_w][3][3] with x = output gradient, dy = input)
+                    self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin, L.O if L.kind == "convT" else L.I)
+                    tasks.append((-(units // wp.splits), len(tasks), wp, tiles, flops))
+                tasks.sort(key=lambda t: t[:2])
+                starts = [0]
+                for _, _, wp, tiles, _ in tasks:
+                    starts.append(starts[-1] + tiles * wp.splits)
+                tab = to_device_table([t[2] for t in tasks], e.dev)
+                stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
+                self._wgrad_tables.append((tab, stt))
+                nt, nb = len(tasks), starts[-1]
 
-            def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
-                # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
-                # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
-                check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
+                if kind:
+                    # resident workgroups: under a data-gradient chain only part of the CUs (the chain's workgroups cannot share a CU with
+                    # this kernel), the whole chip when nothing runs beside it
+                    grid = e.wgrad_w128_grid_last if last_bucket else e.wgrad_w128_grid
 
-            run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
-            run.side = True
-            if cut in first_group:
-                self._bucket_end(bkt, run)
-            else:
-                self.bwd_groups[cut].append(run)   # behind the data gradients of group `cut`, the last-executed one of this launch
+                    def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, grid=grid):
+                        check(lib.gdrn_conv3x3_wgrad_multi_w128(ptr(tab), ptr(stt), nt, nb, grid if (e.wgrad_stream or e.wgrad_force_lds) else 0, st),
+                              "conv3x3_wgrad_multi_w128")
+
+                    run.meta = dict(kernel="conv3x3_wgrad_w128_multi_kernel", flops=sum(t[4] for t in tasks),
+                                    layer=f"bucket{bkt}@{cut}:wgrad128 x{nt} ({nb} wg, grid {grid or nb})")
+                else:
+                    def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
+                        # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
+                        # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
+                        check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
+
+                    run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
+                run.side = True
+                if cut in first_group:
+                    self._bucket_end(bkt, run)
+                else:
+                    self.bwd_groups[cut].append(run)   # behind the data gradients of group `cut`, the last-executed one of this launch
 
         per_bucket = {i: [] for i in range(len(first_group))}
         red_bucket = {i: [] for i in range(len(first_group))}

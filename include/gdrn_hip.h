@@ -26,11 +26,17 @@
 extern "C" {
 #endif
 
-#define GDRN_ABI_VERSION 1
+/* 2: status / dtype enums renamed (GDRN_E_* -> GDRN_ERR_*, GDRN_F32 / GDRN_BF16 -> GDRN_DT_*; the old names stay as deprecated aliases),
+ *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
+#define GDRN_ABI_VERSION 2
 /* `dtype` arguments */
 enum { GDRN_DT_F32 = 0, GDRN_DT_BF16 = 1 };
 /* status codes (0 = GDRN_OK) */
 enum { GDRN_OK = 0, GDRN_ERR_ARG = -1, GDRN_ERR_SHAPE = -2, GDRN_ERR_LAUNCH = -3 };
+/* deprecated aliases of ABI version 1 */
+enum { GDRN_F32 = GDRN_DT_F32, GDRN_BF16 = GDRN_DT_BF16, GDRN_E_ARG = GDRN_ERR_ARG, GDRN_E_SHAPE = GDRN_ERR_SHAPE, GDRN_E_LAUNCH = GDRN_ERR_LAUNCH };
+/* gdrn_wgrad_params.variant */
+enum { GDRN_WGRAD_T64 = 0, GDRN_WGRAD_W128 = 1 };
 
 int gdrn_version(void);
 /* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
@@ -170,7 +176,7 @@ int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
 
 /* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
- *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather; bf16 fragments through the LDS transpose read).  variant: reserved, 0.
+ *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather; bf16 fragments through the LDS transpose read).  variant: 0 (only gdrn_conv3x3_wgrad* read it, see GDRN_WGRAD_W128).
  *   splits <= 0: automatic pixel-range split.
  * ws (gdrn_conv3x3_wgrad only, else NULL): per-split partial tiles go here (plain stores) instead of atomics on dw.
  * Replaces the autograd weight-gradients of the same layers (engine.py:279). */
@@ -203,6 +209,14 @@ int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* p);
 int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
 /* the same with an LDS request of lds_bytes (> 64 KiB: one workgroup per CU, the rest of the CU stays free for another stream's kernels) */
 int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int lds_bytes, void* stream);
+/* p->variant = GDRN_WGRAD_W128 (Cout a multiple of 128): 128(co) x 64(ci) workgroup tiles -- one wave per SIMD, 288 accumulator registers
+ * per lane of which 256 are the AGPRs; a third of the LDS fragment reads per MFMA of the 64 x 64 tile and the X patch staged once per 128
+ * output channels.  gdrn_conv3x3_wgrad / _ok / _splits honour the field; the workspace layout is the 64 x 64 tile's (a 128-channel tile is
+ * stored as its two halves), so gdrn_wgrad_reduce_multi reads both kinds.  Grouped launch: every task of the table has the variant set,
+ * blk_start[i] = sum_{j<i} (Cout_j/128)*(Cin_j/64)*splits_j, nblocks = blk_start[ntasks] (the kernel reads it from blk_start_dev[ntasks]);
+ * grid = resident workgroups walking the nblocks logical ones (<= 0: nblocks).  A resident workgroup shares its CU with nothing, so a grid
+ * below the CU count leaves the other CUs to kernels of other streams. */
+int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int grid, void* stream);
 /* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
 typedef struct gdrn_wreduce_task {
     const float* ws;

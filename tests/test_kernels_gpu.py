@@ -223,39 +223,53 @@ def test_conv_wgrad(H, dt, case, variant):
     assert H.rel(got, w.grad) < (5e-5 if dt == F32 else 1e-2)
 
 
+W128 = 1  # GDRN_WGRAD_W128: 128 x 64 workgroup tile, accumulators in the AGPRs
+
+
+@pytest.mark.parametrize("variant", [0, W128])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (5, 512, 512, 8)])
-def test_conv3x3_wgrad_halo(H, case, splits):
-    """halo-tiled weight gradient (nine taps from one staged pixel patch) against autograd."""
+def test_conv3x3_wgrad_halo(H, case, splits, variant):
+    """halo-tiled weight gradient (nine taps from one staged pixel patch) against autograd; both workgroup tiles."""
     B, I, O, Hh = case
     dt = BF16
+    if variant == W128 and O % 128:
+        wp = cabi.WgradParams()
+        wp.Hi = wp.Wi = wp.Ho = wp.Wo = Hh
+        wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.variant = I, O, I, O, 3, 3, 1, 1, B * Hh * Hh, dt, W128
+        assert cabi.load().gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0   # the wide tile needs Cout % 128 == 0
+        return
     x = H.rounded(H.randn(43, B, I, Hh, Hh), dt)
     w = H.randn(44, O, I, 3, 3).requires_grad_(True)
     dy = H.rounded(H.randn(45, B, O, Hh, Hh), dt)
     F.conv2d(x, w, None, 1, 1).backward(dy)
-    dw = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True)
+    dw = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True, variant=variant)
     assert H.rel(dw.view(O, 3, 3, I).permute(0, 3, 1, 2), w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [0, W128])
 @pytest.mark.parametrize("splits", [0, 1, 5])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (5, 512, 512, 8), (8, 64, 64, 64)])
-def test_conv3x3_wgrad_halo_workspace(H, case, splits):
+def test_conv3x3_wgrad_halo_workspace(H, case, splits, variant):
     """halo weight gradient with per-split workspace partials + multi-layer reduce (writes the OIHW gradient directly)."""
     B, I, O, Hh = case
     dt = BF16
     x = H.rounded(H.randn(46, B, I, Hh, Hh), dt)
     w = H.randn(47, O, I, 3, 3).requires_grad_(True)
     dy = H.rounded(H.randn(48, B, O, Hh, Hh), dt)
+    if variant == W128 and O % 128:
+        pytest.skip("wide tile: Cout % 128 == 0")
     F.conv2d(x, w, None, 1, 1).backward(dy)
-    grad = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True, ws=True)
+    grad = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True, ws=True, variant=variant)
     assert torch.isfinite(grad).all()
     assert H.rel(grad, w.grad) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [0, W128])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 @pytest.mark.parametrize("ws", [False, True])
 @pytest.mark.parametrize("case", [(2, 64, 128, 16), (3, 128, 256, 8), (2, 256, 512, 4), (1, 128, 128, 32), (5, 64, 64, 12)])
-def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws):
+def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws, variant):
     """stride-2 3x3 weight gradient on the halo kernel (4x8 output-pixel stages against a 9x17 input patch): the ResNet stage-entry
     convs / Patch-PnP convs, against autograd; atomics path and workspace + reduce path.  case = (B, Cin, Cout, Hout)."""
     B, I, O, Ho = case
@@ -272,7 +286,9 @@ def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws):
         wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype = I, O, I, O, 3, 3, 2, 1, B * Ho * Ho, dt
         assert cabi.load().gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0
         return
-    got = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hi, Hi, I, I, Ho, Ho, O, O, 3, 3, 2, 1, dt, splits=splits, halo=True, ws=ws)
+    if variant == W128 and O % 128:
+        pytest.skip("wide tile: Cout % 128 == 0")
+    got = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hi, Hi, I, I, Ho, Ho, O, O, 3, 3, 2, 1, dt, splits=splits, halo=True, ws=ws, variant=variant)
     if not ws:
         got = got.view(O, 3, 3, I).permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
@@ -530,13 +546,17 @@ def test_bn_bwd_coef(H, nrows, C_):
     assert H.rel(o[3], s[1]) < 1e-6 and H.rel(o[4], s[0]) < 1e-6
 
 
-def test_conv3x3_wgrad_grouped(H):
-    """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer."""
+@pytest.mark.parametrize("variant,grid", [(0, 0), (W128, 0), (W128, 8), (W128, 21)])
+def test_conv3x3_wgrad_grouped(H, variant, grid):
+    """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer.  Wide tile: also with
+    fewer resident workgroups than logical ones (a resident workgroup walks several tiles; 21 is rounded down to 16)."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
 
     lib = cabi.load()
     dt, dev = BF16, H.DEV
     cases = [(2, 64, 64, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1)]  # B, I, O, H, requested splits
+    if variant == W128:
+        cases = [(2, 64, 128, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1), (2, 256, 512, 8, 3)]
     keep, wps, tasks, refs, grads = [], [], [], [], []
     for i, (B, I, O, Hh, sp) in enumerate(cases):
         x = H.rounded(H.randn(60 + i, B, I, Hh, Hh), dt)
@@ -548,7 +568,7 @@ def test_conv3x3_wgrad_grouped(H):
         wp = WgradParams()
         wp.x, wp.dy, wp.dw = ptr(xd), ptr(dyd), None
         wp.Hi, wp.Wi, wp.Cin, wp.x_cs, wp.Ho, wp.Wo, wp.Cout, wp.dy_cs = Hh, Hh, I, I, Hh, Hh, O, O
-        wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.splits, wp.variant = 3, 3, 1, 1, B * Hh * Hh, dt, sp, 0
+        wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.splits, wp.variant = 3, 3, 1, 1, B * Hh * Hh, dt, sp, variant
         wp.ws = ptr(xd)  # placeholder for the query
         wp.splits = lib.gdrn_conv3x3_wgrad_splits(C.byref(wp))
         assert 1 <= wp.splits <= sp
@@ -561,11 +581,14 @@ def test_conv3x3_wgrad_grouped(H):
         tasks.append(WreduceTask(ws=ptr(ws), dst=ptr(g), nsplit=wp.splits, Cout=O, Cin=I, cin_valid=0, s_co=I * 9, s_ci=9, s_t=1))
     st1, st2 = [0], [0]
     for wp in wps:
-        st1.append(st1[-1] + (wp.Cout // 64) * (wp.Cin // 64) * wp.splits)
+        st1.append(st1[-1] + (wp.Cout // (128 if variant == W128 else 64)) * (wp.Cin // 64) * wp.splits)
         st2.append(st2[-1] + wp.Cout * wp.Cin // 256)
     tab1, tab2 = to_device_table(wps, dev), to_device_table(tasks, dev)
     s1, s2 = torch.tensor(st1, dtype=torch.int32, device=dev), torch.tensor(st2, dtype=torch.int32, device=dev)
-    check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab1), ptr(s1), len(wps), st1[-1], H.stream()), "conv3x3_wgrad_multi")
+    if variant == W128:
+        check(lib.gdrn_conv3x3_wgrad_multi_w128(ptr(tab1), ptr(s1), len(wps), st1[-1], grid, H.stream()), "conv3x3_wgrad_multi_w128")
+    else:
+        check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab1), ptr(s1), len(wps), st1[-1], H.stream()), "conv3x3_wgrad_multi")
     check(lib.gdrn_wgrad_reduce_multi(ptr(tab2), ptr(s2), len(tasks), st2[-1], H.stream()), "wgrad_reduce_multi")
     torch.cuda.synchronize()
     for g, r in zip(grads, refs):
