@@ -48,7 +48,112 @@ def parse():
     ap.add_argument("--dist-force", action="store_true",
                     help="run the data-parallel code path (RCCL process group, parameter broadcast, bucketed side-stream all-reduce) even with one rank")
     ap.add_argument("--comm-dtype", default=os.environ.get("GDRN_COMM_DTYPE", "fp32"), choices=["fp32", "bf16"], help="wire format of the gradient buckets")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only with --dry)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no kernels: the launcher, the process group and the bucketed gradient-exchange protocol on the dry engine's REAL bs=64 "
+                         "backward launch list (host tensors); what the CPU test of the N > 1 path runs")
     return ap.parse_args()
+
+
+def _json_error(args, msg, **extra):
+    """ONE JSON line also when the run cannot happen (the driver parses the last line of stdout)"""
+    res = {"metric": "RoI crops/sec (fwd+bwd) at 256\u00d7256 bs=64", "value": None, "unit": "RoI/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "error": msg}
+    res.update(extra)
+    print(json.dumps(res), flush=True)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves (torch.distributed.run, one
+    process per GPU, 127.0.0.1) and pass rank 0's JSON line through.  Returns the process exit code."""
+    import socket
+    import subprocess
+
+    if not args.dry:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            _json_error(args, f"--gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {have}", gpus_visible=have)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GDRN_BENCH_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in pr.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if pr.returncode != 0 or line is None:
+        _json_error(args, f"the {args.gpus}-rank launch failed (exit code {pr.returncode}); ranks' stdout tail: " + pr.stdout[-400:].replace("\n", " | "))
+        return pr.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def dry_main(args):
+    """--dry: every rank builds the dry engine's REAL backward launch list at bs = args.bs on host tensors and walks it; the reducer fires at the
+    plan's own bucket marks (gloo all-reduce per bucket, deferred 1/world), the mean must land in every parameter's gradient view.  Timed like
+    the real run (barrier, K steps, max over ranks); `value` counts RoIs per second of protocol time -- it measures the launcher, not a GPU."""
+    import torch
+    import torch.distributed as dist
+
+    from gdrnet_amd import GDRN as G
+    from gdrnet_amd.cfg import lm13_cfg
+    from gdrnet_amd.dist import GradReducer
+    from gdrnet_amd.engine import Engine
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(args.backend if args.backend == "gloo" else "gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model, _ = G.build_model_optimizer(lm13_cfg(device="cpu"))
+    eng = Engine(dict(model.named_parameters()), dict(model.named_buffers()), dtype="bf16", dry=True)
+    plan = eng.plan(args.bs, True, True)
+    flat, bounds = eng.grad_flat, eng.bucket_bounds
+    red = GradReducer(flat, bounds, average=True, defer_scale=True, comm_dtype=args.comm_dtype)
+
+    def before(i):
+        lo, hi = bounds[i]
+        flat[lo:hi] = float(rank + 1)
+
+    def step():
+        flat.zero_()
+        fired = plan.walk_backward(red.on_bucket, before)
+        red.finish()
+        return fired
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fired = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    mean = sum(r + 1 for r in range(world)) / world
+    ok = bool(torch.allclose(flat, torch.full_like(flat, mean))) and [b for _, b in fired] == list(range(len(bounds)))
+    if world > 1:
+        t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, ok = float(t[0]), float(t[1]) == 0.0
+    if rank == 0:
+        print(json.dumps({"metric": "RoI crops/sec (fwd+bwd) at 256\u00d7256 bs=64", "value": round(world * args.bs * args.steps / dt, 2), "unit": "RoI/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry": True,
+                          "process_group": {"backend": "gloo", "world_size": dist.get_world_size() if world > 1 else 1},
+                          "buckets": len(bounds), "bucket_mb": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in bounds],
+                          "backward_launches": len(plan.bwd), "protocol_ok": ok,
+                          "config": {"workload": "DRY: no kernels -- launcher + process group + bucketed gradient exchange on the real bs=%d backward "
+                                                 "launch list (host tensors)" % args.bs, "global_batch": args.bs * world, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def kernel_source_hash():
@@ -313,6 +418,13 @@ def main():
     args = parse()
     if args.cpu_threads_sweep:
         return cpu_threads_sweep()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)   # `python bench.py --gpus N`: this process becomes the launcher of the N ranks
+    if args.dry:
+        return dry_main(args)
+    if args.backend != "nccl":
+        _json_error(args, "--backend gloo only exists for --dry (the kernels need a GPU and RCCL)")
+        return 2
     import torch
     import torch.distributed as dist
 
@@ -324,8 +436,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if world != args.gpus:
+        if rank == 0:
+            _json_error(args, f"--gpus {args.gpus} but the launcher started {world} ranks")
+        return 2
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        if rank == 0:
+            _json_error(args, f"rank {rank}: no GPU {local} on this box ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible)")
+        return 2
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     use_dist = world > 1 or args.dist_force
@@ -443,6 +561,7 @@ def main():
             "value": round(value, 2), "unit": "RoI/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            "process_group": ({"backend": "nccl (RCCL)", "world_size": dist.get_world_size()} if use_dist else None),
             "config": {"workload": "LM-13 a6_cPnP_lm13 graph: ResNet-34 + RotWithRegionHead + ConvPnPNet, 256x256 RoIs, "
                                    f"bs={B}/GPU, {'train step: fwd + 8 losses + bwd + fused Ranger optimizer step (all inside the timed region)' if not args.fwd_only else 'inference fwd'}",
                        "global_batch": B * world, "parallelism": f"dp{world}",
@@ -467,4 +586,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -91,6 +91,7 @@ class Engine:
         # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
         # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
         self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
+        self.post_on = self.wgrad_stream and _os.environ.get("GDRN_POST_STREAM", "1") == "1"
         # 128 x 64 weight-gradient tile (conv3x3_wgrad.hip, GDRN_WGRAD_W128): 0 off, 1 stride-1 layers with Cout % 128 == 0, 2 stride-2 / ConvT too
         self.wgrad_w128 = int(_os.environ.get("GDRN_WGRAD_W128", "0"))
         self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
@@ -153,6 +154,16 @@ class Engine:
         if getattr(self, "_side", None) is None:
             self._side = make_stream(self.dev, os.environ.get("GDRN_SIDE_PRIO", "low"))
         return self._side
+
+    def post_stream(self):
+        """third stream (low priority): the HBM-bound tail of a gradient bucket -- partial-tile reduction, gradient unpack, the bucket's Ranger
+        update and operand re-pack -- behind an event of the side stream, so that the side stream goes straight on to the next bucket's
+        MFMA-bound weight gradient instead of serialising ~0.5 ms of streaming kernels between them (GDRN_POST_STREAM=0: on the side stream)"""
+        if not self.post_on:
+            return None
+        if getattr(self, "_post", None) is None:
+            self._post = make_stream(self.dev, os.environ.get("GDRN_SIDE_PRIO", "low"))
+        return self._post
 
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.dev)
@@ -618,7 +629,10 @@ class Plan:
             kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>"
         else:
             kname = f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
-        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + (":dgrad" if w is not None else ""))
+        # algorithmic bytes (SURVEY 8(d) convention: activations in + out once, weights once, at the storage width)
+        esz = 2 if e.dt != F32 else 4
+        nbytes = (self.B * Hi * Wi * cp.Cin + self.B * Ho * Wo * cp.Cout) * esz + cp.Cout * cp.Cin * cp.KH * cp.KW * esz
+        run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(nbytes), layer=L.key + (":dgrad" if w is not None else ""))
         return run, cp
 
     def _stats_rows(self, cp):
@@ -640,7 +654,9 @@ class Plan:
         if use_halo:
             # deferred: one grouped launch per gradient bucket (see _finish_unpack) -- weight gradients are off the
             # critical path, and a grid over many layers fills the chip with far fewer pixel-range splits per layer
-            self._wgrad_deferred.append((len(self.bwd_groups), L, wp, 2.0 * self.B * Ho * Wo * L.O * L.I * L.KK))
+            # (flops, algorithmic bytes: X and dY read once at the storage width, the fp32 gradient written once)
+            self._wgrad_deferred.append((len(self.bwd_groups), L, wp, (2.0 * self.B * Ho * Wo * L.O * L.I * L.KK,
+                                                                      2.0 * self.B * (Hi * Wi * cin + Ho * Wo * cout) + 4.0 * cout * cin * 9)))
             return None
 
         self._zero_regions.append(self._pad16(L.dwp, e.dwp_flat))  # accumulated with fp32 atomics
@@ -658,7 +674,9 @@ class Plan:
             macs = self.B * Ho * Wo * L.O * L.I * L.KK
         bco, bci = (64 if cout <= 64 else 128), (128 if cin % 128 == 0 else 64)
         kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>"
-        run.meta = dict(kernel=kname, flops=2.0 * macs, layer=L.key + ":wgrad")
+        esz = 2 if e.dt != F32 else 4
+        run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(self.B * (Hi * Wi * cin + Ho * Wo * cout) * esz + 4 * cout * cin * wp.KH * wp.KW),
+                        layer=L.key + ":wgrad")
         run.side = e.side_small  # feeds only the optimizer: off the data-gradient chain (side stream, see run_backward)
         return run
 
@@ -846,8 +864,8 @@ class Plan:
         cuts = sorted(set(first_group) | (set(e.wgrad_cuts) if e.wgrad_stream else set()), reverse=True)
         cut_of = lambda gi: next(c for c in cuts if gi >= c)
         wg_bucket = {c: [] for c in cuts}
-        for gi, L, wp, flops in self._wgrad_deferred:
-            wg_bucket[cut_of(gi)].append((L, wp, flops))
+        for gi, L, wp, fb in self._wgrad_deferred:
+            wg_bucket[cut_of(gi)].append((L, wp, fb))
         self._wgrad_tables = []
         for cut, items_all in wg_bucket.items():
             if not items_all:
@@ -901,7 +919,7 @@ class Plan:
                         check(lib.gdrn_conv3x3_wgrad_multi_w128(ptr(tab), ptr(stt), nt, nb, grid if (e.wgrad_stream or e.wgrad_force_lds) else 0, st),
                               "conv3x3_wgrad_multi_w128")
 
-                    run.meta = dict(kernel="conv3x3_wgrad_w128_multi_kernel", flops=sum(t[4] for t in tasks),
+                    run.meta = dict(kernel="conv3x3_wgrad_w128_multi_kernel", flops=sum(t[4][0] for t in tasks), bytes=sum(t[4][1] for t in tasks),
                                     layer=f"bucket{bkt}@{cut}:wgrad128 x{nt} ({nb} wg, grid {grid or nb})")
                 else:
                     def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
@@ -909,7 +927,8 @@ class Plan:
                         # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
                         check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
 
-                    run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4] for t in tasks), layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
+                    run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4][0] for t in tasks), bytes=sum(t[4][1] for t in tasks),
+                                    layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
                 run.side = True
                 if cut in first_group:
                     self._bucket_end(bkt, run)
@@ -946,6 +965,7 @@ class Plan:
                 check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi")
 
             unpack.side = True
+            unpack.post = True   # HBM-bound bucket tail: third stream (Engine.post_stream)
             self._bucket_end(bkt, unpack)
         for bkt, tasks in red_bucket.items():
             if not tasks:
@@ -961,6 +981,7 @@ class Plan:
                 check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi")
 
             wreduce.side = True
+            wreduce.post = True
             self._bucket_end(bkt, wreduce)
 
     # ---- graph -------------------------------------------------------------------------------
@@ -1447,7 +1468,8 @@ class Plan:
         # the RCCL exchange: it goes to a second stream behind an event, so the next bucket's dependent chain of short
         # data-gradient / BatchNorm kernels (one workgroup per CU on the small feature maps) shares the CUs with it.
         side = e.side_stream() if e.wgrad_stream else None
-        used_side = in_side = False
+        post = e.post_stream() if side is not None else None
+        used_side = in_side = in_post = used_post = False
         probe = getattr(self, "op_events", None)   # bench.py: [(start, end, meta, on_side)] HIP events around the conv launches of THIS pass
         for i, op in enumerate(self.bwd):
             if probe is not None and getattr(op, "meta", None) is not None:
@@ -1456,22 +1478,41 @@ class Plan:
                 if not in_side:
                     side.wait_stream(main)  # everything enqueued so far on the main stream
                     in_side = used_side = True
-                op(side.cuda_stream, ctx)
+                tail = side
+                if post is not None and getattr(op, "post", False):
+                    if not in_post:
+                        post.wait_stream(side)   # ... and on the side stream (this bucket's weight gradients)
+                        in_post = used_post = True
+                    tail = post
+                else:
+                    in_post = False
+                op(tail.cuda_stream, ctx)
                 if i in marks:
-                    with torch.cuda.stream(side):
+                    if post is not None and tail is not post:
+                        post.wait_stream(side)
+                        used_post = True
+                        tail = post
+                    with torch.cuda.stream(tail):
                         on_bucket(marks[i])
             else:
-                in_side = False
+                in_side = in_post = False
                 op(st, ctx)
                 if i in marks:
                     if used_side:     # the bucket's side-stream work (weight-gradient reduction) is part of the bucket
                         side.wait_stream(main)
-                        with torch.cuda.stream(side):
+                        tail = side
+                        if post is not None:
+                            post.wait_stream(side)
+                            used_post = True
+                            tail = post
+                        with torch.cuda.stream(tail):
                             on_bucket(marks[i])
                     else:
                         on_bucket(marks[i])
         if used_side:
             main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
+        if used_post:
+            main.wait_stream(post)
 
     def walk_backward(self, on_bucket, before_bucket=None):
         """The backward launch list WITHOUT launching (works on a dry engine): calls before_bucket(i) / on_bucket(i) where

@@ -258,3 +258,33 @@ def test_bucket_layout_follows_the_process_group_and_rejects_bad_values(monkeypa
     monkeypatch.setenv("GDRN_BUCKETS", "3")
     with pytest.raises(ValueError, match="GDRN_BUCKETS"):
         Engine(dict(model.named_parameters()), dict(model.named_buffers()), dtype="bf16", dry=True)
+
+
+# ---------------------------------------------------------------------------------------------- bench.py starts its own ranks
+def _bench(*argv):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (pr.stdout[-2000:], pr.stderr[-2000:])   # ONE JSON line, whatever happened
+    return pr.returncode, json.loads(lines[0])
+
+
+def test_bench_gpus2_launches_its_own_ranks_dry_gloo():
+    """`python bench.py --gpus 2` (no torch.distributed.run in front, as the driver's single-GPU command looks) starts two ranks itself; --dry
+    --backend gloo runs the launcher, the process group and the bucket protocol of the real bs=64 backward launch list without kernels."""
+    rc, j = _bench("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "1")
+    assert rc == 0, j
+    assert j["n_gpus"] == 2 and j["process_group"]["world_size"] == 2 and j["dry"] is True and j["protocol_ok"] is True
+    assert j["buckets"] == 5 and abs(sum(j["bucket_mb"]) - 140.2) < 0.5          # the data-parallel layout, 35.05 M fp32 gradients
+    assert j["config"]["global_batch"] == 128 and j["value"] > 0 and j["steps"] == 2 and j["warmup"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="box has two GPUs: the launch would really run")
+def test_bench_gpus2_without_two_gpus_is_one_json_error_line():
+    rc, j = _bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert rc != 0 and j["value"] is None and j["n_gpus"] == 2 and "needs 2 visible GPUs" in j["error"]
