@@ -235,7 +235,8 @@ class _PathFn(torch.autograd.Function):
             # the plan keeps ONE set of activations per (batch size, mode): a second forward overwrote what this backward needs
             raise cabi.GdrnHipError("backward of a forward pass whose activations were overwritten by a later forward of the same "
                                     "batch size: call loss.backward() before the next model(...) call")
-        plan.gw.copy_(glosses.to(torch.float32))
+        ls = float(getattr(e, "loss_scale", 1.0))
+        plan.gw.copy_(glosses.to(torch.float32) * ls)   # (fp16: the engine's static loss scale on the whole gradient chain)
         plan._gw_key = None
         plan.run_backward(ctx.kctx, on_bucket=ctx.model._on_bucket)
         red = getattr(ctx.model, "_reducer", None)
@@ -243,6 +244,8 @@ class _PathFn(torch.autograd.Function):
             # autograd clones these views into .grad on the compute stream right after we return: the bucket all-reduces
             # running on the reducer's side stream must have landed (and the mean be applied) before that
             red.finish()
+        if ls != 1.0:
+            e.grad_flat.mul_(1.0 / ls)   # .grad is the unscaled gradient, as after GradScaler.unscale_()
         return (None, None, None) + tuple(e.grads[n] for n in e.param_names)
 
 
@@ -262,27 +265,43 @@ class GDRN(nn.Module):
         self.cfg = cfg
         self.concat = cfg.MODEL.CDPN.ROT_HEAD.ROT_CONCAT
         self.r_out_dim, self.mask_out_dim, self.region_out_dim = get_xyz_mask_region_out_dim(cfg)
-        self.hip_dtype = str(cfg.MODEL.CDPN.get("HIP_DTYPE", os.environ.get("GDRN_HIP_DTYPE", "bf16")))
-        self._eng = None
-        self._eng_key = None
+        # Arithmetic of the kernels: "bf16" (default), "fp16", "fp32" (parity mode).  An explicit cfg.MODEL.CDPN.HIP_DTYPE / GDRN_HIP_DTYPE
+        # applies to training and inference alike.  Without one the reference's two AMP switches select fp16, the format of its autocast:
+        # cfg.SOLVER.AMP.ENABLED (autocast + GradScaler around the train step, main_gdrn.py:53-56,141, engine.py:276-283) -> fp16 training
+        # with the engine's static loss scale; cfg.TEST.AMP_TEST (autocast around the test-time forward, gdrn_evaluator.py:568) -> fp16
+        # inference (eval-mode forward) whatever the training arithmetic is.
+        explicit = cfg.MODEL.CDPN.get("HIP_DTYPE", os.environ.get("GDRN_HIP_DTYPE"))
+        solver, test = cfg.get("SOLVER", None), cfg.get("TEST", None)
+        amp_train = bool(solver is not None and solver.get("AMP", None) is not None and solver.AMP.get("ENABLED", False))
+        amp_test = bool(test is not None and test.get("AMP_TEST", False))
+        self.hip_dtype = str(explicit) if explicit else ("fp16" if amp_train else "bf16")
+        self.hip_dtype_eval = str(explicit) if explicit else ("fp16" if amp_test else self.hip_dtype)
+        self._engs = {}          # arithmetic -> (parameter-storage key, Engine)
+        self._eng = None         # the engine of the last engine() call (dist.attach / broadcast_parameters look at it)
         self._on_bucket = None   # set by dist.attach(): overlap the RCCL all-reduce with backward
         self._loss_w = None
         self.last_vis = None
 
     # -------------------------------------------------------------------------------------------
-    def engine(self):
-        """The HIP engine bound to the current parameter storage (rebuilt after .to()/.load_state_dict re-allocation)."""
+    def engine(self, dtype=None):
+        """The HIP engine bound to the current parameter storage (rebuilt after .to()/.load_state_dict re-allocation) for the arithmetic of
+        the current mode: hip_dtype in train mode, hip_dtype_eval in eval mode (they differ only for cfg.TEST.AMP_TEST); one engine per
+        arithmetic in use."""
+        dtype = dtype or (self.hip_dtype if self.training else self.hip_dtype_eval)
         params = dict(self.named_parameters())
-        key = (self.hip_dtype,) + tuple(p.data_ptr() for p in params.values())
-        if self._eng is None or self._eng_key != key:
+        key = tuple(p.data_ptr() for p in params.values())
+        hit = self._engs.get(dtype)
+        if hit is None or hit[0] != key:
             dev = next(iter(params.values())).device
             if dev.type != "cuda":
                 raise cabi.GdrnHipError("GDRN runs on the HIP engine only: move the model to an MI355X (`model.to('cuda')`)")
             r, p = self.cfg.MODEL.CDPN.ROT_HEAD, self.cfg.MODEL.CDPN.PNP_NET
-            self._eng = Engine(params, dict(self.named_buffers()), dtype=self.hip_dtype, num_regions=r.NUM_REGIONS)
-            self._eng_key = key
+            hit = (key, Engine(params, dict(self.named_buffers()), dtype=dtype, num_regions=r.NUM_REGIONS))
+            self._engs = {k: v for k, v in self._engs.items() if v[0] == key}   # engines of a re-allocated parameter set are dead
+            self._engs[dtype] = hit
             lw = [r.XYZ_LW, r.XYZ_LW, r.XYZ_LW, r.MASK_LW, r.REGION_LW, p.PM_LW, p.CENTROID_LW, p.Z_LW]
             self._loss_w = torch.tensor(lw, dtype=torch.float32, device=dev)
+        self._eng = hit[1]
         return self._eng
 
     @staticmethod
@@ -463,14 +482,15 @@ class GDRN(nn.Module):
                 return out
         eng, plan, kctx = self._prepare(x, True, a)
         plan.run_forward(kctx)
+        eng = plan.e
+        ls = eng.loss_scale   # fp16: static loss scale on dL/dloss, divided out where the optimizer reads the gradients
         if loss_weights is not None:
-            plan.gw.copy_(self._loss_w * loss_weights)
+            plan.gw.copy_(self._loss_w * loss_weights * ls)
             plan._gw_key = None
         elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version):
-            plan.gw.copy_(self._loss_w)  # dL/dloss_k = the config's loss weights: written once, not every step
+            plan.gw.copy_(self._loss_w * ls)  # dL/dloss_k = the config's loss weights: written once, not every step
             plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version)
         red = getattr(self, "_reducer", None)
-        eng = plan.e
         # The optimizer update of a gradient bucket goes out as soon as the bucket is final, under the rest of the backward pass
         # (Ranger.step_buckets_*), instead of behind the whole pass: on one GPU on the engine's side stream right behind the bucket's
         # weight-gradient reduction; with a GradReducer attached (dist.attach) on the reducer's stream right behind the bucket's all-reduce,
@@ -484,7 +504,7 @@ class GDRN(nn.Module):
                 eng._bucket_of = lambda p_, off=off, bb=eng.bucket_bounds: next(i for i, (lo, hi) in enumerate(bb) if lo <= off[id(p_)] < hi)
                 eng._bucket_of_bounds = tuple(eng.bucket_bounds)
             early = optimizer.step_buckets_begin({eng.P[n]: eng.grads[n] for n in eng.param_names}, eng._bucket_of, len(eng.bucket_bounds),
-                                                 grad_scale=(red.grad_scale if red is not None else 1.0))
+                                                 grad_scale=(red.grad_scale if red is not None else 1.0) / ls)
         if early:
             packed = []
 
@@ -498,18 +518,24 @@ class GDRN(nn.Module):
                 optimizer.step_bucket(b)
                 packed.append(eng.repack_bucket(b))
 
-            plan.run_backward(kctx, on_bucket=bucket_done)
+            try:
+                plan.run_backward(kctx, on_bucket=bucket_done)
+            except BaseException:
+                optimizer.step_buckets_abort()   # step counters untouched
+                raise
             if red is not None:
                 red.wait()   # the main stream (next forward, the caller) behind every bucket's exchange + update
             optimizer.step_buckets_end()
+            if red is not None and red.active and red.world > 1:
+                self._dp_divergence_check(eng)
             if packed and all(packed):
                 eng.mark_packed()
             return plan.losses * self._loss_w
         plan.run_backward(kctx, on_bucket=self._on_bucket)
-        gs = 1.0
+        gs = 1.0 / ls
         if red is not None:
             red.wait()
-            gs = red.grad_scale  # 1/world, folded into the fused optimizer's gradient read
+            gs = red.grad_scale / ls  # 1/world, folded into the fused optimizer's gradient read
         if optimizer is not None:
             eng = plan.e
             grads = {eng.P[n]: eng.grads[n] for n in eng.param_names}
@@ -523,6 +549,28 @@ class GDRN(nn.Module):
         elif gs != 1.0:
             plan.e.grad_flat.mul_(gs)
         return plan.losses * self._loss_w  # weighted like forward()'s loss_dict
+
+    def _dp_divergence_check(self, eng):
+        """Data-parallel safety net of the per-bucket optimizer (the update of a bucket runs on the reducer's stream right behind its all-reduce,
+        ADVICE r3: that path has only run with one real rank).  Ranks that apply the same summed gradients hold bit-identical parameters; on the
+        first GDRN_DP_CHECK_STEPS (default 2) data-parallel steps every rank compares a checksum of its parameters with the other ranks' and
+        raises instead of training on silently diverged replicas.  Two host synchronisations in the life of a run."""
+        n = self.__dict__.get("_dp_checked", 0)
+        if n >= int(os.environ.get("GDRN_DP_CHECK_STEPS", "2")):
+            return
+        self.__dict__["_dp_checked"] = n + 1
+        import torch.distributed as dist
+
+        red = self._reducer
+        with torch.no_grad():
+            cs = torch.stack([eng.P[k].detach().double().sum() for k in eng.param_names] +
+                             [eng.P[k].detach().double().abs().sum() for k in eng.param_names]).sum(0, keepdim=True)
+        got = [torch.empty_like(cs) for _ in range(red.world)]
+        dist.all_gather(got, cs, group=red.group)
+        vals = [float(g.item()) for g in got]
+        if any(v != vals[0] for v in vals) or not all(v == v for v in vals):
+            raise cabi.GdrnHipError(f"data-parallel replicas diverged after step {n + 1}: parameter checksums {vals} "
+                               "(set GDRN_EARLY_OPT=0 to run the optimizer behind the whole backward pass)")
 
     def _train_step_graph(self, x, optimizer, a):
         """The step as ONE hipGraph replay: operand repack + forward + losses + backward (~350 kernel launches, many of

@@ -8,8 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDRN_HIP_LIB") or os.path.join(_HERE, "lib", "libgdrn_hip.so")   # (GDRN_HIP_LIB: A/B runs of two builds on one box)
+# the same sources built with IEEE half as the 16-bit format (csrc/common.h): the reference's fp16 autocast arithmetic
+LIB_PATH_F16 = os.environ.get("GDRN_HIP_LIB_F16") or os.path.join(_HERE, "lib", "libgdrn_hip_f16.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 PREZEROED = 0x100  # GDRN_PREZEROED
 P = C.c_void_p
 I = C.c_int
@@ -164,30 +166,35 @@ _SIGS = {
     "gdrn_roi_targets": [P, P, I, I, P, I, P, P, P, P, P, P, P],
 }
 
+_SIGS["gdrn_half_format"] = []
 EXPORTS = tuple(_SIGS.keys())
-_lib = None
+_libs = {}
 
 
-def lib_path():
-    return LIB_PATH
+def lib_path(dtype=BF16):
+    return LIB_PATH_F16 if dtype == F16 else LIB_PATH
 
 
-def load():
-    """Load (once) and return the ctypes handle; raises GdrnHipError if the library is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(dtype=BF16):
+    """Load (once) and return the ctypes handle of the library build that computes `dtype` (F32 and BF16: libgdrn_hip.so; F16:
+    libgdrn_hip_f16.so -- identical entry points, IEEE half as the 16-bit format); raises GdrnHipError if the library is absent."""
+    kind = F16 if dtype == F16 else BF16
+    if kind in _libs:
+        return _libs[kind]
+    path = lib_path(kind)
+    if not os.path.exists(path):
         raise GdrnHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = LL if name == "gdrn_workspace_bytes" else I
-    _lib = lib
+    if lib.gdrn_half_format() != kind:
+        raise GdrnHipError(f"{path} computes 16-bit dtype code {lib.gdrn_half_format()}, expected {kind}")
+    _libs[kind] = lib
     return lib
 
 

@@ -154,9 +154,10 @@ def _base():
             REL_STEPS=(0.5, 0.75),
             CHECKPOINT_PERIOD=5,
             CHECKPOINT_BY_EPOCH=True,
+            AMP=dict(ENABLED=False),   # configs/_base_/common_base.py:130 (True in the 30 single-object AMP configs): fp16 kernels + loss scale here
         ),
         INPUT=dict(DZI_TYPE="uniform", DZI_PAD_SCALE=1.5, DZI_SCALE_RATIO=0.25, DZI_SHIFT_RATIO=0.25, SMOOTH_XYZ=False),  # common_base.py:49,53; a6_cPnP_lm13.py:5
-        TEST=dict(USE_PNP=False),
+        TEST=dict(USE_PNP=False, AMP_TEST=False),   # AMP_TEST: common_base.py:173 -> fp16 inference (gdrn_evaluator.py:568)
     )
 
 

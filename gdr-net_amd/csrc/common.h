@@ -1,16 +1,48 @@
 // Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the GDR-Net RoI path.
-// Element type T is either float (parity mode, fp32 MFMA) or bf16_t (throughput mode, bf16 MFMA,
-// fp32 accumulate).  All activations are NHWC.
+// Element type T is either float (parity mode, fp32 MFMA) or bf16_t = the 16-bit storage type of THIS BUILD (throughput mode, 16-bit
+// MFMA operands, fp32 accumulate).  All activations are NHWC.
+//
+// The 16-bit format is a property of the library build, not of a template parameter: the same sources are compiled twice --
+//   libgdrn_hip.so      16-bit type = bfloat16  (dtype code GDRN_DT_BF16; v_mfma_f32_*_bf16, v_cvt_pk_bf16_f32)
+//   libgdrn_hip_f16.so  16-bit type = IEEE half (dtype code GDRN_DT_F16, -DGDRN_HALF_F16; v_mfma_f32_*_f16, v_cvt_pk_f16_f32: the
+//                       reference's fp16 autocast, main_gdrn.py:53-56,141 / gdrn_evaluator.py:568; same MFMA rate, 11 instead of 8
+//                       significand bits) --
+// and everything format-specific lives in this header: the storage <-> fp32 conversions (h16lo / h16hi / bf2f / pack_bf2), the MFMA
+// builtins (GDRN_MFMA16 / GDRN_MFMA32), their assembler mnemonic (GDRN_MFMA16_ASM), the transposing LDS read (GDRN_TR16) and the
+// packed constant 1.0 (GDRN_H16_ONE2).  The names bf16_t / bf16x8_t keep their round-1 spelling in the kernels: read "the build's half".
+// GDRN_DT_H16 is the dtype code this build accepts for its 16-bit kernels (the other one is GDRN_ERR_ARG).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef unsigned short bf16_t;  // raw bits of the build's 16-bit format
+#ifdef GDRN_HALF_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4_t;
+#define GDRN_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_f16(a_, b_, c_, 0, 0, 0)
+#define GDRN_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#define GDRN_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 gdrn_fp16x4_t;   // the builtin's own element type
+typedef __attribute__((address_space(3))) gdrn_fp16x4_t gdrn_lds_fp16x4_t;
+#define GDRN_TR16(p_) __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((gdrn_lds_fp16x4_t*)(p_)))
+#define GDRN_H16_ONE2 0x3c003c00u
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+#define GDRN_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
+#define GDRN_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#define GDRN_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#define GDRN_TR16(p_) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p_)
+#define GDRN_H16_ONE2 0x3f803f80u
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #include "../../include/gdrn_hip.h"  // status codes (GDRN_OK, GDRN_ERR_*) and dtype selectors (GDRN_DT_*)
+#ifdef GDRN_HALF_F16
+#define GDRN_DT_H16 GDRN_DT_F16
+#else
+#define GDRN_DT_H16 GDRN_DT_BF16
+#endif
 
 #define GDRN_CHECK_LAUNCH()                                  \
     do {                                                     \
@@ -18,7 +50,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
         if (e__ != hipSuccess) return GDRN_ERR_LAUNCH;       \
     } while (0)
 
+#ifdef GDRN_HALF_F16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// the low / high 16-bit element of a packed pair as fp32 (v_cvt_f32_f16, the high one through SDWA)
+__device__ __forceinline__ float h16lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float h16hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+// fp32 -> fp16 pair, round-to-nearest-even (values beyond 65504 become inf, as torch's .half())
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    typedef float f32x2_cvt_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_cvt_t __attribute__((ext_vector_type(2)));
+    const f32x2_cvt_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_cvt_t));
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float h16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // fp32 -> bf16, round-to-nearest-even, on the gfx950 converter (v_cvt_pk_bf16_f32: one instruction per PAIR; the
 // integer-arithmetic version cost ~7 VALU instructions per element in every bf16-writing epilogue)
@@ -28,6 +75,7 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     const f32x2_cvt_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_cvt_t));
 }
+#endif
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
@@ -57,10 +105,10 @@ template <>
 struct Vec16<bf16_t> {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ void unpack(uint4 u, float* v) {
-        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+        v[0] = h16lo(u.x); v[1] = h16hi(u.x);
+        v[2] = h16lo(u.y); v[3] = h16hi(u.y);
+        v[4] = h16lo(u.z); v[5] = h16hi(u.z);
+        v[6] = h16lo(u.w); v[7] = h16hi(u.w);
     }
     __device__ static __forceinline__ uint4 pack(const float* v) {
         return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));

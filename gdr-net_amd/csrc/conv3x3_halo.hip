@@ -42,7 +42,7 @@ template <typename T>
 __device__ __forceinline__ f32x4_t mma_step(uint4 a, uint4 b, f32x4_t c);
 template <>
 __device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c);
 }
 
 // fragment-major weight packing: granule (16 B) permutation of the row-major [rows][9][Cin] operand
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                         for (int a = 0; a < FN; ++a) {
                             av[bb][a] = make_uint2(0u, 0u);
-                            mq[bb][a] = make_uint2(0x3f803f80u, 0x3f803f80u);
+                            mq[bb][a] = make_uint2(GDRN_H16_ONE2, GDRN_H16_ONE2);
                         }
                     }
                     if (ab != nullptr) {
@@ -436,12 +436,12 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                         for (int a = 0; a < FN; ++a) {
                             const uint2 xw = xq[bb][a], aw = av[bb][a], mw = mq[bb][a];
-                            const float xv[4] = {__uint_as_float(xw.x << 16), __uint_as_float(xw.x & 0xffff0000u),
-                                                 __uint_as_float(xw.y << 16), __uint_as_float(xw.y & 0xffff0000u)};
-                            const float mv[4] = {__uint_as_float(mw.x << 16), __uint_as_float(mw.x & 0xffff0000u),
-                                                 __uint_as_float(mw.y << 16), __uint_as_float(mw.y & 0xffff0000u)};
-                            const float ad[4] = {__uint_as_float(aw.x << 16), __uint_as_float(aw.x & 0xffff0000u),
-                                                 __uint_as_float(aw.y << 16), __uint_as_float(aw.y & 0xffff0000u)};
+                            const float xv[4] = {h16lo(xw.x), h16hi(xw.x),
+                                                 h16lo(xw.y), h16hi(xw.y)};
+                            const float mv[4] = {h16lo(mw.x), h16hi(mw.x),
+                                                 h16lo(mw.y), h16hi(mw.y)};
+                            const float ad[4] = {h16lo(aw.x), h16hi(aw.x),
+                                                 h16lo(aw.y), h16hi(aw.y)};
                             float v[4];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         const uint2 av_ = avq[b][a];
-                        float v0 = acc[a][b][0] + bq[a][0] + __uint_as_float(av_.x << 16), v1 = acc[a][b][1] + bq[a][1] + __uint_as_float(av_.x & 0xffff0000u);
-                        float v2 = acc[a][b][2] + bq[a][2] + __uint_as_float(av_.y << 16), v3 = acc[a][b][3] + bq[a][3] + __uint_as_float(av_.y & 0xffff0000u);
+                        float v0 = acc[a][b][0] + bq[a][0] + h16lo(av_.x), v1 = acc[a][b][1] + bq[a][1] + h16hi(av_.x);
+                        float v2 = acc[a][b][2] + bq[a][2] + h16lo(av_.y), v3 = acc[a][b][3] + bq[a][3] + h16hi(av_.y);
                         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         ov[a] = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
                     }
@@ -638,7 +638,7 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     if (p->w_frag == 2) { gdrn_v3_tile(p, th, tw, bn); return GDRN_OK; }
     if (p->mode != 0 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->Hi != p->Ho || p->Wi != p->Wo) return GDRN_OK;
     if ((p->Ho % 8) || (p->Wo % 8)) return GDRN_OK;
-    if (p->dtype != GDRN_DT_BF16) return GDRN_OK;  // parity (fp32) mode keeps the generic kernel: its per-stage partial
+    if (p->dtype != GDRN_DT_H16) return GDRN_OK;  // parity (fp32) mode keeps the generic kernel: its per-stage partial
                                                     // accumulators plus the weight ring do not fit the register file
     *th = 8;
     *tw = (p->Wo % 16 == 0) ? 16 : 8;
@@ -658,13 +658,13 @@ extern "C" int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p) {
 
 extern "C" int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, void* stream) {
     if (!src || !dst || rows <= 0 || (rows % 16) || Cin <= 0) return GDRN_ERR_ARG;
-    const int esz = dtype == GDRN_DT_BF16 ? 2 : 4;
+    const int esz = dtype == GDRN_DT_H16 ? 2 : 4;
     if ((Cin * esz) % ROWB) return GDRN_ERR_SHAPE;
     const long long n = (long long)rows * 9 * Cin * esz / 16;
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_wfrag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Cin);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(pack_wfrag_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_wfrag_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -674,9 +674,9 @@ extern "C" int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, in
 extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (!pp || !pp->x || !pp->w || !pp->y) return GDRN_ERR_ARG;
     const gdrn_conv_params& p = *pp;
-    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_H16) return GDRN_ERR_ARG;
     if (p.w_frag == 2) return gdrn_v3_launch(pp, stream);
-    const int esz = p.dtype == GDRN_DT_BF16 ? 2 : 4;
+    const int esz = p.dtype == GDRN_DT_H16 ? 2 : 4;
     int th, tw, bn;
     gdrn_conv3x3_tile(pp, &th, &tw, &bn);
     if (th == 0) return GDRN_ERR_SHAPE;

@@ -346,8 +346,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     {                                                                                                                   \
         _Pragma("unroll") for (int a_ = 0; a_ < FA; ++a_)                                                               \
             _Pragma("unroll") for (int b_ = 0; b_ < FB; ++b_)                                                           \
-                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa_[a_]),            \
-                                                                      __builtin_bit_cast(bf16x8_t, fb_[b_]), acc[a_][b_], 0, 0, 0); \
+                acc[a_][b_] = GDRN_MFMA32(__builtin_bit_cast(bf16x8_t, fa_[a_]),            \
+                                                                      __builtin_bit_cast(bf16x8_t, fb_[b_]), acc[a_][b_]); \
     }
 
 #ifdef V3_DBG
@@ -704,7 +704,7 @@ int launch_v3_cfg(const gdrn_conv_params& p, int cfg, int N, hipStream_t st) {
 // channels (8 waves, 64 x 64 wave tiles, K range split between two wave groups); 0 = shape not covered.
 int gdrn_v3_config(const gdrn_conv_params* p) {
     if (p->mode != 0 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->Hi != p->Ho || p->Wi != p->Wo) return 0;
-    if (p->dtype != GDRN_DT_BF16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
+    if (p->dtype != GDRN_DT_H16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
     if (p->act > 1 || p->out_f32) return 0;
     const int N = p->M / (p->Ho * p->Wo);
     const char* force = getenv("GDRN_V3_CFG");   // bring-up: "ab" = configuration a for the large-map choice, b for the small-map one
@@ -744,7 +744,7 @@ int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn) {
 
 extern "C" int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, int dtype, void* stream) {
     if (!src || !dst || rows <= 0 || (rows & 63) || Cin <= 0 || (Cin & 63)) return GDRN_ERR_ARG;
-    if (dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_ARG;
     const long long n = (long long)rows * 9 * Cin / 8;
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_wfrag32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)src, (bf16_t*)dst, rows, Cin);

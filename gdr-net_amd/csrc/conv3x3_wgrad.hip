@@ -50,8 +50,8 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ bf16x8_t tr_pair(const unsigned char* p0, const unsigned char* p1) {
-    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p0);
-    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)p1);
+    bf16x4_t lo = GDRN_TR16((lds_bf16x4_t*)p0);
+    bf16x4_t hi = GDRN_TR16((lds_bf16x4_t*)p1);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -231,12 +231,12 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 if constexpr (NA == 4) {
-                    acc[j % 9][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a], 0, 0, 0);
+                    acc[j % 9][a] = GDRN_MFMA16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a]);
                 } else if (j % 9 < 8) {
-                    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]),
+                    asm volatile(GDRN_MFMA16_ASM " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]),
                                  "i"(4 * ((j % 9) * 8 + a)), "i"(4 * ((j % 9) * 8 + a) + 3));
                 } else {
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[j % 9][a]) : "v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]));
+                    asm volatile(GDRN_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[j % 9][a]) : "v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]));
                 }
             }
             // next patch: one address piece + its loads per group (same scheduling region as the MFMAs above)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wred
 // 1 if the shape is covered by the halo weight-gradient kernel
 extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
     if (!p) return 0;
-    if (!(p->dtype == GDRN_DT_BF16 && p->KH == 3 && p->KW == 3 && p->pad == 1 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
+    if (!(p->dtype == GDRN_DT_H16 && p->KH == 3 && p->KW == 3 && p->pad == 1 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
           (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0 && (p->Wo % 8) == 0))
         return 0;
     if (p->variant != 0 && !(p->variant == GDRN_WGRAD_W128 && (p->Cout % 128) == 0)) return 0;

@@ -27,7 +27,7 @@ __device__ __forceinline__ f32x4_t mma_step(uint4 a, uint4 b, f32x4_t c);
 
 template <>
 __device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c);
 }
 
 template <>
@@ -368,17 +368,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     uint2 xq[FN], aq[FN], mq[FN], ov[FN];
                     ld_ch(xb, orow * (unsigned)p.bnb_cs + cl, xq);
 #pragma unroll
-                    for (int a = 0; a < FN; ++a) { aq[a] = make_uint2(0u, 0u); mq[a] = make_uint2(0x3f803f80u, 0x3f803f80u); }
+                    for (int a = 0; a < FN; ++a) { aq[a] = make_uint2(0u, 0u); mq[a] = make_uint2(GDRN_H16_ONE2, GDRN_H16_ONE2); }
                     if (ab != nullptr) ld_ch(ab, orow * (unsigned)p.add_cs + cl, aq);
                     if (mb != nullptr) ld_ch(mb, orow * (unsigned)p.bnb_cs + cl, mq);
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
-                        const float xv[4] = {__uint_as_float(xq[a].x << 16), __uint_as_float(xq[a].x & 0xffff0000u),
-                                             __uint_as_float(xq[a].y << 16), __uint_as_float(xq[a].y & 0xffff0000u)};
-                        const float mv[4] = {__uint_as_float(mq[a].x << 16), __uint_as_float(mq[a].x & 0xffff0000u),
-                                             __uint_as_float(mq[a].y << 16), __uint_as_float(mq[a].y & 0xffff0000u)};
-                        const float ad[4] = {__uint_as_float(aq[a].x << 16), __uint_as_float(aq[a].x & 0xffff0000u),
-                                             __uint_as_float(aq[a].y << 16), __uint_as_float(aq[a].y & 0xffff0000u)};
+                        const float xv[4] = {h16lo(xq[a].x), h16hi(xq[a].x),
+                                             h16lo(xq[a].y), h16hi(xq[a].y)};
+                        const float mv[4] = {h16lo(mq[a].x), h16hi(mq[a].x),
+                                             h16lo(mq[a].y), h16hi(mq[a].y)};
+                        const float ad[4] = {h16lo(aq[a].x), h16hi(aq[a].x),
+                                             h16lo(aq[a].y), h16hi(aq[a].y)};
                         float v[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                 if (ab != nullptr) {
                     if constexpr (sizeof(T) == 2) {
                         const uint2 q = aqb[a];
-                        v0 += __uint_as_float(q.x << 16); v1 += __uint_as_float(q.x & 0xffff0000u);
-                        v2 += __uint_as_float(q.y << 16); v3 += __uint_as_float(q.y & 0xffff0000u);
+                        v0 += h16lo(q.x); v1 += h16hi(q.x);
+                        v2 += h16lo(q.y); v3 += h16hi(q.y);
                     } else {
                         const float4 q = *reinterpret_cast<const float4*>(ab + ((size_t)orow * p.add_cs + c) * 4);
                         v0 += q.x; v1 += q.y; v2 += q.z; v3 += q.w;
@@ -574,8 +574,8 @@ extern "C" int gdrn_conv_stats_rows(const gdrn_conv_params* p) {
 extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
     if (!pp || !pp->x || !pp->w || !pp->y) return GDRN_ERR_ARG;
     const gdrn_conv_params& p = *pp;
-    const int esz = (p.dtype == GDRN_DT_BF16) ? 2 : 4;
-    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
+    const int esz = (p.dtype == GDRN_DT_H16) ? 2 : 4;
+    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_H16) return GDRN_ERR_ARG;
     if (p.Cin <= 0 || (p.Cin * esz) % ROWB != 0) return GDRN_ERR_SHAPE;
     if ((p.x_cs * esz) % 8 != 0 || p.KH * p.KW > 64 || p.KH * p.KW < 1) return GDRN_ERR_SHAPE;
     if (p.mode == 1 && (p.stride != 2 || (p.Ho & 1) || (p.Wo & 1))) return GDRN_ERR_SHAPE;
@@ -586,14 +586,14 @@ extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
     gdrn_conv_tile(pp, &bm, &bn);
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: the straight-line bf16 epilogue only
-        if (p.dtype != GDRN_DT_BF16 || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (p.dtype != GDRN_DT_H16 || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || p.stats || (p.Cout % bn) || (p.bnb_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || p.bnb_cs < p.Cout)
             return GDRN_ERR_SHAPE;  // (rows of whole 16-byte groups: the epilogue's accesses)
         const unsigned long long rows_out = (p.mode == 1) ? 4ull * (unsigned long long)p.M : (unsigned long long)p.M;
         if (rows_out * (unsigned long long)std::max(std::max(p.y_cs, p.add_cs), p.bnb_cs) * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.dtype == GDRN_DT_BF16) {
+    if (p.dtype == GDRN_DT_H16) {
         if (bn == 64) return bm == 128 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 64, 64>(p, st);
         return bm == 128 ? launch<bf16_t, 128, 128>(p, st) : launch<bf16_t, 64, 128>(p, st);
     } else {

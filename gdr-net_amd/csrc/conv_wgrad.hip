@@ -150,15 +150,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
 #pragma unroll
                     for (int a = 0; a < FA; ++a) {
                         const unsigned char* q0 = tA + trow * PA + (wa * WCO + a * 16 + tcol) * 2;
-                        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0));
-                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 16 * PA));
+                        bf16x4_t lo = GDRN_TR16((lds_bf16x4_t*)(q0));
+                        bf16x4_t hi = GDRN_TR16((lds_bf16x4_t*)(q0 + 16 * PA));
                         fa[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
 #pragma unroll
                     for (int b = 0; b < FB; ++b) {
                         const unsigned char* q0 = tB + trow * PB + (wb * WCI + b * 16 + tcol) * 2;
-                        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0));
-                        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(q0 + 16 * PB));
+                        bf16x4_t lo = GDRN_TR16((lds_bf16x4_t*)(q0));
+                        bf16x4_t hi = GDRN_TR16((lds_bf16x4_t*)(q0 + 16 * PB));
                         fb[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
                 }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const gdrn_wgrad_params
                 for (int a = 0; a < FA; ++a)
 #pragma unroll
                     for (int b = 0; b < FB; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = GDRN_MFMA16(fa[a], fb[b], acc[a][b]);
             }
         } else {
 #pragma unroll 4
@@ -238,8 +238,8 @@ int launch(const gdrn_wgrad_params& p, hipStream_t st) {
 extern "C" int gdrn_conv_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     if (!pp || !pp->x || !pp->dy || !pp->dw) return GDRN_ERR_ARG;
     const gdrn_wgrad_params& p = *pp;
-    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_BF16) return GDRN_ERR_ARG;
-    const int esz = p.dtype == GDRN_DT_BF16 ? 2 : 4;
+    if (p.dtype != GDRN_DT_F32 && p.dtype != GDRN_DT_H16) return GDRN_ERR_ARG;
+    const int esz = p.dtype == GDRN_DT_H16 ? 2 : 4;
     if (p.Cin <= 0 || p.Cin % 64 != 0 || p.M <= 0 || p.Cout <= 0) return GDRN_ERR_SHAPE;
     if ((p.x_cs * esz) % 16 != 0 && (p.x_cs * esz) % 8 != 0) return GDRN_ERR_SHAPE;
     const int bco = p.Cout <= 64 ? 64 : 128;
@@ -247,7 +247,7 @@ extern "C" int gdrn_conv_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     // dY rows are read in BCO-wide slabs: the caller guarantees dy_cs >= ceil(Cout/BCO)*BCO readable columns
     if (p.dy_cs < cdiv(p.Cout, bco) * bco) return GDRN_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.dtype == GDRN_DT_BF16) {
+    if (p.dtype == GDRN_DT_H16) {
         if (bco == 64) return bci == 64 ? launch<bf16_t, 64, 64>(p, st) : launch<bf16_t, 64, 128>(p, st);
         return bci == 64 ? launch<bf16_t, 128, 64>(p, st) : launch<bf16_t, 128, 128>(p, st);
     } else {

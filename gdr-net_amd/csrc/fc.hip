@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f][u]), __builtin_bit_cast(bf16x8_t, bq[u]),
-                                                                 acc[f], 0, 0, 0);
+                acc[f] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, aq[f][u]), __builtin_bit_cast(bf16x8_t, bq[u]),
+                                                                 acc[f]);
     }
     for (; k < kq; k += 32) {
         const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + k));
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const bf16_t* __rest
 #pragma unroll
         for (int f = 0; f < 4; ++f) aq[f] = *reinterpret_cast<const uint4*>(xp[f] + k);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aq[f]), b, acc[f], 0, 0, 0);
+        for (int f = 0; f < 4; ++f) acc[f] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, aq[f]), b, acc[f]);
     }
     // D[i = g*4 + j (row m of the fragment)][col = r16 (column n0 + r16)]
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restr
 extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
                                   int y_rs, int act, float* ws, int dtype, void* stream) {
     if (!x || !w || !y || !ws || M <= 0 || M > 64 || K <= 0 || N <= 0) return GDRN_ERR_ARG;
-    if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
     if ((N % 16) || (K % 128) || (x_rs % 8) || (w_rs % 8) || x_rs < K || w_rs < K || y_rs < N) return GDRN_ERR_SHAPE;
     // K range per workgroup: a multiple of 128 (32 per wave-step x 4 waves); ~1024 workgroups
     const int ntile = N / 16;

@@ -11,14 +11,14 @@ __host__ __device__ constexpr int xf_nk(int XF) { return XF == 0 ? 0 : (XF == 1 
 template <int XF>
 __device__ __forceinline__ uint2 xf_half(uint2 v1h, uint2 v2h, const float* t, int Cin, float lo) {
     const float4 a = *reinterpret_cast<const float4*>(t), c = *reinterpret_cast<const float4*>(t + Cin);
-    float x[4] = {__uint_as_float(v1h.x << 16), __uint_as_float(v1h.x & 0xffff0000u), __uint_as_float(v1h.y << 16), __uint_as_float(v1h.y & 0xffff0000u)};
+    float x[4] = {h16lo(v1h.x), h16hi(v1h.x), h16lo(v1h.y), h16hi(v1h.y)};
     const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
     float y[4];
     if constexpr (XF == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = fmaxf(__builtin_fmaf(x[j], av[j], cv[j]), lo);      // bn_apply_kernel's arithmetic
     } else {
-        const float x2[4] = {__uint_as_float(v2h.x << 16), __uint_as_float(v2h.x & 0xffff0000u), __uint_as_float(v2h.y << 16), __uint_as_float(v2h.y & 0xffff0000u)};
+        const float x2[4] = {h16lo(v2h.x), h16hi(v2h.x), h16lo(v2h.y), h16hi(v2h.y)};
         const float4 b = *reinterpret_cast<const float4*>(t + 2 * Cin);
         const float bv[4] = {b.x, b.y, b.z, b.w};
         if constexpr (XF == 2) {
@@ -28,7 +28,7 @@ __device__ __forceinline__ uint2 xf_half(uint2 v1h, uint2 v2h, const float* t, i
             const float c2v[4] = {c2.x, c2.y, c2.z, c2.w};
             const uint32_t r01 = pack_bf2(__builtin_fmaf(x2[0], bv[0], c2v[0]), __builtin_fmaf(x2[1], bv[1], c2v[1]));
             const uint32_t r23 = pack_bf2(__builtin_fmaf(x2[2], bv[2], c2v[2]), __builtin_fmaf(x2[3], bv[3], c2v[3]));
-            const float q[4] = {__uint_as_float(r01 << 16), __uint_as_float(r01 & 0xffff0000u), __uint_as_float(r23 << 16), __uint_as_float(r23 & 0xffff0000u)};
+            const float q[4] = {h16lo(r01), h16hi(r01), h16lo(r23), h16hi(r23)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = fmaxf(__builtin_fmaf(x[j], av[j], cv[j]) + q[j], lo);
         } else {

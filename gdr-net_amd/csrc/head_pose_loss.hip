@@ -75,8 +75,8 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float (
 }
 template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[0] = h16lo(t.x); v[1] = h16hi(t.x);
+    v[2] = h16lo(t.y); v[3] = h16hi(t.y);
 }
 
 template <typename T, bool LOSS>
@@ -646,7 +646,7 @@ extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2
                                   int N, int HW, int nreg, int dtype, void* stream) {
     const int dt = dtype & 0xff;
     if (!head || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0 || nreg < 1 || nreg > 64 || hs < nreg + 5 ||
-        pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
+        pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_H16))
         return GDRN_ERR_ARG;
     return launch_ht_fwd<false>(head, hs, coord2d, extents, pnp_in, pcs, nullptr, nullptr, nullptr, nullptr, nullptr, N, HW, nreg, dtype, ST);
 }
@@ -656,7 +656,7 @@ extern "C" int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* c
                                        double* acc, int N, int HW, int nreg, int dtype, void* stream) {
     const int dt = dtype & 0xff;
     if (!head || !coord2d || !extents || !pnp_in || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || N <= 0 || HW <= 0 ||
-        nreg < 1 || nreg > 64 || hs < nreg + 5 || pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
+        nreg < 1 || nreg > 64 || hs < nreg + 5 || pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_H16))
         return GDRN_ERR_ARG;
     if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     return launch_ht_fwd<true>(head, hs, coord2d, extents, pnp_in, pcs, gt_xyz, mask_visib, mask_trunc, gt_region, acc, N, HW, nreg, dtype, ST);
@@ -687,7 +687,7 @@ extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in,
                                   int HW, int nreg, int dtype, void* stream) {
     const int dt = dtype & 0xff, write_pad = (dtype & GDRN_PREZEROED) ? 0 : 1;
     if (!head || !extents || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || !gw || !d_head || N <= 0 ||
-        HW <= 0 || nreg < 1 || nreg > 64 || dcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_BF16))
+        HW <= 0 || nreg < 1 || nreg > 64 || dcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_H16))
         return GDRN_ERR_ARG;
     if (d_pnp_in != nullptr && pnp_in == nullptr) return GDRN_ERR_ARG;
     const long long M = (long long)N * HW;

@@ -293,7 +293,7 @@ extern "C" int gdrn_pack_chunk(void) { return PACK_CHUNK; }
 extern "C" int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

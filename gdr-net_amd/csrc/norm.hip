@@ -698,7 +698,7 @@ inline int ew_grid(long long n) { return (int)std::min<long long>((n + 255) / 25
 #define DISPATCH(dtype, CALL_F32, CALL_BF16)                \
     do {                                                    \
         if ((dtype) == GDRN_DT_F32) { CALL_F32; }           \
-        else if ((dtype) == GDRN_DT_BF16) { CALL_BF16; }    \
+        else if ((dtype) == GDRN_DT_H16) { CALL_BF16; }    \
         else return GDRN_ERR_ARG;                           \
     } while (0)
 
@@ -734,7 +734,7 @@ extern "C" int gdrn_bn_eval_params(const float* gamma, const float* beta, const 
 extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shift, const void* residual, void* y,
                              long long npix, int C, int relu, int dtype, void* stream) {
     if (!x || !scale || !shift || !y || npix <= 0 || C <= 0 || (C % 8)) return GDRN_ERR_ARG;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
     int rpb, blocks;
     ew_rows(npix, C / V, &rpb, &blocks);
@@ -749,7 +749,7 @@ extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shi
 
 // grid of the reduce pass: >= 4 rows per thread, at most 1024 workgroups (= partial rows)
 static void bwd_reduce_grid(long long npix, int C, int dtype, int* rpb_out, int* blocks_out) {
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     const int rpp = 256 / (C / V);
     int rpb = rpp * 4;  // >= 4 rows per thread, as many workgroups as that allows (small layers were latency-bound at 64)
     long long blocks = (npix + rpb - 1) / rpb;
@@ -760,7 +760,7 @@ static void bwd_reduce_grid(long long npix, int C, int dtype, int* rpb_out, int*
 
 extern "C" int gdrn_bn_bwd_reduce_rows(long long npix, int C, int dtype) {
     if (npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     if (256 % (C / V)) return GDRN_ERR_SHAPE;
     int rpb, blocks;
     bwd_reduce_grid(npix, C, dtype, &rpb, &blocks);
@@ -772,7 +772,7 @@ extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void*
                                   void* stream) {
     if (!dy || !x || !mean || !invstd || !rows || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
     if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     if (256 % (C / V)) return GDRN_ERR_SHAPE;
     int rpb, blocks;
     bwd_reduce_grid(npix, C, dtype, &rpb, &blocks);
@@ -790,7 +790,7 @@ extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* 
                                  int dtype, void* stream) {
     if (!dy || !x || !a || !b || !c || !dx || npix <= 0 || C <= 0 || C > 512 || (C % 8)) return GDRN_ERR_ARG;
     if ((mask_scale != nullptr) != (mask_shift != nullptr)) return GDRN_ERR_ARG;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     if ((C / V) > 256 || 256 % (C / V)) return GDRN_ERR_SHAPE;
     int rpb, blocks;
     ew_rows(npix, C / V, &rpb, &blocks);
@@ -822,7 +822,7 @@ extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const
 extern "C" int gdrn_maxpool_bwd_rows(int N, int H, int W, int C, int dtype) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return GDRN_ERR_ARG;
     const long long n = (long long)N * H * W * C;
-    return ew_grid(n / (dtype == GDRN_DT_BF16 ? 8 : 4));
+    return ew_grid(n / (dtype == GDRN_DT_H16 ? 8 : 4));
 }
 
 extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, const float* scale,
@@ -832,7 +832,7 @@ extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const 
     if (C > 512 || (long long)N * H * W * C / 4 >= (1ll << 31)) return GDRN_ERR_SHAPE;
     if (rows != nullptr) {
         if (!mean || !invstd) return GDRN_ERR_ARG;
-        const int cvn = C / (dtype == GDRN_DT_BF16 ? 8 : 4);
+        const int cvn = C / (dtype == GDRN_DT_H16 ? 8 : 4);
         if (cvn > 64 || 64 % cvn) return GDRN_ERR_SHAPE;  // a thread keeps one channel vector over its grid-stride iterations
     }
     const long long n = (long long)N * H * W * C;
@@ -879,7 +879,7 @@ extern "C" int gdrn_gn_relu_fwd(const void* x, const float* gamma, const float* 
     if (!x || !gamma || !beta || !y || !mean_rstd || N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 128 || C > 512 || (C % G) ||
         (C % 8))
         return GDRN_ERR_ARG;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     const int CS = gn_slab(C, G, V);
     if (256 % (CS / V)) return GDRN_ERR_SHAPE;
     DISPATCH(dtype,
@@ -896,7 +896,7 @@ extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, co
         return GDRN_ERR_ARG;
     const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
     dtype &= ~GDRN_PREZEROED;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     const int CS = gn_slab(C, G, V);
     if (256 % (CS / V)) return GDRN_ERR_SHAPE;
     if (!prezeroed) {
@@ -925,7 +925,7 @@ extern "C" int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db
     if (!dy || !db || rows <= 0 || C <= 0 || C > cs || cs > 1024 || (cs % 8)) return GDRN_ERR_ARG;
     const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
     dtype &= ~GDRN_PREZEROED;
-    const int V = dtype == GDRN_DT_BF16 ? 8 : 4;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
     if ((cs / V) > 256 || 256 % (cs / V)) return GDRN_ERR_SHAPE;
     if (!prezeroed && hipMemsetAsync(db, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     const int rpp = 256 / (cs / V);

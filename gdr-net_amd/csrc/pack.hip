@@ -152,6 +152,7 @@ inline int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<lo
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 extern "C" int gdrn_version(void) { return GDRN_ABI_VERSION; }
+extern "C" int gdrn_half_format(void) { return GDRN_DT_H16; }
 
 extern "C" int gdrn_device_info(int dev, char* name, int* cus, char* arch) {
     hipDeviceProp_t prop;
@@ -168,7 +169,7 @@ extern "C" int gdrn_pack4(const float* src, void* dst, int A1, int A2, int T, in
     const long long n = (long long)A1 * A2 * T * B;
     if (dtype == GDRN_DT_F32)
         hipLaunchKernelGGL(pack4_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
-    else if (dtype == GDRN_DT_BF16)
+    else if (dtype == GDRN_DT_H16)
         hipLaunchKernelGGL(pack4_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
     else
         return GDRN_ERR_ARG;
@@ -189,7 +190,7 @@ extern "C" int gdrn_pack_stem_w(const float* w, void* dst, int dtype, void* stre
     if (!w || !dst) return GDRN_ERR_ARG;
     const int n = 64 * 7 * 64;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_stem_w_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (float*)dst);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(pack_stem_w_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (bf16_t*)dst);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_stem_w_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (bf16_t*)dst);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -206,7 +207,7 @@ extern "C" int gdrn_pack_image(const float* img, void* dst, int N, int H, int W,
     if (!img || !dst || N <= 0 || Hp < H + 6 || Wp < W + 6) return GDRN_ERR_ARG;
     const long long n = (long long)N * Hp * Wp;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_image_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (float*)dst, N, H, W, Hp, Wp);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (bf16_t*)dst, N, H, W, Hp, Wp);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (bf16_t*)dst, N, H, W, Hp, Wp);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -215,7 +216,7 @@ extern "C" int gdrn_pack_image(const float* img, void* dst, int N, int H, int W,
 extern "C" int gdrn_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream) {
     if (!src || !dst || n <= 0) return GDRN_ERR_ARG;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, n);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, n);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, n);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -224,7 +225,7 @@ extern "C" int gdrn_cast_from_f32(const float* src, void* dst, long long n, int 
 extern "C" int gdrn_cast_to_f32(const void* src, float* dst, long long n, int dtype, void* stream) {
     if (!src || !dst || n <= 0) return GDRN_ERR_ARG;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, dst, n);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, dst, n);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, dst, n);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -234,7 +235,7 @@ extern "C" int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, flo
     if (!src || !dst || N <= 0 || HW <= 0 || C <= 0 || c0 < 0 || c0 + C > cs) return GDRN_ERR_ARG;
     const long long n = (long long)N * C * HW;
     if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, cs, c0, C, dst, N, HW);
-    else if (dtype == GDRN_DT_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, cs, c0, C, dst, N, HW);
+    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, cs, c0, C, dst, N, HW);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

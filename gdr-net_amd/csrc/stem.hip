@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[t][ky]), __builtin_bit_cast(bf16x8_t, xq[ky]),
-                                                                 acc[t], 0, 0, 0);
+                acc[t] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, wq[t][ky]), __builtin_bit_cast(bf16x8_t, xq[ky]),
+                                                                 acc[t]);
         // D[i = g*4 + j][col = r16 (pixel)] of fragment t = channel g*16 + t*4 + j: 16 consecutive channels of one pixel per lane, two
         // 16-byte stores (four 8-byte ones with the plain row order)
         const int seg = tile & 7, oy = (tile >> 3) & 127, n = tile >> 10;
@@ -187,18 +187,18 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const bf16_t* __rest
             // transpose-read map of conv_wgrad.hip: lane group g takes reduction rows {4g..4g+3} and {16+4g..} of the k-step
             const int trow = ks * 32 + g * 4 + (r16 >> 2), tcol = (r16 & 3) * 4;
             const unsigned char* qa = tA + trow * SW_PA + (wave * 16 + tcol) * 2;
-            const bf16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qa));
-            const bf16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qa + 16 * SW_PA));
+            const bf16x4_t alo = GDRN_TR16((lds_bf16x4_t*)(qa));
+            const bf16x4_t ahi = GDRN_TR16((lds_bf16x4_t*)(qa + 16 * SW_PA));
             const bf16x8_t fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     const unsigned char* qb = tX + ky * SW_SPAN + trow * 16 + (nf * 16 + tcol) * 2;
-                    const bf16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qb));
-                    const bf16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(qb + 16 * 16));
+                    const bf16x4_t blo = GDRN_TR16((lds_bf16x4_t*)(qb));
+                    const bf16x4_t bhi = GDRN_TR16((lds_bf16x4_t*)(qb + 16 * 16));
                     const bf16x8_t fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[ky][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[ky][nf], 0, 0, 0);
+                    acc[ky][nf] = GDRN_MFMA16(fa, fb, acc[ky][nf]);
                 }
             }
         }
@@ -272,7 +272,7 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
     if (a != nullptr && (!raw || !b || !c)) return GDRN_ERR_ARG;
     const bool prezeroed = (dtype & GDRN_PREZEROED) != 0;
     dtype &= ~GDRN_PREZEROED;
-    if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
     if ((long long)N * 128 * 128 * 64 >= (1ll << 40)) return GDRN_ERR_SHAPE;
     const int nstages = N * 256;
     const int per = cdiv(nstages, SW_PARTS);
@@ -289,7 +289,7 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
 
 extern "C" int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream) {
     if (!w || !dst) return GDRN_ERR_ARG;
-    if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
     hipLaunchKernelGGL(pack_stem_w32_kernel, dim3(cdiv(64 * 7 * 32, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
                        reinterpret_cast<bf16_t*>(dst));
     GDRN_CHECK_LAUNCH();
@@ -307,7 +307,7 @@ extern "C" int gdrn_stem_stats_rows(int N) {
 // stats (nullable): [gdrn_stem_stats_rows(N)][2][64] fp32 partial sums / sums of squares for gdrn_bn_finalize.
 extern "C" int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, int N, int dtype, void* stream) {
     if (!canvas || !w32 || !y || N <= 0) return GDRN_ERR_ARG;
-    if (dtype != GDRN_DT_BF16) return GDRN_ERR_SHAPE;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
     if ((long long)N * HP * WP * 8 >= (1ll << 40)) return GDRN_ERR_SHAPE;
     const int ntiles = N * 128 * 8;
     const int tpw = cdiv(ntiles, STEM_WAVES);

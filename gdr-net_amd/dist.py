@@ -125,8 +125,7 @@ def broadcast_parameters(model, src=0, group=None):
                 n = t.numel()
                 t.copy_(flat[off:off + n].view_as(t))
                 off += n
-    eng = getattr(model, "_eng", None)
-    if eng is not None:  # an engine already packed the pre-broadcast weights
+    for _, eng in getattr(model, "_engs", {}).values():  # engines that already packed the pre-broadcast weights
         eng.repack(force=True)
         eng.bn_epoch += 1
 

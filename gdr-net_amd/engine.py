@@ -19,7 +19,7 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import cabi
-from .cabi import BF16, F32, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
+from .cabi import BF16, F16, F32, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
 
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
@@ -45,12 +45,21 @@ class Engine:
     def __init__(self, params, buffers, dtype="bf16", num_regions=64, dry=False):
         """params / buffers: dict name -> tensor with the reference's state_dict names.
         dry: build-only engine on host tensors for inspecting the launch lists without a GPU (tests); it cannot run."""
-        self.lib = cabi.load()
+        # dtype: "bf16" | "fp16" | "fp32".  The 16-bit modes run the same kernels out of two builds of the library (cabi.load)
+        self.dt = {"bf16": BF16, BF16: BF16, "fp16": F16, "f16": F16, F16: F16}.get(dtype, F32)
+        if self.dt == F32 and dtype not in ("fp32", "f32", F32):
+            raise ValueError(f"HIP_DTYPE {dtype!r}: one of bf16, fp16, fp32")
+        self.h16 = self.dt != F32          # 16-bit storage / MFMA operands (throughput modes)
+        self.lib = cabi.load(self.dt)
         self.P = params
         self.Bf = buffers
-        self.dt = BF16 if dtype in ("bf16", BF16) else F32
-        self.tdt = torch.bfloat16 if self.dt == BF16 else torch.float32
-        self.esz = 2 if self.dt == BF16 else 4
+        self.tdt = {BF16: torch.bfloat16, F16: torch.float16, F32: torch.float32}[self.dt]
+        self.esz = 2 if self.h16 else 4
+        # fp16 carries the reference's GradScaler idea (main_gdrn.py:53-56) as a STATIC factor on dL/dloss: the data-gradient chain is stored
+        # in fp16 (6e-5 smallest normal), the fp32 parameter gradients come out multiplied by it and the optimizer's gradient read divides
+        # it out again (Ranger.step(grad_scale=)); 1 for bf16 / fp32
+        import os as _os0
+        self.loss_scale = float(_os0.environ.get("GDRN_LOSS_SCALE", "1024")) if self.dt == F16 else 1.0
         self.dev = next(iter(params.values())).device
         self.dry = bool(dry)
         if self.dev.type != "cuda" and not self.dry:
@@ -58,7 +67,7 @@ class Engine:
         self.nreg = num_regions
         import os as _os
 
-        self.use_halo = self.dt == BF16  # 3x3 stride-1 convs on the halo-tiled kernel (bf16); the fp32 parity mode keeps the generic one
+        self.use_halo = self.h16  # 3x3 stride-1 convs on the halo-tiled kernel (bf16); the fp32 parity mode keeps the generic one
         # bucket-end work (grouped weight gradients, their reduction, gradient unpack) on a 2nd stream: it runs under the next bucket's chain of
         # small-map data-gradient kernels (one workgroup per CU, matrix pipe ~20 % busy); same-box A/B: 8.05 -> 7.85 ms/step with the LDS request
         # below, 7.77 with the optimizer update of a bucket behind its reduction on that stream (GDRN.train_step, GDRN_EARLY_OPT)
@@ -66,16 +75,16 @@ class Engine:
         self.tail_overlap = _os.environ.get("GDRN_TAIL_OVERLAP", "1") == "1"  # last bucket's weight gradients under the stem's backward
         self.side_small = _os.environ.get("GDRN_SIDE_SMALL", "1") == "1"  # generic weight gradients / bias gradients on the side stream too
         self.wgrad_side_lds = int(_os.environ.get("GDRN_WGRAD_SIDE_LDS", str(84 * 1024)))  # LDS request of a side-stream weight-gradient launch
-        self.stem_direct = self.dt == BF16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
+        self.stem_direct = self.h16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
         self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
-        self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=torch.bfloat16, device=self.dev) if self.stem_direct else None
+        self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=self.tdt, device=self.dev) if self.stem_direct else None
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
         self.fuse_xf = self.use_halo and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
         # BatchNorm-backward mask + sums also in the generic kernel's epilogue (1x1 output conv, stride-2 / transposed data gradients)
-        self.gemm_bnb = dtype == "bf16" and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
+        self.gemm_bnb = self.h16 and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
@@ -221,7 +230,7 @@ class Engine:
         # operand layouts of the two halo operands: 1 = gdrn_pack_wfrag, 2 = gdrn_pack_wfrag32 (second-generation kernel); chosen by the
         # library per launch (gdrn_conv3x3_wfrag) when the first plan that uses the operand is built (Plan._conv)
         L.wfmt = {"f": 0, "d": 0}
-        if kind == "conv" and KK == 9 and not s2 and self.dt == BF16:  # halo-kernel operands (fragment-major)
+        if kind == "conv" and KK == 9 and not s2 and self.h16:  # halo-kernel operands (fragment-major)
             L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
         self.layers[key] = L
         return L
@@ -315,12 +324,12 @@ class Engine:
                     if dst is None or (halo_only and not frag):
                         continue
                     A1, A2, T, B, A1v, A2v, Bv, s1, s2, stt, sb, flip = self._pack_args(L, "f")
-                    kch = B * (2 if self.dt == BF16 else 4) // 128
+                    kch = B * (2 if self.h16 else 4) // 128
                     sh = (kch.bit_length() if (frag and kch > 0 and kch & (kch - 1) == 0) else 0)
                     t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), scale=f.scale.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v,
                                  A2v=A2v, Bv=Bv, flip=flip, s1=s1, s2=s2, st=stt, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
                     tasks.append(t)
-                    starts.append(starts[-1] + ((A1 // 16) * (B // 64) if (frag and self.dt == BF16) else (t.n + chunk - 1) // chunk))
+                    starts.append(starts[-1] + ((A1 // 16) * (B // 64) if (frag and self.h16) else (t.n + chunk - 1) // chunk))
             self._eval_tab = (to_device_table(tasks, self.dev), torch.tensor(starts, dtype=torch.int32, device=self.dev), len(tasks), starts[-1])
         for bnkey, f in self.bn_fold.items():
             g, b = self.P[bnkey + ".weight"], self.P[bnkey + ".bias"]
@@ -344,13 +353,13 @@ class Engine:
                 if dst is None or (halo_only and not frag):
                     continue
                 A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip = self._pack_args(L, which)
-                kch = B * (2 if self.dt == BF16 else 4) // 128  # 128-byte chunks per pixel row
+                kch = B * (2 if self.h16 else 4) // 128  # 128-byte chunks per pixel row
                 sh = (kch.bit_length() if (frag and kch > 0 and kch & (kch - 1) == 0) else 0)  # 1 + log2(kch)
                 t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
                              s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
                 tasks.append(t)
                 # workgroups of the task: bf16 fragment-major operands go brick by brick (16 rows x 64 b x 9 taps)
-                nblk = (A1 // 16) * (B // 64) if (frag and self.dt == BF16) else (t.n + chunk - 1) // chunk
+                nblk = (A1 // 16) * (B // 64) if (frag and self.h16) else (t.n + chunk - 1) // chunk
                 starts.append(starts[-1] + nblk)
         self._pack_tasks = to_device_table(tasks, self.dev)
         self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.dev)
@@ -577,7 +586,7 @@ class Plan:
             if baffine:
                 cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
         if xf is not None:
-            assert use_halo and e.dt == BF16, L.key
+            assert use_halo and e.h16, L.key
             assert xf["out"] is None or (xf["out"].shape == x.shape and xf["out"].dtype == x.dtype), L.key
             assert xf.get("x2") is None or xf["x2"].shape == x.shape, L.key
             cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
@@ -622,7 +631,7 @@ class Plan:
             if L.kind == "convT":
                 sp = 8 * 8  # Hin*Win*Cin*Cout*k^2
             macs = self.B * sp * L.O * L.I * L.KK
-        dn = "bf16" if e.dt == BF16 else "f32"
+        dn = "bf16" if e.h16 else "f32"   # (the 16-bit instantiation: its name in a trace is the same in both library builds)
         if use_halo and cp.w_frag == 2:
             kname = f"conv3x3_v3_kernel<{th.value},{hbn.value},{'2,4,1' if hbn.value == 256 else '2,2,2'},{cp.xf_mode}>"  # (the template's name in a trace)
         elif use_halo:
@@ -630,7 +639,7 @@ class Plan:
         else:
             kname = f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
         # algorithmic bytes (SURVEY 8(d) convention: activations in + out once, weights once, at the storage width)
-        esz = 2 if e.dt != F32 else 4
+        esz = 2 if e.h16 else 4
         nbytes = (self.B * Hi * Wi * cp.Cin + self.B * Ho * Wo * cp.Cout) * esz + cp.Cout * cp.Cin * cp.KH * cp.KW * esz
         run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(nbytes), layer=L.key + (":dgrad" if w is not None else ""))
         return run, cp
@@ -673,8 +682,8 @@ class Plan:
         else:
             macs = self.B * Ho * Wo * L.O * L.I * L.KK
         bco, bci = (64 if cout <= 64 else 128), (128 if cin % 128 == 0 else 64)
-        kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.dt == BF16 else 'f32'},{bco},{bci}>"
-        esz = 2 if e.dt != F32 else 4
+        kname = "conv3x3_wgrad_kernel" if use_halo else f"conv_wgrad_kernel<{'bf16' if e.h16 else 'f32'},{bco},{bci}>"
+        esz = 2 if e.h16 else 4
         run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(self.B * (Hi * Wi * cin + Ho * Wo * cout) * esz + 4 * cout * cin * wp.KH * wp.KW),
                         layer=L.key + ":wgrad")
         run.side = e.side_small  # feeds only the optimizer: off the data-gradient chain (side stream, see run_backward)
@@ -1356,7 +1365,7 @@ class Plan:
         self.fc_out = E(B, 64, dtype=F32t)
         self.tensors.update({"pnp_net.fc1.act": f1, "pnp_net.fc2.act": f2, "fc_out": self.fc_out})
         b1, b2 = e.P["pnp_net.fc1.bias"], e.P["pnp_net.fc2.bias"]
-        if e.dt == BF16 and B <= 64 and e.fc_splitk:
+        if e.h16 and B <= 64 and e.fc_splitk:
             # fc1 is bound by reading its 16.8 MB of weights once: split-K skinny GEMM instead of 8 gather workgroups.
             # L1.wf = [1024 rows][64 taps][128 ch] = row-major [N][K] in the (pixel, channel) order of the NHWC input
             ws1 = e._zeros(16 * B * 1024 + 64, dtype=F32t)  # GDRN_LINEAR_MAX_SPLITS slabs + tickets

@@ -22,6 +22,22 @@ def _bump_version(t):
         t.add_(0)
 
 
+def _global_pre_hooks():
+    try:
+        from torch.optim.optimizer import _global_optimizer_pre_hooks
+        return _global_optimizer_pre_hooks.values()
+    except ImportError:   # private name: absent -> no global hooks to fire
+        return ()
+
+
+def _global_post_hooks():
+    try:
+        from torch.optim.optimizer import _global_optimizer_post_hooks
+        return _global_optimizer_post_hooks.values()
+    except ImportError:
+        return ()
+
+
 def radam_step_size(step, beta1, beta2, n_sma_threshold):
     """(N_sma, step_size) of ranger.py:160-186."""
     beta2_t = beta2 ** step
@@ -120,10 +136,12 @@ class Ranger(Optimizer):
         lib = cabi.load()
         self._bucket_launches = [[] for _ in range(nbuckets)]
         self._bucket_params = []
+        self._bucket_states = []   # their step counters advance in step_buckets_end: an exception inside the backward pass leaves them alone
+        for hook in list(_global_pre_hooks()) + list(getattr(self, "_optimizer_step_pre_hooks", {}).values()):
+            hook(self, (), {})     # the hooks torch fires around optimizer.step()
         for gi, group, items, states in plan:
-            for s in states:
-                s["step"] += 1
-            step = states[0]["step"]
+            self._bucket_states += states
+            step = states[0]["step"] + 1
             beta1, beta2 = group["betas"]
             n_sma, step_size = radam_step_size(step, beta1, beta2, self.N_sma_threshhold)
             by_b = {}
@@ -145,9 +163,21 @@ class Ranger(Optimizer):
                                                           self.alpha, gs, st), "ranger_multi")
 
     def step_buckets_end(self):
+        """every bucket's update is enqueued: commit the step counters, tell torch an optimizer step happened (LR schedulers check
+        ``_opt_called``; step post-hooks fire as for ``step()``)"""
+        for s in self._bucket_states:
+            s["step"] += 1
         for p in self._bucket_params:
             _bump_version(p)  # updated in place behind autograd's back: tell repack() the weights changed
-        self._bucket_launches, self._bucket_params = [], []
+        self._bucket_launches, self._bucket_params, self._bucket_states = [], [], []
+        self._opt_called = True
+        for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
+            hook(self, (), {})
+
+    def step_buckets_abort(self):
+        """the backward pass raised before every bucket went out: forget the prepared launches, the step counters never moved.  (Updates
+        already enqueued for earlier buckets stay applied -- the caller's exception says the step is incomplete.)"""
+        self._bucket_launches, self._bucket_params, self._bucket_states = [], [], []
 
     @torch.no_grad()
     def step(self, closure=None, grads=None, grad_scale=1.0):

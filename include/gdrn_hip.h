@@ -13,8 +13,8 @@
  *   - every call enqueues asynchronously on `stream` (a hipStream_t passed as void*; 0 = null stream)
  *     and returns an int status: 0 ok, <0 error (GDRN_ERR_*); nothing throws across the boundary;
  *   - activations are NHWC with an explicit pixel stride (`*_cs`, in elements); `dtype` selects the
- *     storage/operand type: GDRN_DT_F32 (fp32 MFMA, parity mode) or GDRN_DT_BF16 (bf16 MFMA, fp32
- *     accumulate, throughput mode).  Statistics, losses, pose and parameter gradients are fp32.
+ *     storage/operand type: GDRN_DT_F32 (fp32 MFMA, parity mode), GDRN_DT_BF16 or GDRN_DT_F16 (16-bit MFMA operands,
+ *     fp32 accumulate, throughput mode; which of the two: the library build).  Statistics, losses, pose and parameter gradients are fp32.
  *   - re-entrant and thread-compatible: one host thread per stream.
  */
 #ifndef GDRN_HIP_H
@@ -29,8 +29,11 @@ extern "C" {
 /* 2: status / dtype enums renamed (GDRN_E_* -> GDRN_ERR_*, GDRN_F32 / GDRN_BF16 -> GDRN_DT_*; the old names stay as deprecated aliases),
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
 #define GDRN_ABI_VERSION 2
-/* `dtype` arguments */
-enum { GDRN_DT_F32 = 0, GDRN_DT_BF16 = 1 };
+/* `dtype` arguments.  The 16-bit format is a property of the library build: libgdrn_hip.so computes GDRN_DT_BF16, libgdrn_hip_f16.so (the same
+ * sources compiled with -DGDRN_HALF_F16: v_mfma_f32_*_f16, IEEE-half storage -- the arithmetic of the reference's fp16 autocast,
+ * core/gdrn_modeling/main_gdrn.py:53-56,141, gdrn_evaluator.py:568) computes GDRN_DT_F16; each rejects the other's code with GDRN_ERR_ARG,
+ * both compute GDRN_DT_F32.  gdrn_half_format() tells a host which one it opened. */
+enum { GDRN_DT_F32 = 0, GDRN_DT_BF16 = 1, GDRN_DT_F16 = 2 };
 /* status codes (0 = GDRN_OK) */
 enum { GDRN_OK = 0, GDRN_ERR_ARG = -1, GDRN_ERR_SHAPE = -2, GDRN_ERR_LAUNCH = -3 };
 /* deprecated aliases of ABI version 1 */
@@ -39,6 +42,7 @@ enum { GDRN_F32 = GDRN_DT_F32, GDRN_BF16 = GDRN_DT_BF16, GDRN_E_ARG = GDRN_ERR_A
 enum { GDRN_WGRAD_T64 = 0, GDRN_WGRAD_W128 = 1 };
 
 int gdrn_version(void);
+int gdrn_half_format(void);   /* GDRN_DT_BF16 or GDRN_DT_F16: the 16-bit dtype code this library build accepts */
 /* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
  * memory, no initialisation needed unless stated): `op` selects the buffer, `params` points at the arguments that determine its
  * size.  < 0: GDRN_ERR_*.  (the Python engine sizes its plan buffers with the same rules.) */

@@ -25,9 +25,12 @@ import torch.nn.functional as F
 from . import gdrn_oracle as O
 
 
+_STORAGE = [torch.bfloat16]   # the 16-bit storage format being emulated: bf16 (libgdrn_hip.so) or fp16 (libgdrn_hip_f16.so)
+
+
 def r(x):
-    """value after a round trip through bf16 storage (round-to-nearest-even, as v_cvt_pk_bf16_f32)."""
-    return x.to(torch.bfloat16).to(torch.float32)
+    """value after a round trip through the 16-bit storage format (round-to-nearest-even, as v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)."""
+    return x.to(_STORAGE[0]).to(torch.float32)
 
 
 def _fma(x, a, c):
@@ -51,8 +54,18 @@ def _conv(x, sd, name, stride, pad):
     return F.conv2d(x, r(sd[name].float()), None, stride, pad)
 
 
-def forward_train(sd, batch, sym=False):
-    """gdrn_oracle.gdrn_forward(do_loss=True, training=True) with bf16 storage; returns the same dict (maps fp32 [B,69,64,64])."""
+def forward_train(sd, batch, sym=False, storage=torch.bfloat16):
+    """gdrn_oracle.gdrn_forward(do_loss=True, training=True) with 16-bit storage (bf16, or torch.float16 for the fp16 library build); returns
+    the same dict (maps fp32 [B,69,64,64])."""
+    old = _STORAGE[0]
+    _STORAGE[0] = storage
+    try:
+        return _forward_train(sd, batch, sym)
+    finally:
+        _STORAGE[0] = old
+
+
+def _forward_train(sd, batch, sym=False):
     p = "backbone."
     acc = _conv(r(batch["roi_img"].float()), sd, p + "conv1.weight", 2, 3)
     sc, sh = _bn_train(acc, sd, p + "bn1")

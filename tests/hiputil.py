@@ -5,13 +5,13 @@ import numpy as np
 import torch
 
 from gdrnet_amd import cabi
-from gdrnet_amd.cabi import BF16, F32, ConvParams, WgradParams, check, ptr
+from gdrnet_amd.cabi import BF16, F16, F32, ConvParams, WgradParams, check, ptr
 
 DEV = "cuda:0"
 
 
 def tdt(dt):
-    return torch.bfloat16 if dt == BF16 else torch.float32
+    return {BF16: torch.bfloat16, F16: torch.float16}.get(dt, torch.float32)
 
 
 def stream():
@@ -49,7 +49,7 @@ def rounded(x, dt):
 
 
 def pack(w_src, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip, dt):
-    lib = cabi.load()
+    lib = cabi.load(dt)
     dst = torch.zeros(A1, A2, T, B, dtype=tdt(dt), device=DEV)
     w = w_src.to(DEV).float().contiguous()
     check(lib.gdrn_pack4(ptr(w), ptr(dst), A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip, dt, stream()), "pack4")
@@ -84,13 +84,13 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging.
     v3 (with halo): the second-generation kernel (operand of gdrn_pack_wfrag32, w_frag = 2).
     reps > 0: also time `reps` back-to-back launches with HIP events; the average (ms) is returned as a third value."""
-    lib = cabi.load()
+    lib = cabi.load(dt)
     if halo:  # the halo kernels take a fragment-major permutation of the same operand
         wf = torch.empty_like(w)
         check((lib.gdrn_pack_wfrag32 if v3 else lib.gdrn_pack_wfrag)(ptr(w), ptr(wf), w.shape[0], Cin, dt, stream()), "pack_wfrag")
         w = wf
     y_cs = y_cs or ru(Cout, 4)
-    ydt = torch.float32 if (out_f32 or dt == F32) else torch.bfloat16
+    ydt = torch.float32 if (out_f32 or dt == F32) else tdt(dt)
     y = torch.full((B, Ho, Wo, y_cs), float("nan"), dtype=ydt, device=DEV)
     cp = ConvParams()
     cp.x, cp.w, cp.y = ptr(x), ptr(w), ptr(y)
@@ -138,7 +138,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
 
 def conv_wgrad(x, dy, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, dy_cs, KH, KW, stride, pad, dt, variant=0, splits=0, halo=False, ws=False):
     """ws: halo kernel with workspace partials + gdrn_wgrad_reduce_multi; returns the OIHW gradient in that case."""
-    lib = cabi.load()
+    lib = cabi.load(dt)
     dw = torch.zeros(Cout, KH * KW, Cin, dtype=torch.float32, device=DEV)
     wp = WgradParams()
     wp.x, wp.dy, wp.dw = ptr(x), ptr(dy), ptr(dw)

@@ -220,3 +220,17 @@ def test_pretrained_backbone_is_resolved_from_the_hub_cache_or_refused(tmp_path,
     cfg2.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
     m, _ = GDRN.build_model_optimizer(cfg2)
     assert float(m.backbone.layer1[0].conv1.weight.mean()) == 0.25
+
+
+def test_fp16_library_build_exports_the_same_abi():
+    """libgdrn_hip_f16.so = the same sources with IEEE half as the 16-bit format (csrc/common.h): same entry points, it reports GDRN_DT_F16
+    as its 16-bit dtype code and the loader refuses a library of the wrong kind."""
+    if not os.path.exists(cabi.LIB_PATH_F16):
+        from gdrnet_amd import build
+
+        build.build(verbose=False)
+    lib = cabi.load(cabi.F16)
+    for name in _header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.gdrn_half_format() == cabi.F16 == 2 and cabi.load(cabi.BF16).gdrn_half_format() == cabi.BF16 == 1
+    assert lib is not cabi.load(cabi.BF16) and cabi.load(cabi.F32) is cabi.load(cabi.BF16)

@@ -1,7 +1,10 @@
 """Kernel-level parity tests (-m gpu): every HIP kernel, called through the C-ABI, against the same op
 evaluated with plain PyTorch on the CPU (fp32).  fp32 kernels: tolerance 2e-5 relative L2 (different
-summation order only).  bf16 kernels: inputs are rounded to bf16 first so the reference sees the same
-operands; tolerance 6e-3 (bf16 output rounding is 2^-9 ~ 2e-3 relative per element)."""
+summation order only).  16-bit kernels: inputs are rounded to the storage format first so the reference sees the same
+operands; tolerance 6e-3 for bf16 (output rounding is 2^-9 ~ 2e-3 relative per element), 8e-4 for fp16 (2^-12).
+
+The 16-bit format is a property of the library build (csrc/common.h): this module tests libgdrn_hip.so (bf16);
+tests/test_kernels_fp16_gpu.py executes the same source a second time with `BF16` bound to the fp16 code and libgdrn_hip_f16.so."""
 import ctypes as C
 import math
 
@@ -11,12 +14,15 @@ import torch
 import torch.nn.functional as F
 
 from gdrnet_amd import cabi
-from gdrnet_amd.cabi import BF16, F32, check, ptr
+from gdrnet_amd.cabi import F32, check, ptr
 
 pytestmark = pytest.mark.gpu
 
-DTS = [F32, BF16]
-TOL = {F32: 2e-5, BF16: 6e-3}
+BF16 = globals().get("__HALF__", cabi.BF16)       # the 16-bit dtype code under test ("BF16" reads "the build's half" below)
+IS_F16 = BF16 == cabi.F16
+HT = torch.float16 if IS_F16 else torch.bfloat16   # its torch dtype
+DTS = [BF16] if IS_F16 else [F32, BF16]            # (the fp32 kernels are tested once, out of the bf16 library)
+TOL = {F32: 2e-5, BF16: 8e-4 if IS_F16 else 6e-3}
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +31,7 @@ def H():
         pytest.skip("needs an MI355X")
     import hiputil
 
-    cabi.load()
+    cabi.load(BF16)
     return hiputil
 
 
@@ -121,7 +127,7 @@ def test_conv_epilogue_bias_act_addend_f32out(H, dt):
 @pytest.mark.parametrize("dt", DTS)
 def test_stem_conv(H, dt):
     """7x7 s2 p3 conv on a zero-padded NHWC4 image as a 7x1-tap gather of 16 px * 4 ch (resnet_backbone.py:23)."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B = 2
     img = H.rounded(torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(7)), dt)
     w = H.rounded(H.randn(8, 64, 3, 7, 7) / 12, dt)
@@ -237,7 +243,7 @@ def test_conv3x3_wgrad_halo(H, case, splits, variant):
         wp = cabi.WgradParams()
         wp.Hi = wp.Wi = wp.Ho = wp.Wo = Hh
         wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.variant = I, O, I, O, 3, 3, 1, 1, B * Hh * Hh, dt, W128
-        assert cabi.load().gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0   # the wide tile needs Cout % 128 == 0
+        assert cabi.load(BF16).gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0   # the wide tile needs Cout % 128 == 0
         return
     x = H.rounded(H.randn(43, B, I, Hh, Hh), dt)
     w = H.randn(44, O, I, 3, 3).requires_grad_(True)
@@ -284,7 +290,7 @@ def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws, variant):
         wp.Hi = wp.Wi = Hi
         wp.Ho = wp.Wo = Ho
         wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype = I, O, I, O, 3, 3, 2, 1, B * Ho * Ho, dt
-        assert cabi.load().gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0
+        assert cabi.load(BF16).gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0
         return
     if variant == W128 and O % 128:
         pytest.skip("wide tile: Cout % 128 == 0")
@@ -301,7 +307,7 @@ def test_conv3x3_wgrad_halo_conv_transpose_and_padded_channels(H):
     (b) Patch-PnP's first conv: 69 real input channels in a 128-channel operand -- the reduce skips the padded channels."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
 
-    lib, dev, dt = cabi.load(), H.DEV, BF16
+    lib, dev, dt = cabi.load(BF16), H.DEV, BF16
     # (a)
     B, Ci, Co, Hin = 2, 128, 64, 8
     xin = H.rounded(H.randn(150, B, Ci, Hin, Hin), dt)
@@ -470,7 +476,7 @@ def test_conv3x3_halo_operand_transform(H, case, mode, v3):
     vb = H.rounded(v, dt)
     ref = F.conv2d(vb, w, None, 1, 1)
     d = lambda t: t.to(dev).float().contiguous()
-    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
+    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=HT, device=dev)
     xf = dict(mode=mode, relu=relu, a=d(a), c=d(c), out=out)
     if mode == 2:
         xf["c2"] = d(c2)
@@ -514,7 +520,7 @@ def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H, v3):
     gg = (F.conv2d(v, w, None, 1, 1) + add) * (ystored > 0)
     xhat = (bx - V(mean)) * V(invstd)
     d = lambda t: t.to(dev).float().contiguous()
-    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=torch.bfloat16, device=dev)
+    out = torch.full((B, Hh, Hh, I), float("nan"), dtype=HT, device=dev)
     y, sums = H.conv_gemm(H.nhwc(g, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, addend=H.nhwc(add, dt), halo=True,
                           bnb=dict(x=H.nhwc(bx, dt), mask=H.nhwc(ystored, dt), mean=d(mean), invstd=d(invstd)),
                           xf=dict(mode=3, relu=False, x2=H.nhwc(raw, dt), a=d(ka), b=d(kb), c=d(kc), out=out), v3=v3)
@@ -527,7 +533,7 @@ def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H, v3):
 @pytest.mark.parametrize("nrows,C_", [(16, 64), (128, 256), (2048, 256), (37, 512)])
 def test_bn_bwd_coef(H, nrows, C_):
     """rows of BatchNorm-backward sums -> (a, b, c) of dx = a*g + b*x + c, dgamma, dbeta (gdrn_bn_bwd_apply's coefficients)."""
-    lib, dev = cabi.load(), H.DEV
+    lib, dev = cabi.load(BF16), H.DEV
     rows = H.randn(60, nrows, 2, C_)
     gamma, mean = torch.rand(C_) + 0.5, H.randn(61, C_) * 0.3
     invstd = torch.rand(C_, generator=torch.Generator().manual_seed(62)) + 0.5
@@ -552,7 +558,7 @@ def test_conv3x3_wgrad_grouped(H, variant, grid):
     fewer resident workgroups than logical ones (a resident workgroup walks several tiles; 21 is rounded down to 16)."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
 
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dt, dev = BF16, H.DEV
     cases = [(2, 64, 64, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1)]  # B, I, O, H, requested splits
     if variant == W128:
@@ -599,7 +605,7 @@ def test_conv3x3_wgrad_grouped(H, variant, grid):
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])
 def test_batchnorm_train_fwd_bwd(H, dt, C_):
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, Hh = 3, 12
     x = H.rounded(H.randn(50, B, C_, Hh, Hh) * 2 + 0.5, dt).requires_grad_(True)
     res = H.rounded(H.randn(51, B, C_, Hh, Hh), dt)
@@ -653,7 +659,7 @@ def test_batchnorm_train_fwd_bwd(H, dt, C_):
 @pytest.mark.parametrize("C_,B,Hh", [(64, 3, 12), (512, 2, 8), (256, 5, 16)])
 def test_batchnorm_bwd_affine_mask(H, dt, C_, B, Hh):
     """BN -> ReLU (no residual) backward with the ReLU mask recomputed from x*scale+shift == autograd."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev = H.DEV
     x = H.rounded(H.randn(150, B, C_, Hh, Hh) * 2 + 0.5, dt).requires_grad_(True)
     gam = (0.5 + torch.rand(C_, generator=torch.Generator().manual_seed(1))).requires_grad_(True)
@@ -689,7 +695,7 @@ def test_batchnorm_bwd_affine_mask(H, dt, C_, B, Hh):
 
 @pytest.mark.parametrize("dt", DTS)
 def test_bn_relu_maxpool(H, dt):
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, C_, Hh = 2, 64, 24
     x = H.rounded(H.randn(60, B, C_, Hh, Hh), dt).requires_grad_(True)
     scale, shift = 0.5 + torch.rand(C_), torch.rand(C_) - 0.5
@@ -721,7 +727,7 @@ def test_bn_relu_maxpool(H, dt):
 
 @pytest.mark.parametrize("dt", DTS)
 def test_upsample2x(H, dt):
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, C_, Hh = 2, 256, 16
     x = H.rounded(H.randn(70, B, C_, Hh, Hh), dt).requires_grad_(True)
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
@@ -739,7 +745,7 @@ def test_upsample2x(H, dt):
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Hh", [32, 8])
 def test_groupnorm_relu(H, dt, Hh):
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, C_ = 3, 128
     x = H.rounded(H.randn(80, B, C_, Hh, Hh) * 1.5 + 0.3, dt).requires_grad_(True)
     gam = (0.5 + torch.rand(C_)).requires_grad_(True)
@@ -765,7 +771,7 @@ def test_groupnorm_relu(H, dt, Hh):
 
 @pytest.mark.parametrize("dt", DTS)
 def test_leaky_and_bias_grad(H, dt):
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, C_ = 4, 1024
     y = H.rounded(H.randn(90, B, C_), dt)
     dy = H.rounded(H.randn(91, B, C_), dt)
@@ -792,7 +798,7 @@ def test_head_tail_and_map_losses(H, dt):
     from gdrnet_amd import synth
     from oracle import gdrn_oracle as O
 
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     B, HW, nreg, hs = 2, 4096, 64, 72
     M = B * HW
     b = synth.make_batch(B, seed=9)
@@ -856,7 +862,7 @@ def test_head_tail_generic_region_count(H):
     path gives when the 32 surplus classes carry -inf-like logits and are never the target."""
     from gdrnet_amd import synth
 
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dt = F32
     B, HW, hs = 1, 4096, 72
     M = B * HW
@@ -894,7 +900,7 @@ def test_head_tail_generic_region_count(H):
 @pytest.mark.parametrize("rows,C_", [(1000, 64), (4096, 64), (513, 256), (130, 512), (64, 128)])
 def test_bn_finalize_workspace(H, rows, C_):
     """two-launch finalize for many partial rows (fold to <= 64 rows, then finalise) == fp64 numpy, also on the second call."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev = H.DEV
     rng = np.random.default_rng(rows + C_)
     part = rng.normal(size=(rows, 2, C_)).astype(np.float32)
@@ -922,17 +928,17 @@ def test_bn_finalize_workspace(H, rows, C_):
 @pytest.mark.parametrize("M,K,N,act", [(64, 8192, 1024, 2), (4, 8192, 1024, 2), (37, 1024, 256, 0), (16, 128, 16, 1)])
 def test_linear_splitk(H, M, K, N, act):
     """split-K skinny linear (Patch-PnP fc1) == F.linear + bias + activation; workspace needs no initialisation (called twice)."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev = H.DEV
     x = H.rounded(H.randn(200, M, K), BF16)
     w = H.rounded(H.randn(201, N, K) / math.sqrt(K), BF16)
     b = H.randn(202, N) * 0.1
     ref = F.linear(x, w, b)
     ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.1) if act == 2 else ref)
-    xd, wd, bd = x.to(dev).to(torch.bfloat16), w.to(dev).to(torch.bfloat16), b.to(dev)
+    xd, wd, bd = x.to(dev).to(HT), w.to(dev).to(HT), b.to(dev)
     ws = torch.full((16 * M * N,), float("nan"), dtype=torch.float32, device=dev)  # GDRN_LINEAR_MAX_SPLITS slabs, uninitialised
     for _ in range(2):
-        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        y = torch.full((M, N), float("nan"), dtype=HT, device=dev)
         check(lib.gdrn_linear_splitk(ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, K, K, N, act, ptr(ws), BF16, H.stream()), "linear_splitk")
         torch.cuda.synchronize()
         assert H.rel(y.float().cpu(), ref) < TOL[BF16]
@@ -944,7 +950,7 @@ def test_pack_multi_fragment_major(H, O, I):
     data-gradient operand of a 3x3 conv, both in ONE launch."""
     from gdrnet_amd.cabi import PackTask, to_device_table
 
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev, dt = H.DEV, BF16
     w = H.randn(300, O, I, 3, 3).to(dev).contiguous()
     ru64 = lambda v: (v + 63) // 64 * 64
@@ -955,7 +961,7 @@ def test_pack_multi_fragment_major(H, O, I):
         rowmajor = H.pack(w, A1, 1, 9, B, A1v, 1, Bv, s1, 0, 1, sb, flip, dt)
         ref = torch.empty_like(rowmajor)
         check(lib.gdrn_pack_wfrag(ptr(rowmajor), ptr(ref), A1, B, dt, H.stream()), "pack_wfrag")
-        dst = torch.full((A1 * 9 * B,), float("nan"), dtype=torch.bfloat16, device=dev)
+        dst = torch.full((A1 * 9 * B,), float("nan"), dtype=HT, device=dev)
         kch = B // 64
         tasks.append(PackTask(src=ptr(w), dst=ptr(dst), A1=A1, A2=1, T=9, B=B, A1v=A1v, A2v=1, Bv=Bv, flip=flip, s1=s1, s2=0, st=1, sb=sb,
                               n=A1 * 9 * B, frag=1, pad_=kch.bit_length() if kch & (kch - 1) == 0 else 0))
@@ -974,20 +980,20 @@ def test_pack_multi_fragment_major(H, O, I):
 def test_stem_conv_direct(H, B):
     """dedicated stem kernel (one kernel row per MFMA k-step, fragments straight from the NHWC4 canvas) == F.conv2d
     7x7 s2 p3, and its per-wave partial statistics sum to the tensor's sum / sum of squares."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev, dt = H.DEV, BF16
     img = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(7))
     w = H.rounded(H.randn(400, 64, 3, 7, 7) / math.sqrt(147), dt)
     ref = F.conv2d(H.rounded(img, dt), w, None, 2, 3)
-    canvas = torch.zeros(B, 262, 272, 4, dtype=torch.bfloat16, device=dev)
+    canvas = torch.zeros(B, 262, 272, 4, dtype=HT, device=dev)
     imgd = img.to(dev).contiguous()
     check(lib.gdrn_pack_image(ptr(imgd), ptr(canvas), B, 256, 256, 262, 272, dt, H.stream()), "pack_image")
-    w32 = torch.empty(64 * 7 * 32, dtype=torch.bfloat16, device=dev)
+    w32 = torch.empty(64 * 7 * 32, dtype=HT, device=dev)
     wd = w.to(dev).contiguous()
     check(lib.gdrn_pack_stem_w32(ptr(wd), ptr(w32), dt, H.stream()), "pack_stem_w32")
     rows = lib.gdrn_stem_stats_rows(B)
     stats = torch.full((rows, 2, 64), float("nan"), dtype=torch.float32, device=dev)
-    y = torch.full((B, 128, 128, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    y = torch.full((B, 128, 128, 64), float("nan"), dtype=HT, device=dev)
     check(lib.gdrn_stem_conv(ptr(canvas), ptr(w32), ptr(y), ptr(stats), B, dt, H.stream()), "stem_conv")
     torch.cuda.synchronize()
     assert H.rel(H.nchw(y), ref) < TOL[dt]
@@ -999,13 +1005,13 @@ def test_stem_conv_direct(H, B):
 def test_stem_wgrad_fused_bn_backward(H, B, fused):
     """dedicated stem weight gradient == autograd's conv weight gradient, with dy either given (fused=False) or evaluated on the
     fly as the BatchNorm-backward apply dy = a*g + (b*raw + c) (bn_bwd_apply's formula, bf16-rounded), incl. dgamma / dbeta."""
-    lib = cabi.load()
+    lib = cabi.load(BF16)
     dev, dt = H.DEV, BF16
     gen = torch.Generator().manual_seed(11 + B)
     img = torch.rand(B, 3, 256, 256, generator=gen)
     g = H.rounded(torch.randn(B, 64, 128, 128, generator=gen) * 0.1, dt)
     raw = H.rounded(torch.randn(B, 64, 128, 128, generator=gen), dt)
-    canvas = torch.zeros(B, 262, 272, 4, dtype=torch.bfloat16, device=dev)
+    canvas = torch.zeros(B, 262, 272, 4, dtype=HT, device=dev)
     imgd = img.to(dev).contiguous()
     check(lib.gdrn_pack_image(ptr(imgd), ptr(canvas), B, 256, 256, 262, 272, dt, H.stream()), "pack_image")
     gd, rawd = H.nhwc(g, dt), H.nhwc(raw, dt)

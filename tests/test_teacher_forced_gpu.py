@@ -35,8 +35,11 @@ RESNET34_LAYERS = (3, 4, 6, 3)
 HEAD_CONVS = ((3, 4, False), (6, 7, False), (10, 11, True), (13, 14, False), (17, 18, True), (20, 21, False))
 
 
+_ST = [torch.bfloat16]   # the 16-bit storage format of the case: bf16, or fp16 for the fp16 library build (HIP_DTYPE="fp16")
+
+
 def r(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(_ST[0]).to(torch.float32)
 
 
 def rel(a, b):
@@ -72,20 +75,29 @@ def bn_bwd(g, x, gamma, mean, inv):
 
 # (batch size, environment): the BASELINE size with the default plan; the plan variants (separate BatchNorm passes, no BatchNorm-backward
 # epilogue in the generic kernel, first / second generation halo kernel everywhere it applies) at a size the CPU reference finishes quickly
-CASES = [(64, {}), (8, {"GDRN_GEMM_BNB": "0"}), (8, {"GDRN_FUSE_XF": "0"}), (8, {"GDRN_V3": "2", "GDRN_V3_MINWG": "1"}), (8, {"GDRN_V3": "0"})]
+# ... and the fp16 arithmetic mode (the same kernels built with IEEE half, csrc/common.h): the 16-bit tensors are rounded in 2^-12 instead of
+# 2^-9 steps, so the bounds of everything that carries a 16-bit rounding are 8x tighter; the data-gradient chain runs under the engine's
+# static loss scale (every check is relative and from the engine's own stage inputs: the scale drops out unless something underflows)
+CASES = [(64, {}, "bf16"), (8, {"GDRN_GEMM_BNB": "0"}, "bf16"), (8, {"GDRN_FUSE_XF": "0"}, "bf16"), (8, {"GDRN_V3": "2", "GDRN_V3_MINWG": "1"}, "bf16"),
+         (8, {"GDRN_V3": "0"}, "bf16"), (64, {}, "fp16"), (8, {"GDRN_V3": "2", "GDRN_V3_MINWG": "1"}, "fp16")]
+TOLS = {"bf16": (1e-3, 7e-3), "fp16": (1.25e-4, 9e-4)}   # (16-bit tensors, dgamma / dbeta)
 
 
-@pytest.mark.parametrize("B,env", CASES, ids=["bs64-default", "bs8-no-gemm-bnb", "bs8-unfused-bn", "bs8-v3-everywhere", "bs8-no-v3"])
-def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, monkeypatch):
+@pytest.mark.parametrize("B,env,dtype", CASES, ids=["bs64-default", "bs8-no-gemm-bnb", "bs8-unfused-bn", "bs8-v3-everywhere", "bs8-no-v3",
+                                                    "bs64-fp16", "bs8-fp16-v3-everywhere"])
+def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, dtype, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     from gdrnet_amd import GDRN as G
 
+    global TOL_BF16, TOL_SUM
+    TOL_BF16, TOL_SUM = TOLS[dtype]
+    monkeypatch.setitem(_ST, 0, torch.float16 if dtype == "fp16" else torch.bfloat16)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     cfg = lm13_cfg(device=DEV)
-    cfg.MODEL.CDPN.HIP_DTYPE = "bf16"
+    cfg.MODEL.CDPN.HIP_DTYPE = dtype
     model, _ = G.build_model_optimizer(cfg)
     sd = synth.make_state_dict(0)
     model.load_state_dict(sd)
