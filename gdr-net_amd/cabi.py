@@ -36,6 +36,19 @@ class ConvParams(C.Structure):
         ("M", I), ("w_rows", I), ("dtype", I),
         ("xf_mode", I), ("xf_relu", I),
         ("xf_x2", P), ("xf_a", P), ("xf_b", P), ("xf_c", P), ("xf_c2", P), ("xf_msc", P), ("xf_msh", P), ("xf_out", P),
+        ("stats_bn", P), ("bnb_bn", P),
+    ]
+
+
+BN_SLOTS = 8  # GDRN_BN_SLOTS
+
+
+class BnDesc(C.Structure):
+    _fields_ = [
+        ("sums", P), ("counter", P), ("C", I), ("kind", I), ("count", D), ("eps", F), ("momentum", F),
+        ("gamma", P), ("beta", P), ("running_mean", P), ("running_var", P), ("nbt", P),
+        ("mean", P), ("invstd", P), ("scale", P), ("shift", P),
+        ("ka", P), ("kb", P), ("kc", P), ("dgamma", P), ("dbeta", P),
     ]
 
 

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "bn_tail.h"
 #include "common.h"
 #include "halo_xf.h"
 #include "../../include/gdrn_hip.h"
@@ -349,7 +350,11 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                     for (int a = 0; a < FN; ++a) *reinterpret_cast<uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u) = src[a];
                 }
             };
-            if (p.stats != nullptr) {
+            // statistics finished by this launch (bn_tail.h): the workgroup that arrives last writes the BatchNorm vectors
+            auto bn_finish = [&](const gdrn_bn_desc* d) {
+                if (bn_tail::arrive(d, gridDim.x, reinterpret_cast<unsigned*>(smem))) bn_tail::finish(d);   // (the patch buffers are dead)
+            };
+            if (p.stats != nullptr || p.stats_bn != nullptr) {
                 float* srow = p.stats + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
@@ -363,8 +368,16 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         s2[j] = row16_sum(q);
                     }
                     if (r16 == 0) {
-                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                        if (p.stats_bn != nullptr) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                bn_tail::add(p.stats_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, s1[j]);
+                                bn_tail::add(p.stats_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, s2[j]);
+                            }
+                        } else {
+                            *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                            *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                        }
                     }
                 }
             }
@@ -466,10 +479,19 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { u1[j] = row16_sum(t1[a][j]); u2[j] = row16_sum(t2[a][j]); }
                     if (r16 == 0) {
-                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
-                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+                        if (p.bnb_bn != nullptr) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                bn_tail::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, u1[j]);
+                                bn_tail::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, u2[j]);
+                            }
+                        } else {
+                            *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                            *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+                        }
                     }
                 }
+                if (p.bnb_bn != nullptr) bn_finish(p.bnb_bn);
                 return;
             }
             // optional bias (eval mode: the folded BatchNorm shift) and ReLU
@@ -516,6 +538,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                     st_ch(yb, pr * (unsigned)p.y_cs + (unsigned)cl, ov);
                 }
             }
+            if (p.stats_bn != nullptr) bn_finish(p.stats_bn);
             return;
         }
     }
@@ -686,8 +709,12 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
+    if (p.w_frag < 0 || p.w_frag > 2) return GDRN_ERR_ARG;
+    if (p.stats_bn || p.bnb_bn) {  // statistics finished in the epilogue: the straight-line epilogue only (16-bit, full channel tiles)
+        if (p.dtype != GDRN_DT_H16 || p.act > 1 || p.out_f32 || (p.Cout % bn) || (p.bnb_bn && !p.bnb_x)) return GDRN_ERR_ARG;
+    }
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
-        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (!p.bnb_mean || !p.bnb_invstd || (!p.bnb_rows && !p.bnb_bn) || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }

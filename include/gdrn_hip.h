@@ -95,6 +95,39 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *      weight-gradient launch / the next residual without a separate pass.  Replaces gdrn_bn_apply /
  *      gdrn_bn_bwd_apply launches between two halo convs (BasicBlock, cdpn_rot_head_region.py:103-123 and backward).
  */
+/* BatchNorm descriptor of a conv launch whose epilogue FINISHES the statistics itself (stats_bn / bnb_bn below; device memory, built once by
+ * the host).  Every workgroup adds its per-tile partial sums to `sums` as 64-bit fixed-point integers (order-independent, hence deterministic:
+ * the value does not depend on which workgroup arrives when) in slot (pixel tile % GDRN_BN_SLOTS) and bumps `counter`; the workgroup that
+ * arrives last turns the totals into the per-channel vectors the consumers read -- what gdrn_bn_finalize (kind 0) / gdrn_bn_bwd_coef (kind 1)
+ * compute from per-tile rows in a launch of their own (~6 us alone, ~12 us beside a weight-gradient launch; 86 of them per step) -- and
+ * clears sums and counter for the next launch.  Replaces nn.BatchNorm2d's batch statistics / their backward sums
+ * (torchvision BasicBlock bn1 / bn2, cdpn_rot_head_region.py:84-133 norm layers; detectron2 BatchNorm2d, layer_utils.py:30).
+ *   kind 0: count pixels per channel; gamma, beta; mean, invstd, scale, shift written; running_mean / running_var / nbt updated when given.
+ *   kind 1: count = pixels per channel; gamma, mean, invstd read; ka, kb, kc (dx = ka*g + kb*x + kc) and dgamma / dbeta (when given) written.
+ * sums: GDRN_BN_SLOTS * 2 * C long long, counter: one unsigned int, both zero before the first launch. */
+#define GDRN_BN_SLOTS 8
+typedef struct gdrn_bn_desc {
+    long long* sums;
+    unsigned int* counter;
+    int C, kind;
+    double count;
+    float eps, momentum;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* nbt;
+    float* mean;
+    float* invstd;
+    float* scale;
+    float* shift;
+    float* ka;
+    float* kb;
+    float* kc;
+    float* dgamma;
+    float* dbeta;
+} gdrn_bn_desc;
+
 /* w_frag (gdrn_conv3x3_halo only): layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments, first halo kernel), 2: gdrn_pack_wfrag32
  * (second-generation kernel, see gdrn_pack_wfrag32 below). */
 typedef struct gdrn_conv_params {
@@ -127,6 +160,8 @@ typedef struct gdrn_conv_params {
     const float* xf_msc;
     const float* xf_msh;
     void* xf_out;
+    const gdrn_bn_desc* stats_bn;   /* gdrn_conv3x3_halo, 16-bit, full channel tiles: forward statistics finished in the epilogue (stats unused) */
+    const gdrn_bn_desc* bnb_bn;     /* ... the BatchNorm-backward sums of a bnb_x launch finished in the epilogue (bnb_rows unused) */
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);

@@ -92,7 +92,7 @@ def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, dtype, monk
 
     global TOL_BF16, TOL_SUM
     TOL_BF16, TOL_SUM = TOLS[dtype]
-    monkeypatch.setitem(_ST, 0, torch.float16 if dtype == "fp16" else torch.bfloat16)
+    _ST[0] = torch.float16 if dtype == "fp16" else torch.bfloat16   # read by r(); every case sets it
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -111,7 +111,9 @@ def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, dtype, monk
     plan = eng.plan(B, True, True)
     P = {k: v.detach().float().cpu() for k, v in model.named_parameters()}
     W = lambda n: r(P[n])
-    GR = {n: g.detach().float().cpu() for n, g in eng.grads.items()}
+    # fp16: the gradient chain (plan tensors d_*) runs under the engine's static loss scale; train_step(optimizer=None) has already divided
+    # it out of the parameter gradients -- put it back so that every stage is checked against its own (scaled) inputs
+    GR = {n: g.detach().float().cpu() * eng.loss_scale for n, g in eng.grads.items()}
 
     def T(name, C=None):
         """plan tensor (NHWC on the device) -> NCHW fp32 on the host, first C channels"""
