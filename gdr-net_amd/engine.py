@@ -100,7 +100,10 @@ class Engine:
         # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
         # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
         self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
-        self.post_on = self.wgrad_stream and _os.environ.get("GDRN_POST_STREAM", "1") == "1"
+        self.post_on = self.wgrad_stream and _os.environ.get("GDRN_POST_STREAM", "0") == "1"   # (measured r4: 7.42-7.45 against 7.36-7.37 ms without)
+        # BatchNorm statistics / backward sums finished by the producing conv's epilogue (csrc/bn_tail.h) instead of a bn_finalize / bn_bwd_coef
+        # launch behind it: bit 0 forward statistics, bit 1 backward sums (halo kernel launches; "0": the separate launches)
+        self.bn_tail = int(_os.environ.get("GDRN_BN_TAIL", "3")) if self.h16 else 0
         # 128 x 64 weight-gradient tile (conv3x3_wgrad.hip, GDRN_WGRAD_W128): 0 off, 1 stride-1 layers with Cout % 128 == 0, 2 stride-2 / ConvT too
         self.wgrad_w128 = int(_os.environ.get("GDRN_WGRAD_W128", "0"))
         self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
@@ -534,7 +537,7 @@ class Plan:
 
     # ---- op builders -------------------------------------------------------------------------
     def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
-              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False, xf=None):
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False, xf=None, bn=None):
         """bnb = (bn key, raw input of that BN, stored activation or None, affine mask?): data-gradient launch whose
         output is the gradient w.r.t. that BatchNorm(+ReLU)'s output -- the halo kernel's epilogue masks it and
         accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass.
@@ -577,12 +580,20 @@ class Plan:
             cp.w = ptr(L.wfF_e if use_halo else L.wf_e)
         elif use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
+        # statistics finished in this launch's own epilogue (first halo kernel, full channel tiles): no finalize / coefficient launch behind it
+        tail_ok = use_halo and cp.w_frag != 2 and cp.Cout % hbn.value == 0 and not out_f32 and act <= 1
+        cp._bn_tail = False
+        if bn is not None and stats is not None and tail_ok and (e.bn_tail & 1):
+            cp.stats, cp.stats_bn = None, self._bn_desc(bn, 0, cp.Cout, cp.M)
+            cp._bn_tail = True   # read by _bn_fwd: no bn_finalize launch
         if bnb is not None:
             assert use_halo or e.gemm_bnb, L.key
             bkey, braw, bmask, baffine = bnb
             sb = self.bn[bkey]
             cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(braw), ptr(bmask), braw.shape[-1]
             cp.bnb_mean, cp.bnb_invstd, cp.bnb_rows = ptr(sb.mean), ptr(sb.invstd), ptr(self.stats)  # stats scratch is idle in backward
+            if tail_ok and (e.bn_tail & 2):
+                cp.bnb_rows, cp.bnb_bn = None, self._bn_desc(bkey, 1, cp.Cout, cp.M)
             if baffine:
                 cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
         if xf is not None:
@@ -595,7 +606,14 @@ class Plan:
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
-        if bnb is not None:
+        if bnb is not None and cp.bnb_bn:
+            self._bn_coef_op(bnb[0], self.stats, 1)   # bookkeeping only (coefficient vectors exist, gradient group): the epilogue writes them
+
+            def run(st, ctx):
+                s = fn(ref, st)
+                if s:
+                    check(s, f"conv {L.key}")
+        elif bnb is not None:
             nrows_b = int(cp._stats_rows)
             assert nrows_b * 2 * cp.Cout <= self.stats.numel(), (L.key, nrows_b)
             # the epilogue's per-tile rows -> that BatchNorm's backward coefficients (+ dgamma / dbeta), for its apply pass or
@@ -739,13 +757,13 @@ class Plan:
     def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
         """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
         e, lib = self.e, self.e.lib
-        s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
-               scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
-        self.bn[bnkey] = s
+        s = self._bn_state(bnkey, C_, npix)
         g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
         rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
         ops = []
-        if self.bn_train:
+        if self.bn_train and getattr(cp, "_bn_tail", False):
+            pass   # the producing conv's last workgroup has written mean / invstd / scale / shift and the running statistics (csrc/bn_tail.h)
+        elif self.bn_train:
             rows = self._stats_rows(cp)
             assert rows * 2 * C_ <= self.stats.numel(), (bnkey, rows, C_)  # the producer's partial rows fit the scratch
             ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
@@ -760,6 +778,41 @@ class Plan:
             ops.append(lambda st, ctx: check(lib.gdrn_bn_apply(ptr(raw), ptr(s.scale), ptr(s.shift), ptr(residual), ptr(y), npix,
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
+
+    def _bn_state(self, bnkey, C_, npix):
+        """the per-channel vectors of a BatchNorm (created on first use: a conv that finishes the statistics itself needs them before _bn_fwd)"""
+        s = self.bn.get(bnkey)
+        if s is None:
+            e = self.e
+            s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
+                   scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
+            self.bn[bnkey] = s
+        assert s.C == C_ and s.npix == npix, (bnkey, s.C, C_, s.npix, npix)
+        return s
+
+    def _bn_desc(self, bnkey, kind, C_, npix):
+        """device-resident gdrn_bn_desc of BatchNorm `bnkey` (kind 0 forward statistics, 1 backward sums) for a conv launch that finishes them
+        in its epilogue; its fixed-point table and arrival counter are zero between launches (the finishing workgroup clears them)."""
+        from .cabi import BN_SLOTS, BnDesc, to_device_table
+
+        e = self.e
+        s = self._bn_state(bnkey, C_, npix)
+        sums = e._zeros(BN_SLOTS * 2 * C_, dtype=torch.int64)
+        counter = e._zeros(1, dtype=torch.int32)
+        d = BnDesc(sums=ptr(sums), counter=ptr(counter), C=C_, kind=kind, count=float(npix), eps=1e-5, momentum=0.1,
+                   gamma=ptr(e.P[bnkey + ".weight"]), mean=ptr(s.mean), invstd=ptr(s.invstd), scale=ptr(s.scale), shift=ptr(s.shift))
+        if kind == 0:
+            d.beta = ptr(e.P[bnkey + ".bias"])
+            d.running_mean, d.running_var = ptr(e.Bf[bnkey + ".running_mean"]), ptr(e.Bf[bnkey + ".running_var"])
+            d.nbt = ptr(e.Bf[bnkey + ".num_batches_tracked"])
+        else:
+            if getattr(s, "ka", None) is None:
+                s.ka, s.kb, s.kc = (e._empty(C_, dtype=torch.float32) for _ in range(3))
+            d.ka, d.kb, d.kc = ptr(s.ka), ptr(s.kb), ptr(s.kc)
+            d.dgamma, d.dbeta = ptr(e.grads[bnkey + ".weight"]), ptr(e.grads[bnkey + ".bias"])
+        tab = to_device_table([d], e.dev)
+        self.keep += [sums, counter, tab]
+        return tab.data_ptr()
 
     def _xf_ok(self, L, mode=None, hw=0):
         """can layer L's halo launches (forward and data gradient) take a fused operand transform (of that mode, on hw x hw maps)?"""
@@ -1107,13 +1160,13 @@ class Plan:
                     continue
                 assert pend is None or self._xf_ok(L1)
                 op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
-                                    xf=dict(pend["xf"], out=x) if pend else None)
+                                    xf=dict(pend["xf"], out=x) if pend else None, bn=pfx + ".bn1")
                 self.fwd.append(op)
                 xf1 = self._xf_ok(L2, 1, Ho)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
                 self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, None if xf1 else a1)
                 s1 = self.bn[pfx + ".bn1"]
                 op, cp = self._conv(L2, raw1 if xf1 else a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None,
-                                    xf=dict(mode=1, a=s1.scale, c=s1.shift, relu=True, out=a1) if xf1 else None)
+                                    xf=dict(mode=1, a=s1.scale, c=s1.shift, relu=True, out=a1) if xf1 else None, bn=pfx + ".bn2")
                 self.fwd.append(op)
                 # block output relu(bn2(raw2) + identity): left to the next block's conv1 when that is a halo launch
                 nxt1 = e.layers.get(f"backbone.layer{li}.{b + 1}.conv1")
@@ -1259,7 +1312,7 @@ class Plan:
                 self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
             else:
                 op, cp = self._conv(Lc, pend_h["x1"] if pend_h else xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None,
-                                    xf=dict(pend_h["xf"], out=xin) if pend_h else None)
+                                    xf=dict(pend_h["xf"], out=xin) if pend_h else None, bn=h + str(bi))
                 self.fwd.append(op)
                 self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, None if xf_next else act)
             if T:
