@@ -558,8 +558,11 @@ class GDRN(nn.Module):
         n = self.__dict__.get("_dp_checked", 0)
         if n >= int(os.environ.get("GDRN_DP_CHECK_STEPS", "2")):
             return
-        self.__dict__["_dp_checked"] = n + 1
         import torch.distributed as dist
+
+        if not dist.is_initialized():
+            return   # (a reducer with an explicit world size and no process group: the emulated-rank tests)
+        self.__dict__["_dp_checked"] = n + 1
 
         red = self._reducer
         with torch.no_grad():

@@ -22,7 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "bn_tail.h"
+#include "bn_sums.h"
 #include "common.h"
 #include "halo_xf.h"
 #include "../../include/gdrn_hip.h"
@@ -193,11 +193,26 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
     float xlo = 0.f;
     if constexpr (XF != 0) {
         float* tabw = reinterpret_cast<float*>(smem + (kch == 1 ? 1 : 2) * PBYTES);
+        // coefficient vectors: from memory, or -- p.xf_bn / p.xf_bn2 -- computed here from the producer's fixed-point sums (bn_sums.h); then
+        // workgroup 0 also stores what other kernels read later.  Every workgroup runs the same code on the same totals: identical tables.
+        const bool w0 = blockIdx.x == 0;
         for (int c = tid; c < p.Cin; c += 256) {
-            tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
-            tabw[p.Cin + c] = p.xf_c[c];
-            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
-            if constexpr (XF == 2) tabw[3 * p.Cin + c] = p.xf_c2 ? p.xf_c2[c] : 0.f;
+            float va, vc, vb = 1.f, vc2 = 0.f;
+            if constexpr (XF <= 2) {
+                if (p.xf_bn != nullptr) bn_sums::coef_fwd(p.xf_bn, c, w0, va, vc);
+                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; }
+                if constexpr (XF == 2) {
+                    if (p.xf_bn2 != nullptr) bn_sums::coef_fwd(p.xf_bn2, c, w0, vb, vc2);
+                    else { vb = p.xf_b ? p.xf_b[c] : 1.f; vc2 = p.xf_c2 ? p.xf_c2[c] : 0.f; }
+                }
+            } else {
+                if (p.xf_bn != nullptr) bn_sums::coef_bwd(p.xf_bn, c, w0, va, vb, vc);
+                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; vb = p.xf_b ? p.xf_b[c] : 1.f; }
+            }
+            tabw[c] = va;
+            tabw[p.Cin + c] = vc;
+            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = vb;
+            if constexpr (XF == 2) tabw[3 * p.Cin + c] = vc2;
             if constexpr (XF == 4) { tabw[3 * p.Cin + c] = p.xf_msc[c]; tabw[4 * p.Cin + c] = p.xf_msh[c]; }
         }
         xtab = tabw + (tid & 7) * 8;   // + kc * 64: this thread's 8 channels of chunk kc
@@ -350,10 +365,6 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                     for (int a = 0; a < FN; ++a) *reinterpret_cast<uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u) = src[a];
                 }
             };
-            // statistics finished by this launch (bn_tail.h): the workgroup that arrives last writes the BatchNorm vectors
-            auto bn_finish = [&](const gdrn_bn_desc* d) {
-                if (bn_tail::arrive(d, gridDim.x, reinterpret_cast<unsigned*>(smem))) bn_tail::finish(d);   // (the patch buffers are dead)
-            };
             if (p.stats != nullptr || p.stats_bn != nullptr) {
                 float* srow = p.stats + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll
@@ -371,8 +382,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         if (p.stats_bn != nullptr) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                bn_tail::add(p.stats_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, s1[j]);
-                                bn_tail::add(p.stats_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, s2[j]);
+                                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, s1[j]);
+                                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, s2[j]);
                             }
                         } else {
                             *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
@@ -482,8 +493,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         if (p.bnb_bn != nullptr) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                bn_tail::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, u1[j]);
-                                bn_tail::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, u2[j]);
+                                bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, u1[j]);
+                                bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, u2[j]);
                             }
                         } else {
                             *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
@@ -491,7 +502,6 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         }
                     }
                 }
-                if (p.bnb_bn != nullptr) bn_finish(p.bnb_bn);
                 return;
             }
             // optional bias (eval mode: the folded BatchNorm shift) and ReLU
@@ -538,7 +548,6 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                     st_ch(yb, pr * (unsigned)p.y_cs + (unsigned)cl, ov);
                 }
             }
-            if (p.stats_bn != nullptr) bn_finish(p.stats_bn);
             return;
         }
     }
@@ -710,7 +719,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
     if (p.w_frag < 0 || p.w_frag > 2) return GDRN_ERR_ARG;
-    if (p.stats_bn || p.bnb_bn) {  // statistics finished in the epilogue: the straight-line epilogue only (16-bit, full channel tiles)
+    if (p.stats_bn || p.bnb_bn) {  // statistics into the fixed-point table: the straight-line epilogue only (16-bit, full channel tiles)
         if (p.dtype != GDRN_DT_H16 || p.act > 1 || p.out_f32 || (p.Cout % bn) || (p.bnb_bn && !p.bnb_x)) return GDRN_ERR_ARG;
     }
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
@@ -720,7 +729,8 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     }
     if ((unsigned long long)p.M * (unsigned long long)std::max(p.y_cs, p.add_cs) * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     if (p.xf_mode) {  // operand transform while staging
-        if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
+        if (p.xf_mode < 0 || p.xf_mode > 4 || (!p.xf_c && !p.xf_bn) || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
+        if (p.xf_bn2 && p.xf_mode != 2) return GDRN_ERR_ARG;
         if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
         if (p.xf_mode == 4 && (!p.xf_msc || !p.xf_msh)) return GDRN_ERR_ARG;
         if (p.xf_mode != 2 && p.xf_c2) return GDRN_ERR_ARG;

@@ -110,6 +110,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
         cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
         cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
+        cp.xf_bn, cp.xf_bn2 = xf.get("bn"), xf.get("bn2")   # device pointers of gdrn_bn_desc: coefficient vectors computed in the prologue
     stats = None
     if stats_bn is not None:   # device pointer of a gdrn_bn_desc: the epilogue finishes the forward statistics itself (csrc/bn_tail.h)
         cp.stats_bn = stats_bn
