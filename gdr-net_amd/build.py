@@ -22,7 +22,7 @@ def needs_build():
     if not os.path.exists(LIB) or not os.path.exists(LIB_F16):
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_F16))
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "halo_xf.h"), os.path.join(CSRC, "bn_sums.h"), os.path.join(INCLUDE, "gdrn_hip.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "halo_xf.h"), os.path.join(INCLUDE, "gdrn_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

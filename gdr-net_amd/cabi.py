@@ -36,19 +36,6 @@ class ConvParams(C.Structure):
         ("M", I), ("w_rows", I), ("dtype", I),
         ("xf_mode", I), ("xf_relu", I),
         ("xf_x2", P), ("xf_a", P), ("xf_b", P), ("xf_c", P), ("xf_c2", P), ("xf_msc", P), ("xf_msh", P), ("xf_out", P),
-        ("stats_bn", P), ("bnb_bn", P), ("xf_bn", P), ("xf_bn2", P),
-    ]
-
-
-BN_SLOTS = 8  # GDRN_BN_SLOTS
-
-
-class BnDesc(C.Structure):
-    _fields_ = [
-        ("sums", P), ("counter", P), ("C", I), ("kind", I), ("count", D), ("eps", F), ("momentum", F),
-        ("gamma", P), ("beta", P), ("running_mean", P), ("running_var", P), ("nbt", P),
-        ("mean", P), ("invstd", P), ("scale", P), ("shift", P),
-        ("ka", P), ("kb", P), ("kc", P), ("dgamma", P), ("dbeta", P),
     ]
 
 
@@ -149,7 +136,6 @@ _SIGS = {
     "gdrn_bn_apply": [P, P, P, P, P, LL, I, I, I, P],
     "gdrn_bn_bwd_reduce_rows": [LL, I, I],
     "gdrn_bn_bwd_reduce": [P, P, P, P, P, P, P, LL, I, P, I, P],
-    "gdrn_bn_finish": [P, I, P],
     "gdrn_bn_bwd_coef": [P, I, I, LL, P, P, P, P, P, P, P, P, P],
     "gdrn_bn_bwd_apply": [P, P, P, P, P, P, P, P, LL, I, P, P, I, P],
     "gdrn_bn_relu_maxpool_fwd": [P, P, P, P, P, I, I, I, I, I, P],

@@ -22,7 +22,6 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "bn_sums.h"
 #include "common.h"
 #include "halo_xf.h"
 #include "../../include/gdrn_hip.h"
@@ -193,26 +192,11 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
     float xlo = 0.f;
     if constexpr (XF != 0) {
         float* tabw = reinterpret_cast<float*>(smem + (kch == 1 ? 1 : 2) * PBYTES);
-        // coefficient vectors: from memory, or -- p.xf_bn / p.xf_bn2 -- computed here from the producer's fixed-point sums (bn_sums.h); then
-        // workgroup 0 also stores what other kernels read later.  Every workgroup runs the same code on the same totals: identical tables.
-        const bool w0 = blockIdx.x == 0;
         for (int c = tid; c < p.Cin; c += 256) {
-            float va, vc, vb = 1.f, vc2 = 0.f;
-            if constexpr (XF <= 2) {
-                if (p.xf_bn != nullptr) bn_sums::coef_fwd(p.xf_bn, c, w0, va, vc);
-                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; }
-                if constexpr (XF == 2) {
-                    if (p.xf_bn2 != nullptr) bn_sums::coef_fwd(p.xf_bn2, c, w0, vb, vc2);
-                    else { vb = p.xf_b ? p.xf_b[c] : 1.f; vc2 = p.xf_c2 ? p.xf_c2[c] : 0.f; }
-                }
-            } else {
-                if (p.xf_bn != nullptr) bn_sums::coef_bwd(p.xf_bn, c, w0, va, vb, vc);
-                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; vb = p.xf_b ? p.xf_b[c] : 1.f; }
-            }
-            tabw[c] = va;
-            tabw[p.Cin + c] = vc;
-            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = vb;
-            if constexpr (XF == 2) tabw[3 * p.Cin + c] = vc2;
+            tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
+            tabw[p.Cin + c] = p.xf_c[c];
+            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
+            if constexpr (XF == 2) tabw[3 * p.Cin + c] = p.xf_c2 ? p.xf_c2[c] : 0.f;
             if constexpr (XF == 4) { tabw[3 * p.Cin + c] = p.xf_msc[c]; tabw[4 * p.Cin + c] = p.xf_msh[c]; }
         }
         xtab = tabw + (tid & 7) * 8;   // + kc * 64: this thread's 8 channels of chunk kc
@@ -365,7 +349,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                     for (int a = 0; a < FN; ++a) *reinterpret_cast<uint2*>(base + (elem_off + (unsigned)(a * 4)) * 2u) = src[a];
                 }
             };
-            if (p.stats != nullptr || p.stats_bn != nullptr) {
+            if (p.stats != nullptr) {
                 float* srow = p.stats + (size_t)mt * 2 * p.Cout + cl;
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
@@ -379,16 +363,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
                         s2[j] = row16_sum(q);
                     }
                     if (r16 == 0) {
-                        if (p.stats_bn != nullptr) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, s1[j]);
-                                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, s2[j]);
-                            }
-                        } else {
-                            *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-                            *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-                        }
+                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
                     }
                 }
             }
@@ -490,16 +466,8 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { u1[j] = row16_sum(t1[a][j]); u2[j] = row16_sum(t2[a][j]); }
                     if (r16 == 0) {
-                        if (p.bnb_bn != nullptr) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 0, cl + a * 4 + j, u1[j]);
-                                bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 1, cl + a * 4 + j, u2[j]);
-                            }
-                        } else {
-                            *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
-                            *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
-                        }
+                        *reinterpret_cast<float4*>(srow + a * 4) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+                        *reinterpret_cast<float4*>(srow + p.Cout + a * 4) = make_float4(u2[0], u2[1], u2[2], u2[3]);
                     }
                 }
                 return;
@@ -718,19 +686,15 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
-    if (p.w_frag < 0 || p.w_frag > 2) return GDRN_ERR_ARG;
-    if (p.stats_bn || p.bnb_bn) {  // statistics into the fixed-point table: the straight-line epilogue only (16-bit, full channel tiles)
-        if (p.dtype != GDRN_DT_H16 || p.act > 1 || p.out_f32 || (p.Cout % bn) || (p.bnb_bn && !p.bnb_x)) return GDRN_ERR_ARG;
-    }
+    if (p.w_frag < 0 || p.w_frag > 2) return GDRN_ERR_ARG;   // (ABI 1's padding field: an uninitialised value must not pick a kernel)
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
-        if (!p.bnb_mean || !p.bnb_invstd || (!p.bnb_rows && !p.bnb_bn) || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }
     if ((unsigned long long)p.M * (unsigned long long)std::max(p.y_cs, p.add_cs) * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     if (p.xf_mode) {  // operand transform while staging
-        if (p.xf_mode < 0 || p.xf_mode > 4 || (!p.xf_c && !p.xf_bn) || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
-        if (p.xf_bn2 && p.xf_mode != 2) return GDRN_ERR_ARG;
+        if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
         if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
         if (p.xf_mode == 4 && (!p.xf_msc || !p.xf_msh)) return GDRN_ERR_ARG;
         if (p.xf_mode != 2 && p.xf_c2) return GDRN_ERR_ARG;

@@ -24,7 +24,6 @@
 #include <cstdlib>
 #include <utility>
 
-#include "bn_sums.h"
 #include "common.h"
 #include "halo_xf.h"
 #include "../../include/gdrn_hip.h"
@@ -258,25 +257,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
     const float* xtab = reinterpret_cast<const float*>(smem + K::OFF_TAB) + g8 * 8;  // + kc*64: this thread's 8 channels of chunk kc
     if constexpr (XF != 0) {
         float* tabw = reinterpret_cast<float*>(smem + K::OFF_TAB);
-        // coefficient vectors from memory or -- p.xf_bn / p.xf_bn2 -- from the producer's fixed-point sums (bn_sums.h; see conv3x3_halo.hip)
-        const bool w0 = blockIdx.x == 0;
         for (int c = tid; c < p.Cin; c += NT) {
-            float va, vc, vb = 1.f, vc2 = 0.f;
-            if constexpr (XF <= 2) {
-                if (p.xf_bn != nullptr) bn_sums::coef_fwd(p.xf_bn, c, w0, va, vc);
-                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; }
-                if constexpr (XF == 2) {
-                    if (p.xf_bn2 != nullptr) bn_sums::coef_fwd(p.xf_bn2, c, w0, vb, vc2);
-                    else { vb = p.xf_b ? p.xf_b[c] : 1.f; vc2 = p.xf_c2 ? p.xf_c2[c] : 0.f; }
-                }
-            } else {
-                if (p.xf_bn != nullptr) bn_sums::coef_bwd(p.xf_bn, c, w0, va, vb, vc);
-                else { va = p.xf_a ? p.xf_a[c] : 1.f; vc = p.xf_c[c]; vb = p.xf_b ? p.xf_b[c] : 1.f; }
-            }
-            tabw[c] = va;
-            tabw[p.Cin + c] = vc;
-            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = vb;
-            if constexpr (XF == 2) tabw[3 * p.Cin + c] = vc2;
+            tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
+            tabw[p.Cin + c] = p.xf_c[c];
+            if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
+            if constexpr (XF == 2) tabw[3 * p.Cin + c] = p.xf_c2 ? p.xf_c2[c] : 0.f;
             if constexpr (XF == 4) { tabw[3 * p.Cin + c] = p.xf_msc[c]; tabw[4 * p.Cin + c] = p.xf_msh[c]; }
         }
     }
@@ -535,15 +520,13 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
             for (int i = 0; i < nv; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(w[i], w[i + 1], w[i + 2], w[i + 3]);
         }
     };
-    // per-tile sums: a row of `rows`, or -- bnd -- added to the BatchNorm's fixed-point table (bn_sums.h: no launch turns rows into vectors)
-    auto put_rows = [&](float* rows, const gdrn_bn_desc* bnd) {
+    auto put_rows = [&](float* rows) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int i = tid; i < 2 * BN; i += NT) {
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < WN * WK; ++g) s += part[g * 2 * BN + i];
-            if (bnd != nullptr) bn_sums::add(bnd, mt % GDRN_BN_SLOTS, i / BN, co0 + (i % BN), s);
-            else rows[(size_t)mt * 2 * p.Cout + (size_t)(i / BN) * p.Cout + co0 + (i % BN)] = s;
+            rows[(size_t)mt * 2 * p.Cout + (size_t)(i / BN) * p.Cout + co0 + (i % BN)] = s;
         }
     };
     // the lane's part of fragment pair ap of an NHWC bf16 tensor: [fragment][16-byte quarter of the pair's 64 bytes]
@@ -627,12 +610,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
                 red_put(cl, wsum, 8);
             }
         }
-        put_rows(p.bnb_rows, p.bnb_bn);
+        put_rows(p.bnb_rows);
         flush_tile();
         return;
     }
 
-    if (p.stats != nullptr || p.stats_bn != nullptr) {
+    if (p.stats != nullptr) {
 #pragma unroll
         for (int a = 0; a < FA; ++a) {
             float wsum[16];
@@ -648,7 +631,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv3x3_v3_kernel(const gdrn_
 #ifdef V3_DBG
         dbg_out_.e1 = v3_clock();
 #endif
-        put_rows(p.stats, p.stats_bn);
+        put_rows(p.stats);
 #ifdef V3_DBG
         dbg_out_.e2 = v3_clock();
 #endif
@@ -783,14 +766,14 @@ int gdrn_v3_launch(const gdrn_conv_params* pp, void* stream) {
     const int hw = p.Ho * p.Wo;
     if (p.M <= 0 || p.M % hw != 0) return GDRN_ERR_SHAPE;
     if (p.bnb_x) {
-        if (!p.bnb_mean || !p.bnb_invstd || (!p.bnb_rows && !p.bnb_bn) || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }
     if ((unsigned long long)p.M * (unsigned long long)(p.y_cs > p.add_cs ? p.y_cs : p.add_cs) * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
     if ((unsigned long long)p.M * (unsigned long long)p.x_cs * 2ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     if (p.xf_mode) {
-        if (p.xf_mode < 0 || p.xf_mode > 4 || (!p.xf_c && !p.xf_bn) || p.Cin > 512 || (p.xf_bn2 && p.xf_mode != 2)) return GDRN_ERR_ARG;
+        if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > 512) return GDRN_ERR_ARG;
         if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
         if (p.xf_mode == 4 && (!p.xf_msc || !p.xf_msh)) return GDRN_ERR_ARG;
         if (p.xf_mode != 2 && p.xf_c2) return GDRN_ERR_ARG;

@@ -15,7 +15,6 @@
 // The weight rows feed the MFMA "A" operand and the pixel rows the "B" operand, so each lane ends up
 // with 4 consecutive output channels of one pixel (8/16-byte stores, per-channel BN statistics by a
 // 16-lane butterfly).
-#include "bn_sums.h"
 #include "common.h"
 #include "../../include/gdrn_hip.h"
 
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
     // ---- epilogue ----------------------------------------------------------------------------
     // lane holds D[i = g*4+j][col = r16] of fragment (a,b): channel co0 + wn*WN + a*16 + g*4 + j,
     // pixel row wm*WM + b*16 + r16.
-    if (p.stats != nullptr || p.stats_bn != nullptr) {
+    if (p.stats != nullptr) {
         float* red = reinterpret_cast<float*>(smem + 512);  // [2 (wm)][BN][2]
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
@@ -291,13 +290,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
         if (tid < BN && co0 + tid < p.Cout) {
             const float s1 = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
             const float s2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-            if (p.stats_bn != nullptr) {   // the BatchNorm's fixed-point table instead of a per-tile row (bn_sums.h)
-                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 0, co0 + tid, s1);
-                bn_sums::add(p.stats_bn, mt % GDRN_BN_SLOTS, 1, co0 + tid, s2);
-            } else {
-                p.stats[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = s1;
-                p.stats[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = s2;
-            }
+            p.stats[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = s1;
+            p.stats[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = s2;
         }
     }
 
@@ -413,14 +407,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && BM == 64 && BN == 128) ? 3 
                     }
                 __syncthreads();
                 if (tid < BN) {
-                    const float u1 = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0], u2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-                    if (p.bnb_bn != nullptr) {
-                        bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 0, co0 + tid, u1);
-                        bn_sums::add(p.bnb_bn, mt % GDRN_BN_SLOTS, 1, co0 + tid, u2);
-                    } else {
-                        p.bnb_rows[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = u1;
-                        p.bnb_rows[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = u2;
-                    }
+                    p.bnb_rows[((size_t)mt * 2 + 0) * p.Cout + co0 + tid] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+                    p.bnb_rows[((size_t)mt * 2 + 1) * p.Cout + co0 + tid] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
                 }
                 return;
             }
@@ -598,7 +586,7 @@ extern "C" int gdrn_conv_gemm(const gdrn_conv_params* pp, void* stream) {
     gdrn_conv_tile(pp, &bm, &bn);
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: the straight-line bf16 epilogue only
-        if (p.dtype != GDRN_DT_H16 || !p.bnb_mean || !p.bnb_invstd || (!p.bnb_rows && !p.bnb_bn) || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
+        if (p.dtype != GDRN_DT_H16 || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || p.stats || (p.Cout % bn) || (p.bnb_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || p.bnb_cs < p.Cout)
             return GDRN_ERR_SHAPE;  // (rows of whole 16-byte groups: the epilogue's accesses)
         const unsigned long long rows_out = (p.mode == 1) ? 4ull * (unsigned long long)p.M : (unsigned long long)p.M;

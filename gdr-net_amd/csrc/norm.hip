@@ -6,7 +6,6 @@
 
 #include <algorithm>
 
-#include "bn_sums.h"
 #include "common.h"
 #include "../../include/gdrn_hip.h"
 
@@ -100,16 +99,6 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
         kb[ch] = b;
         kc[ch] = -a * m1 - b * k_mu;
     }
-}
-
-// the vectors of a BatchNorm from the fixed-point table its producer filled (bn_sums.h), for the consumers that do not compute them in
-// their own prologue: one thread per channel
-__global__ __launch_bounds__(256) void bn_finish_kernel(const gdrn_bn_desc* __restrict__ d) {
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= d->C) return;
-    float a, b, c;
-    if (d->kind == 0) bn_sums::coef_fwd(d, ch, true, a, c);
-    else bn_sums::coef_bwd(d, ch, true, a, b, c);
 }
 
 __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -720,13 +709,6 @@ extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double co
     if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || (C & 3)) return GDRN_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3(C / 4), dim3(256), 0, ST, partial, rows, C, count, gamma, beta, running_mean,
                        running_var, nbt, momentum, eps, mean, invstd, scale, shift);
-    GDRN_CHECK_LAUNCH();
-    return GDRN_OK;
-}
-
-extern "C" int gdrn_bn_finish(const gdrn_bn_desc* desc_dev, int C, void* stream) {
-    if (!desc_dev || C <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, desc_dev);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

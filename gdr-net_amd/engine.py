@@ -101,11 +101,6 @@ class Engine:
         # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
         self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
         self.post_on = self.wgrad_stream and _os.environ.get("GDRN_POST_STREAM", "0") == "1"   # (measured r4: 7.42-7.45 against 7.36-7.37 ms without)
-        # BatchNorm statistics / backward sums as fixed-point integer tables (csrc/bn_sums.h): the producing conv adds to the table, the conv that
-        # applies the BatchNorm while staging its operand computes its coefficient vectors from it in its prologue -- no bn_finalize /
-        # bn_bwd_coef launch in between (consumers that cannot: one gdrn_bn_finish launch over the 32 KB table).  Bit 0 forward statistics,
-        # bit 1 backward sums, bit 2: tables but always the gdrn_bn_finish launch (A/B); "0": per-tile rows + the round-3 launches
-        self.bn_tail = int(_os.environ.get("GDRN_BN_SUMS", "3")) if self.h16 else 0
         # 128 x 64 weight-gradient tile (conv3x3_wgrad.hip, GDRN_WGRAD_W128): 0 off, 1 stride-1 layers with Cout % 128 == 0, 2 stride-2 / ConvT too
         self.wgrad_w128 = int(_os.environ.get("GDRN_WGRAD_W128", "0"))
         self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
@@ -528,11 +523,6 @@ class Plan:
         self._wgrad_deferred = []  # (forward group index, layer, WgradParams, flops) of the halo weight gradients
         self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
         self._zero_regions = []    # fp32 tensors the backward accumulates into with atomics: cleared by ONE gdrn_zero_multi launch
-        self._bn_descs = {}        # (kind, BatchNorm) -> device descriptor of its fixed-point statistics table (csrc/bn_sums.h)
-        self._bn_fin = {}          # (kind, BatchNorm) -> the gdrn_bn_finish op behind its producer (skipped when the consumer conv takes over)
-        self._fwd_sum_bufs = []    # forward tables: cleared with the backward's zero launch; _fwd_dirty: a forward ran since
-        self._fwd_dirty = False
-        self._bn_want = {}         # (kind, BatchNorm) -> (conv params, field) of a consumer conv built before the table's producer
         self.generation = 0        # bumped by every run_forward: a backward checks its activations are still the plan's
         self.grad_group = {}       # parameter name -> forward index of the backward group that completes its gradient
         self._build()
@@ -544,7 +534,7 @@ class Plan:
 
     # ---- op builders -------------------------------------------------------------------------
     def _conv(self, L, x, xs, y, Hi, Wi, Ho, Wo, stride, pad, mode=0, w=None, rows=None, cin=None, cout=None, x_cs=None,
-              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False, xf=None, bn=None):
+              y_cs=None, bias=None, addend=None, add_cs=0, act=0, out_f32=0, stats=None, KH=None, KW=None, bnb=None, evalw=False, xf=None):
         """bnb = (bn key, raw input of that BN, stored activation or None, affine mask?): data-gradient launch whose
         output is the gradient w.r.t. that BatchNorm(+ReLU)'s output -- the halo kernel's epilogue masks it and
         accumulates the BN-backward sums (see _fusable), so the BN backward is only its apply pass.
@@ -587,24 +577,12 @@ class Plan:
             cp.w = ptr(L.wfF_e if use_halo else L.wf_e)
         elif use_halo:  # fragment-major operand copy (forward: of wf, data gradient: of wd)
             cp.w = ptr(L.wfF if w is None else L.wdF)
-        # statistics into the BatchNorm's fixed-point table (halo kernels: full channel tiles, 16-bit output; generic kernel: its 16-bit
-        # instantiations): no per-tile rows, no finalize / coefficient launch of the round-3 kind behind this conv
-        if use_halo:
-            sums_ok = cp.Cout % hbn.value == 0 and not out_f32 and act <= 1
-        else:
-            sums_ok = e.h16 and L.kind in ("conv", "convT") and not out_f32
-        cp._bn_sums = False
-        if bn is not None and stats is not None and sums_ok and (e.bn_tail & 1):
-            cp.stats, cp.stats_bn = None, self._bn_desc(bn, 0, cp.Cout, self.B * Ho * Wo)
-            cp._bn_sums = True   # read by _bn_fwd: gdrn_bn_finish (or the consumer conv's prologue) instead of bn_finalize
         if bnb is not None:
             assert use_halo or e.gemm_bnb, L.key
             bkey, braw, bmask, baffine = bnb
             sb = self.bn[bkey]
             cp.bnb_x, cp.bnb_mask, cp.bnb_cs = ptr(braw), ptr(bmask), braw.shape[-1]
             cp.bnb_mean, cp.bnb_invstd, cp.bnb_rows = ptr(sb.mean), ptr(sb.invstd), ptr(self.stats)  # stats scratch is idle in backward
-            if (sums_ok or not use_halo) and (e.bn_tail & 2):
-                cp.bnb_rows, cp.bnb_bn = None, self._bn_desc(bkey, 1, cp.Cout, sb.npix)
             if baffine:
                 cp.bnb_scale, cp.bnb_shift = ptr(sb.scale), ptr(sb.shift)
         if xf is not None:
@@ -614,36 +592,10 @@ class Plan:
             cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
             cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf["c"]), ptr(xf.get("c2"))
             cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
-            # the BatchNorm(s) this conv applies while staging: when their statistics sit in a fixed-point table, the coefficient vectors
-            # are computed in this launch's prologue and the gdrn_bn_finish launch behind the producer is dropped
-            kind = 0 if cp.xf_mode <= 2 else 1
-            for fld, key in (("xf_bn", xf.get("bn")), ("xf_bn2", xf.get("bn2"))):
-                if key is None or (e.bn_tail & 4):
-                    continue
-                fin = self._bn_fin.get((kind, key))
-                if fin is not None:
-                    setattr(cp, fld, self._bn_descs[(kind, key)])
-                    fin.skip = True
-                else:   # the producer is built later (a block's bn2-backward sums come out of the NEXT block's conv1 data gradient)
-                    self._bn_want[(kind, key)] = (cp, fld)
         fn = e.lib.gdrn_conv3x3_halo if use_halo else e.lib.gdrn_conv_gemm
         cp._stats_rows = (e.lib.gdrn_conv3x3_stats_rows if use_halo else e.lib.gdrn_conv_stats_rows)(ref)
 
-        if bnb is not None and cp.bnb_bn:
-            self._bn_coef_op(bnb[0], self.stats, 1)   # bookkeeping only (coefficient vectors exist, gradient group)
-            fin = self._bn_finish_op(1, bnb[0])        # ... their values: the consumer conv's prologue, or this launch
-
-            def conv_only(st, ctx):
-                s = fn(ref, st)
-                if s:
-                    check(s, f"conv {L.key}")
-
-            def run(st, ctx):
-                conv_only(st, ctx)
-                fin(st, ctx)
-
-            run.parts = (conv_only, fin)
-        elif bnb is not None:
+        if bnb is not None:
             nrows_b = int(cp._stats_rows)
             assert nrows_b * 2 * cp.Cout <= self.stats.numel(), (L.key, nrows_b)
             # the epilogue's per-tile rows -> that BatchNorm's backward coefficients (+ dgamma / dbeta), for its apply pass or
@@ -787,15 +739,13 @@ class Plan:
     def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
         """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
         e, lib = self.e, self.e.lib
-        s = self._bn_state(bnkey, C_, npix)
+        s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
+               scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
+        self.bn[bnkey] = s
         g, b = e.P[bnkey + ".weight"], e.P[bnkey + ".bias"]
         rm, rv, nbt = e.Bf[bnkey + ".running_mean"], e.Bf[bnkey + ".running_var"], e.Bf[bnkey + ".num_batches_tracked"]
         ops = []
-        if self.bn_train and getattr(cp, "_bn_sums", False):
-            # the statistics sit in the BatchNorm's fixed-point table: the vectors come out of the consumer conv's prologue (the op below is
-            # then skipped) or out of this one-workgroup launch
-            ops.append(self._bn_finish_op(0, bnkey))
-        elif self.bn_train:
+        if self.bn_train:
             rows = self._stats_rows(cp)
             assert rows * 2 * C_ <= self.stats.numel(), (bnkey, rows, C_)  # the producer's partial rows fit the scratch
             ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
@@ -810,64 +760,6 @@ class Plan:
             ops.append(lambda st, ctx: check(lib.gdrn_bn_apply(ptr(raw), ptr(s.scale), ptr(s.shift), ptr(residual), ptr(y), npix,
                                                                C_, relu, e.dt, st), "bn_apply"))
         return ops
-
-    def _bn_state(self, bnkey, C_, npix):
-        """the per-channel vectors of a BatchNorm (created on first use: a conv that finishes the statistics itself needs them before _bn_fwd)"""
-        s = self.bn.get(bnkey)
-        if s is None:
-            e = self.e
-            s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
-                   scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
-            self.bn[bnkey] = s
-        assert s.C == C_ and s.npix == npix, (bnkey, s.C, C_, s.npix, npix)
-        return s
-
-    def _bn_finish_op(self, kind, bnkey):
-        """gdrn_bn_finish over the table of (kind, bnkey); `skip` is set when a consumer conv computes the vectors in its own prologue"""
-        e = self.e
-        d, C_ = self._bn_descs[(kind, bnkey)], self.bn[bnkey].C
-
-        def fin(st, ctx):
-            if not fin.skip:
-                check(e.lib.gdrn_bn_finish(d, C_, st), "bn_finish")
-
-        fin.skip = False
-        self._bn_fin[(kind, bnkey)] = fin
-        want = self._bn_want.pop((kind, bnkey), None)
-        if want is not None:
-            setattr(want[0], want[1], d)
-            fin.skip = True
-        return fin
-
-    def _bn_desc(self, bnkey, kind, C_, npix):
-        """device-resident gdrn_bn_desc of BatchNorm `bnkey` (kind 0 forward statistics, 1 backward sums) and its fixed-point table, which
-        the backward pass's zero launch clears (run_forward clears the forward tables itself when no backward ran in between)."""
-        from .cabi import BN_SLOTS, BnDesc, to_device_table
-
-        e = self.e
-        if (kind, bnkey) in self._bn_descs:
-            return self._bn_descs[(kind, bnkey)]
-        s = self._bn_state(bnkey, C_, npix)
-        sums = e._zeros(BN_SLOTS * 2 * C_ * 2, dtype=torch.float32)   # int64 [slots][2][C], typed fp32 for the zero table
-        self._zero_regions.append(sums)
-        if kind == 0:
-            self._fwd_sum_bufs.append(sums)
-        counter = None
-        d = BnDesc(sums=ptr(sums), counter=ptr(counter), C=C_, kind=kind, count=float(npix), eps=1e-5, momentum=0.1,
-                   gamma=ptr(e.P[bnkey + ".weight"]), mean=ptr(s.mean), invstd=ptr(s.invstd), scale=ptr(s.scale), shift=ptr(s.shift))
-        if kind == 0:
-            d.beta = ptr(e.P[bnkey + ".bias"])
-            d.running_mean, d.running_var = ptr(e.Bf[bnkey + ".running_mean"]), ptr(e.Bf[bnkey + ".running_var"])
-            d.nbt = ptr(e.Bf[bnkey + ".num_batches_tracked"])
-        else:
-            if getattr(s, "ka", None) is None:
-                s.ka, s.kb, s.kc = (e._empty(C_, dtype=torch.float32) for _ in range(3))
-            d.ka, d.kb, d.kc = ptr(s.ka), ptr(s.kb), ptr(s.kc)
-            d.dgamma, d.dbeta = ptr(e.grads[bnkey + ".weight"]), ptr(e.grads[bnkey + ".bias"])
-        tab = to_device_table([d], e.dev)
-        self.keep += [sums, tab]
-        self._bn_descs[(kind, bnkey)] = tab.data_ptr()
-        return tab.data_ptr()
 
     def _xf_ok(self, L, mode=None, hw=0):
         """can layer L's halo launches (forward and data gradient) take a fused operand transform (of that mode, on hw x hw maps)?"""
@@ -927,7 +819,7 @@ class Plan:
         if xf:
             assert g_out is None and ym is None
             mode = 4 if msc is not None else 3
-            return ops, dict(mode=mode, x2=raw, a=s.ka, b=s.kb, c=s.kc, msc=msc, msh=msh, out=dx, relu=False, bn=bnkey)
+            return ops, dict(mode=mode, x2=raw, a=s.ka, b=s.kb, c=s.kc, msc=msc, msh=msh, out=dx, relu=False)
         if apply:
             ops.append(lambda st, ctx: check(lib.gdrn_bn_bwd_apply(ptr(dy), ptr(ym), ptr(raw), ptr(s.ka), ptr(s.kb), ptr(s.kc), ptr(msc), ptr(msh), s.npix,
                                                                    s.C, ptr(dx), ptr(g_out), e.dt, st), "bn_bwd_apply"))
@@ -1215,13 +1107,13 @@ class Plan:
                     continue
                 assert pend is None or self._xf_ok(L1)
                 op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
-                                    xf=dict(pend["xf"], out=x) if pend else None, bn=pfx + ".bn1")
+                                    xf=dict(pend["xf"], out=x) if pend else None)
                 self.fwd.append(op)
                 xf1 = self._xf_ok(L2, 1, Ho)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
                 self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, None if xf1 else a1)
                 s1 = self.bn[pfx + ".bn1"]
                 op, cp = self._conv(L2, raw1 if xf1 else a1, pl, raw2, Ho, Ho, Ho, Ho, 1, 1, stats=self.stats if S else None,
-                                    xf=dict(mode=1, a=s1.scale, c=s1.shift, relu=True, out=a1, bn=pfx + ".bn1") if xf1 else None, bn=pfx + ".bn2")
+                                    xf=dict(mode=1, a=s1.scale, c=s1.shift, relu=True, out=a1) if xf1 else None)
                 self.fwd.append(op)
                 # block output relu(bn2(raw2) + identity): left to the next block's conv1 when that is a halo launch
                 nxt1 = e.layers.get(f"backbone.layer{li}.{b + 1}.conv1")
@@ -1232,13 +1124,12 @@ class Plan:
                     if idn is not None:
                         self.tensors[pfx + ".idn"] = idn
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
-                    op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None, bn=pfx + ".downsample.1")
+                    op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
                     self.fwd.append(op)
                     self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd, pl, npo, idn, relu=0)
                     s2, sd = self.bn[pfx + ".bn2"], self.bn[pfx + ".downsample.1"]
                     if xf_out:   # relu(scale2*raw2 + scale_d*rawd + shift2 + shift_d)
-                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=rawd, a=s2.scale, b=sd.scale, c=s2.shift, c2=sd.shift, relu=True,
-                                                         bn=pfx + ".bn2", bn2=pfx + ".downsample.1"))
+                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=rawd, a=s2.scale, b=sd.scale, c=s2.shift, c2=sd.shift, relu=True))
                     else:
                         self.fwd.append(lambda st, ctx, raw2=raw2, s2=s2, idn=idn, out=out, npo=npo, pl=pl: check(
                             lib.gdrn_bn_apply(ptr(raw2), ptr(s2.scale), ptr(s2.shift), ptr(idn), ptr(out), npo, pl, 1, e.dt, st), "bn_apply"))
@@ -1246,7 +1137,7 @@ class Plan:
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None if xf_out else out, residual=x)
                     s2 = self.bn[pfx + ".bn2"]
                     if xf_out:   # relu(scale2*raw2 + x + shift2)
-                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=x, a=s2.scale, c=s2.shift, relu=True, bn=pfx + ".bn2"))
+                        nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=x, a=s2.scale, c=s2.shift, relu=True))
                 if not xf_out:
                     nxt_pend = None
                 if T:
@@ -1322,7 +1213,7 @@ class Plan:
         if FOLD:
             self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
         else:
-            op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None, bn=h + "1")
+            op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
             self.fwd.append(op)
             self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, None if xf_first else h0)
         if T:
@@ -1340,7 +1231,7 @@ class Plan:
         hx, d_hx, Hh = h0, (d_h0 if T else None), 16
         prev_bn, prev_raw = h + "1", rawt
         # pend_h: hx = relu(bn(prev_raw)) is evaluated (and written to hx) by the next head conv while it stages its patch
-        pend_h = dict(x1=rawt, xf=dict(mode=1, a=self.bn[h + "1"].scale, c=self.bn[h + "1"].shift, relu=True, bn=h + "1")) if xf_first else None
+        pend_h = dict(x1=rawt, xf=dict(mode=1, a=self.bn[h + "1"].scale, c=self.bn[h + "1"].shift, relu=True)) if xf_first else None
         for hi, (ci, bi, up) in enumerate(HEAD_CONVS):
             Lc = e.layers[h + str(ci)]
             grp = []
@@ -1368,7 +1259,7 @@ class Plan:
                 self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
             else:
                 op, cp = self._conv(Lc, pend_h["x1"] if pend_h else xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None,
-                                    xf=dict(pend_h["xf"], out=xin) if pend_h else None, bn=h + str(bi))
+                                    xf=dict(pend_h["xf"], out=xin) if pend_h else None)
                 self.fwd.append(op)
                 self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, None if xf_next else act)
             if T:
@@ -1394,7 +1285,7 @@ class Plan:
                     grp.append(up_bwd)
                 self.bwd_groups.append(grp)
                 d_hx = d_act
-            pend_h = dict(x1=raw, xf=dict(mode=1, a=self.bn[h + str(bi)].scale, c=self.bn[h + str(bi)].shift, relu=True, bn=h + str(bi))) if xf_next else None
+            pend_h = dict(x1=raw, xf=dict(mode=1, a=self.bn[h + str(bi)].scale, c=self.bn[h + str(bi)].shift, relu=True)) if xf_next else None
             hx, prev_bn, prev_raw = act, h + str(bi), raw
         assert pend_h is None
         LO = e.layers[h + "23"]
@@ -1568,11 +1459,8 @@ class Plan:
                 for op in self.eval_prep:
                     op(st, ctx)
                 self._eval_sig = sig
-        if self._fwd_dirty and self._fwd_sum_bufs:
-            torch._foreach_zero_(self._fwd_sum_bufs)   # a forward without a backward since (whose zero launch clears the tables): rare path
         for op in self.fwd:
             op(st, ctx)
-        self._fwd_dirty = True
 
     def run_backward(self, ctx, on_bucket=None):
         """ctx as in forward; self.gw must hold dL/dloss_k.  on_bucket(i) is called after the ops that
@@ -1584,7 +1472,6 @@ class Plan:
         st = main.cuda_stream
         ztab, zst, znt, znb = self._zero_tab
         check(e.lib.gdrn_zero_multi(ptr(ztab), ptr(zst), znt, znb, st), "zero_multi")
-        self._fwd_dirty = False   # (the BatchNorm tables are part of that launch)
         marks = self._bucket_marks() if on_bucket is not None else {}
         # The bucket-end work (grouped weight gradients, their reduction, gradient unpack) only feeds the optimizer /
         # the RCCL exchange: it goes to a second stream behind an event, so the next bucket's dependent chain of short

@@ -95,41 +95,6 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  *      weight-gradient launch / the next residual without a separate pass.  Replaces gdrn_bn_apply /
  *      gdrn_bn_bwd_apply launches between two halo convs (BasicBlock, cdpn_rot_head_region.py:103-123 and backward).
  */
-/* BatchNorm statistics without a launch of their own (csrc/bn_sums.h).  A PRODUCER conv (stats_bn: forward statistics; bnb_bn: the
- * BatchNorm-backward sums of a bnb_x launch) adds its per-tile partial sums to `sums` -- GDRN_BN_SLOTS * 2 * C 64-bit FIXED-POINT integers,
- * slot = pixel tile % GDRN_BN_SLOTS -- with return-less device-scope atomics: integer addition is order independent, the totals are bit
- * reproducible.  The CONSUMER conv that applies the BatchNorm while it stages its operand (xf_bn / xf_bn2 below) turns the totals into its
- * coefficient vectors in its own prologue and its workgroup 0 stores the vectors other kernels read later; consumers that cannot do that get
- * gdrn_bn_finish (one small launch over the table).  Either way the arithmetic is gdrn_bn_finalize's (kind 0) / gdrn_bn_bwd_coef's (kind 1).
- * The host clears `sums` between uses (the engine: in the zero_multi launch at the start of a backward pass).  Replaces the batch statistics
- * of nn.BatchNorm2d / their backward sums (torchvision BasicBlock bn1 / bn2, cdpn_rot_head_region.py:84-133; detectron2 BatchNorm2d,
- * layer_utils.py:30).  The descriptor lives in DEVICE memory.
- *   kind 0: count pixels per channel; gamma, beta; mean, invstd, scale, shift written; running_mean / running_var / nbt updated when given.
- *   kind 1: count = pixels per channel; gamma, mean, invstd read; ka, kb, kc (dx = ka*g + kb*x + kc) and dgamma / dbeta (when given) written.
- * counter: unused (reserved). */
-#define GDRN_BN_SLOTS 8
-typedef struct gdrn_bn_desc {
-    long long* sums;
-    unsigned int* counter;
-    int C, kind;
-    double count;
-    float eps, momentum;
-    const float* gamma;
-    const float* beta;
-    float* running_mean;
-    float* running_var;
-    long long* nbt;
-    float* mean;
-    float* invstd;
-    float* scale;
-    float* shift;
-    float* ka;
-    float* kb;
-    float* kc;
-    float* dgamma;
-    float* dbeta;
-} gdrn_bn_desc;
-
 /* w_frag (gdrn_conv3x3_halo only): layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments, first halo kernel), 2: gdrn_pack_wfrag32
  * (second-generation kernel, see gdrn_pack_wfrag32 below). */
 typedef struct gdrn_conv_params {
@@ -162,11 +127,6 @@ typedef struct gdrn_conv_params {
     const float* xf_msc;
     const float* xf_msh;
     void* xf_out;
-    const gdrn_bn_desc* stats_bn;   /* 16-bit, full channel tiles: forward statistics into the descriptor's fixed-point table (stats unused) */
-    const gdrn_bn_desc* bnb_bn;     /* ... the BatchNorm-backward sums of a bnb_x launch likewise (bnb_rows unused) */
-    const gdrn_bn_desc* xf_bn;      /* gdrn_conv3x3_halo (first kernel), xf modes 1, 2: (xf_a, xf_c) = scale / shift computed from this table in the
-                                       prologue; modes 3, 4: (xf_a, xf_b, xf_c) = the backward coefficients (kind 1) */
-    const gdrn_bn_desc* xf_bn2;     /* mode 2: (xf_b, xf_c2) likewise, the second BatchNorm (normalised downsample branch) */
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
@@ -323,8 +283,6 @@ int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* x, const fl
                       int dtype, void* stream);
 /* rows [nrows][2][C] (fp64 accumulation, one launch of C/4 workgroups) -> a = gamma*invstd, b = -a*invstd*sum(g*xhat)/npix,
  * c = -a*sum(g)/npix - b*mean; dgamma = sum g*xhat, dbeta = sum g (both or neither NULL); npix = elements per channel. */
-/* the vectors of a descriptor's BatchNorm from its table, for consumers that do not compute them themselves (desc_dev: device pointer) */
-int gdrn_bn_finish(const gdrn_bn_desc* desc_dev, int C, void* stream);
 int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long npix, const float* gamma, const float* mean,
                      const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream);
 int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,

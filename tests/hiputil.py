@@ -78,7 +78,7 @@ def pack_dgrad(w, dt, flip, rows_valid_pad=None, cout_p=None):
 
 
 def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt, mode=0, bias=None, addend=None, act=0,
-              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None, v3=False, reps=0, stats_bn=None, bnb_bn=None):
+              out_f32=0, y_cs=None, want_stats=False, halo=False, bnb=None, xf=None, v3=False, reps=0):
     """bnb (halo and generic kernel, bf16): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
     the second return value is then the [tiles][2][Cout] rows buffer.
     xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging.
@@ -110,11 +110,8 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.xf_mode, cp.xf_relu = xf["mode"], 1 if xf.get("relu") else 0
         cp.xf_x2, cp.xf_a, cp.xf_b, cp.xf_c, cp.xf_c2 = ptr(xf.get("x2")), ptr(xf.get("a")), ptr(xf.get("b")), ptr(xf.get("c")), ptr(xf.get("c2"))
         cp.xf_msc, cp.xf_msh, cp.xf_out = ptr(xf.get("msc")), ptr(xf.get("msh")), ptr(xf.get("out"))
-        cp.xf_bn, cp.xf_bn2 = xf.get("bn"), xf.get("bn2")   # device pointers of gdrn_bn_desc: coefficient vectors computed in the prologue
     stats = None
-    if stats_bn is not None:   # device pointer of a gdrn_bn_desc: the epilogue finishes the forward statistics itself (csrc/bn_tail.h)
-        cp.stats_bn = stats_bn
-    elif want_stats:
+    if want_stats:
         rows = (lib.gdrn_conv3x3_stats_rows if halo else lib.gdrn_conv_stats_rows)(C.byref(cp))
         stats = torch.zeros(rows, 2, Cout, dtype=torch.float32, device=DEV)
         cp.stats = ptr(stats)
@@ -125,8 +122,6 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
         cp.bnb_mean, cp.bnb_invstd, cp.bnb_scale, cp.bnb_shift = ptr(bnb["mean"]), ptr(bnb["invstd"]), ptr(bnb.get("scale")), ptr(bnb.get("shift"))
         cp.bnb_rows = ptr(rows_t)
         stats = rows_t  # per-tile rows [nrows][2][Cout]: callers sum over dim 0
-        if bnb_bn is not None:   # ... the BatchNorm-backward sums likewise
-            cp.bnb_rows, cp.bnb_bn = None, bnb_bn
     fn = lib.gdrn_conv3x3_halo if halo else lib.gdrn_conv_gemm
     check(fn(C.byref(cp), stream()), "conv")
     torch.cuda.synchronize()

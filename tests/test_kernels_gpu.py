@@ -390,115 +390,6 @@ def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind, v3):
         assert H.rel(got[0], g0.sum((0, 2, 3))) < 1e-2 and H.rel(got[1], (g0 * xhat).sum((0, 2, 3))) < 1e-2
 
 
-@pytest.mark.parametrize("v3", [False, True])
-@pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (5, 512, 512, 8), (2, 256, 256, 64)])
-def test_batchnorm_statistics_through_the_fixed_point_tables(H, case, v3):
-    """csrc/bn_sums.h: a producer conv adds its per-tile sums to the BatchNorm's fixed-point integer table (gdrn_conv_params.stats_bn / bnb_bn)
-    instead of writing per-tile rows; (a) gdrn_bn_finish turns the table into the vectors -- equal to the rows + gdrn_bn_finalize /
-    gdrn_bn_bwd_coef result to ~1e-7 (rows: fp64 sums of fp32 partials; table: 2^-24 / 2^-40 steps), bit-identical between repeats whatever the
-    arrival order of the workgroups; (b) a consumer conv that applies the BatchNorm while staging (xf modes 1 and 3) computes the same vectors
-    in its prologue from the table (xf_bn): its output and the vectors its workgroup 0 stores are BIT-IDENTICAL to the launch that reads the
-    gdrn_bn_finish vectors from memory; the running statistics and num_batches_tracked move exactly once per use."""
-    from gdrnet_amd.cabi import BN_SLOTS, BnDesc, to_device_table
-
-    lib = cabi.load(BF16)
-    B, I, O, Hh = case
-    if v3 and (I % 128 or O % 128 or Hh % 16):
-        pytest.skip("second-generation kernel: 128-channel tiles, 16-pixel rows")
-    dt, dev = BF16, H.DEV
-    d = lambda t: t.to(dev)
-    x = H.rounded(H.randn(290, B, I, Hh, Hh), dt)
-    w = H.rounded(H.randn(291, O, I, 3, 3) / math.sqrt(I * 9), dt)
-    w2 = H.rounded(H.randn(296, I, O, 3, 3) / math.sqrt(O * 9), dt)   # the consumer conv: O -> I channels
-    gam, bet = torch.rand(O, generator=torch.Generator().manual_seed(292)) + 0.5, H.randn(293, O) * 0.3
-    npix = B * Hh * Hh
-    xd, wp, wp2 = H.nhwc(x, dt), H.pack_fwd(w, dt), H.pack_fwd(w2, dt)
-    gd, bd = d(gam), d(bet)
-    mk = lambda: torch.zeros(O, device=dev)
-
-    def vecs():
-        return dict(mean=mk(), invstd=mk(), scale=mk(), shift=mk(), rm=mk(), rv=torch.ones(O, device=dev), nbt=torch.zeros((), dtype=torch.int64, device=dev))
-
-    def fwd_desc(v, sums=None):
-        sums = torch.zeros(BN_SLOTS * 2 * O, dtype=torch.int64, device=dev) if sums is None else sums
-        desc = BnDesc(sums=ptr(sums), C=O, kind=0, count=float(npix), eps=1e-5, momentum=0.1, gamma=ptr(gd), beta=ptr(bd), running_mean=ptr(v["rm"]),
-                      running_var=ptr(v["rv"]), nbt=ptr(v["nbt"]), mean=ptr(v["mean"]), invstd=ptr(v["invstd"]), scale=ptr(v["scale"]), shift=ptr(v["shift"]))
-        return sums, to_device_table([desc], dev)
-
-    # ---- forward statistics.  Reference: per-tile rows + gdrn_bn_finalize
-    y0, rows = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, want_stats=True, v3=v3)
-    ref = vecs()
-    check(lib.gdrn_bn_finalize(ptr(rows), rows.shape[0], O, float(npix), ptr(gd), ptr(bd), ptr(ref["rm"]), ptr(ref["rv"]), ptr(ref["nbt"]), 0.1, 1e-5,
-                               ptr(ref["mean"]), ptr(ref["invstd"]), ptr(ref["scale"]), ptr(ref["shift"]), None, H.stream()), "bn_finalize")
-    # (a) table + gdrn_bn_finish, twice from a cleared table
-    fin = vecs()
-    sums, tab = fwd_desc(fin)
-    first = None
-    for rep in range(2):
-        sums.zero_()
-        y1, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, stats_bn=tab.data_ptr(), v3=v3)
-        check(lib.gdrn_bn_finish(tab.data_ptr(), O, H.stream()), "bn_finish")
-        torch.cuda.synchronize()
-        assert torch.equal(y1, y0)
-        for k in ("mean", "invstd", "scale", "shift"):
-            assert H.rel(fin[k], ref[k]) < 1e-6, (k, rep)
-        if first is None:
-            first = {k: fin[k].clone() for k in ("mean", "invstd", "scale", "shift")}
-            assert H.rel(fin["rm"], ref["rm"]) < 1e-6 and H.rel(fin["rv"], ref["rv"]) < 1e-6 and int(fin["nbt"].item()) == 1
-        else:
-            assert all(torch.equal(fin[k], first[k]) for k in first) and int(fin["nbt"].item()) == 2
-    # (b) the consumer conv (mode 1: relu(scale * y + shift) while staging) with the vectors from memory against xf_bn
-    out_a = torch.full((B, Hh, Hh, O), float("nan"), dtype=H.tdt(dt), device=dev)
-    ya, _ = H.conv_gemm(y1, wp2, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3,
-                        xf=dict(mode=1, relu=True, a=fin["scale"], c=fin["shift"], out=out_a))
-    pro = vecs()
-    _, tab_p = fwd_desc(pro, sums)          # the same (still filled) table, its own output vectors
-    out_b = torch.full((B, Hh, Hh, O), float("nan"), dtype=H.tdt(dt), device=dev)
-    yb, _ = H.conv_gemm(y1, wp2, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3,
-                        xf=dict(mode=1, relu=True, bn=tab_p.data_ptr(), out=out_b))
-    torch.cuda.synchronize()
-    assert torch.equal(ya, yb) and torch.equal(out_a, out_b)
-    for k in ("mean", "invstd", "scale", "shift"):
-        assert torch.equal(pro[k], first[k]), k
-    assert int(pro["nbt"].item()) == 1 and H.rel(pro["rm"], ref["rm"]) < 1e-6
-    # ---- backward sums: data-gradient launch with the fused BatchNorm-backward epilogue (addend + affine mask)
-    bx = H.rounded(H.randn(294, B, O, Hh, Hh) * 1.5 + 0.3, dt)
-    bnb = dict(x=H.nhwc(bx, dt), mean=ref["mean"], invstd=ref["invstd"], scale=ref["scale"], shift=ref["shift"])
-    yb0, brows = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, bnb=bnb, v3=v3)
-    rc = {k: mk() for k in ("ka", "kb", "kc", "dg", "db")}
-    check(lib.gdrn_bn_bwd_coef(ptr(brows), brows.shape[0], O, npix, ptr(gd), ptr(ref["mean"]), ptr(ref["invstd"]), ptr(rc["ka"]), ptr(rc["kb"]),
-                               ptr(rc["kc"]), ptr(rc["dg"]), ptr(rc["db"]), H.stream()), "bn_bwd_coef")
-
-    def bwd_desc(v, sums_t):
-        desc = BnDesc(sums=ptr(sums_t), C=O, kind=1, count=float(npix), eps=1e-5, momentum=0.1, gamma=ptr(gd), mean=ptr(ref["mean"]),
-                      invstd=ptr(ref["invstd"]), ka=ptr(v["ka"]), kb=ptr(v["kb"]), kc=ptr(v["kc"]), dgamma=ptr(v["dg"]), dbeta=ptr(v["db"]))
-        return to_device_table([desc], dev)
-
-    gc = {k: mk() for k in rc}
-    sums2 = torch.zeros(BN_SLOTS * 2 * O, dtype=torch.int64, device=dev)
-    tab2 = bwd_desc(gc, sums2)
-    yb1, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, bnb=bnb, bnb_bn=tab2.data_ptr(), v3=v3)
-    check(lib.gdrn_bn_finish(tab2.data_ptr(), O, H.stream()), "bn_finish")
-    torch.cuda.synchronize()
-    assert torch.equal(yb1, yb0)
-    for k in rc:
-        assert H.rel(gc[k], rc[k]) < 2e-6, (k, H.rel(gc[k], rc[k]))
-    # consumer with mode 3 (dx = a*g + b*x + c while staging): vectors from memory against the table
-    g_in = yb1                                   # the masked gradient the producer stored
-    out_c = torch.full((B, Hh, Hh, O), float("nan"), dtype=H.tdt(dt), device=dev)
-    yc, _ = H.conv_gemm(g_in, wp2, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3,
-                        xf=dict(mode=3, x2=bnb["x"], a=gc["ka"], b=gc["kb"], c=gc["kc"], out=out_c))
-    pc = {k: mk() for k in rc}
-    tab3 = bwd_desc(pc, sums2)
-    out_d = torch.full((B, Hh, Hh, O), float("nan"), dtype=H.tdt(dt), device=dev)
-    yd, _ = H.conv_gemm(g_in, wp2, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3,
-                        xf=dict(mode=3, x2=bnb["x"], bn=tab3.data_ptr(), out=out_d))
-    torch.cuda.synchronize()
-    assert torch.equal(yc, yd) and torch.equal(out_c, out_d)
-    for k in rc:
-        assert torch.equal(pc[k], gc[k]), k
-
-
 @pytest.mark.parametrize("kind", ["out1x1", "s2_dgrad", "convT_dgrad"])
 def test_conv_gemm_fused_bn_backward_stats(H, kind):
     """the same fused BatchNorm(+ReLU)-backward epilogue on the generic kernel, for the data gradients that do not run on the halo
