@@ -350,9 +350,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                 const size_t o = ((size_t)(n * Ho + oy) * Wo + ox) * C + cv * V;
                 float d[V];
                 Vec16<T>::load(dy + o, d);
-                const unsigned char* ip = idx + o;
+                // the V tap indices of the vector as ONE 4- / 8-byte load (written that way by the forward kernel; byte loads were 8 separate
+                // memory instructions per window, 32 per input pixel)
+                unsigned long long pk;
+                if constexpr (V == 8) pk = *reinterpret_cast<const unsigned long long*>(idx + o);
+                else pk = *reinterpret_cast<const unsigned int*>(idx + o);
 #pragma unroll
-                for (int j = 0; j < V; ++j) if (ip[j] == tap) acc[j] += d[j];
+                for (int j = 0; j < V; ++j) if ((int)((pk >> (8 * j)) & 0xffull) == tap) acc[j] += d[j];
             }
         }
         Vec16<T>::load(x + (size_t)i * V, xv);

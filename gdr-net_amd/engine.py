@@ -106,6 +106,7 @@ class Engine:
         self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
         self.wgrad_w128_grid = int(_os.environ.get("GDRN_W128_GRID", "128"))           # resident workgroups of a launch that runs under a chain
         self.wgrad_w128_grid_last = int(_os.environ.get("GDRN_W128_GRID_LAST", "0"))   # ... of the last bucket's launch (0: all)
+        self.wgrad_w128_only_last = _os.environ.get("GDRN_W128_ONLY_LAST", "0") == "1"  # the wide tile only where nothing runs beside it
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
@@ -883,7 +884,8 @@ class Plan:
             last_bucket = bkt == len(first_group) - 1
             # two kernels: layers with Cout % 128 == 0 can take the 128 x 64 tile (one wave per SIMD, accumulators in the AGPRs: a resident
             # workgroup owns its CU), the others the 64 x 64 tile; one grouped launch per kind and bucket
-            wide = [it for it in items_all if e.wgrad_w128 and it[1].Cout % 128 == 0 and (e.wgrad_w128 > 1 or it[1].stride == 1)]
+            wide = [it for it in items_all if e.wgrad_w128 and it[1].Cout % 128 == 0 and (e.wgrad_w128 > 1 or it[1].stride == 1)
+                    and (last_bucket or not e.wgrad_w128_only_last)]
             for kind, items in ((1, wide), (0, [it for it in items_all if it not in wide])):
                 if not items:
                     continue
