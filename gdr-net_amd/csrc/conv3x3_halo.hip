@@ -45,6 +45,14 @@ __device__ __forceinline__ f32x4_t mma_step<bf16_t>(uint4 a, uint4 b, f32x4_t c)
     return GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c);
 }
 
+// fp32 (parity mode): a 16-byte operand granule = four k-steps of v_mfma_f32_16x16x4_f32 (lane group g supplies k = g of each); ks_ selects the
+// granule's float.  The four MFMAs of one granule pair are issued ACROSS the accumulator tuples (see MM below), not back to back on one.
+__device__ __forceinline__ f32x4_t mma_f32(uint4 a, uint4 b, f32x4_t c, int ks_) {
+    const unsigned av = ks_ == 0 ? a.x : (ks_ == 1 ? a.y : (ks_ == 2 ? a.z : a.w));
+    const unsigned bv = ks_ == 0 ? b.x : (ks_ == 1 ? b.y : (ks_ == 2 ? b.z : b.w));
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av), __uint_as_float(bv), c, 0, 0, 0);
+}
+
 // fragment-major weight packing: granule (16 B) permutation of the row-major [rows][9][Cin] operand
 template <typename T>
 __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int Cin) {
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void pack_wfrag_kernel(const T* __restrict__ s
         // row of block cb, fragment row r: the FNp blocks of a 16*FNp-row group interleave in units of 4 rows, so that the lane of an MFMA
         // result that holds rows 4g..4g+3 of block a = 0 holds the NEXT four rows in block a = 1: 8 contiguous output channels per lane
         // (one 16-byte access in the conv's epilogue instead of two 8-byte ones).  FNp = 1 for the 64-row operands (64-channel tile).
-        const int FNp = rows <= 64 ? 1 : 2, rr = lane & 15;
+        const int FNp = (rows <= 64 || sizeof(T) == 4) ? 1 : 2, rr = lane & 15;   // (fp32: always the 64-channel tile, rows in natural order)
         const int co = (cb / FNp) * 16 * FNp + (rr >> 2) * (4 * FNp) + (cb % FNp) * 4 + (rr & 3), g = lane >> 4;
         const size_t so = ((size_t)(co * 9 + tap) * Cin + (size_t)kc * EPS) + (size_t)(ks * 4 + g) * GE;
         *reinterpret_cast<uint4*>(dst + i * GE) = *reinterpret_cast<const uint4*>(src + so);
@@ -216,6 +224,10 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
     for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fp32 (parity) mode: every 32-deep tap stage accumulates in a fresh register tile that is then added to the running sum, so that no
+    // fp32 addition chain is longer than 32 + #stages (the generic kernel's rule, conv_gemm.hip: the pose parity sits at the fp32
+    // summation-order noise floor); FN = 1 in that mode (64-channel tile), so the second tile costs 32 registers
+    f32x4_t part[sizeof(T) == 4 ? FN : 1][sizeof(T) == 4 ? FM : 1];
 
     // next-chunk patch slices in flight: slice s is loaded at stage s-1 (0 and 1 at stage 0) and written to LDS at stage s+2, i.e.
     // three tap stages (~1500 cycles) after its load: with a single register written one stage later every stage waited on HBM
@@ -275,9 +287,16 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
     }
 #define MM(WQ_, KS_, src_)                                                                                      \
     {                                                                                                           \
-        _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                       \
-            _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                                   \
-                acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + (KS_)], src_[b_], acc[a_][b_]);                          \
+        if constexpr (sizeof(T) == 4) {                                                                         \
+            _Pragma("unroll") for (int k4_ = 0; k4_ < 4; ++k4_)                                                 \
+                _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                               \
+                    _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                           \
+                        part[a_][b_] = mma_f32(WQ_[a_ * 2 + (KS_)], src_[b_], part[a_][b_], k4_);               \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                               \
+                    acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + (KS_)], src_[b_], acc[a_][b_]);                      \
+        }                                                                                                       \
     }
     // stage TAP_ of chunk kc: compute, refill the ring slot for stage +3, move one slice of the next patch
 #define STEP(WQ_, TAP_)                                                                                         \
@@ -288,12 +307,19 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_h
             else if constexpr ((TAP_) <= 7) LOADP(RP((TAP_) + 1), RQ((TAP_) + 1), kc + 1, (TAP_) + 1)           \
         }                                                                                                       \
         RD(fbB, TAP_, 1)                                                                                        \
-        \
+        if constexpr (sizeof(T) == 4) {                                                                         \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) part[a_][b_] = f32x4_t{0.f, 0.f, 0.f, 0.f};   \
+        }                                                                                                       \
         MM(WQ_, 0, fbA)                                                                                         \
         \
         if constexpr ((TAP_) < 8) RD(fbA, (TAP_) + 1, 0)                                                        \
         \
         MM(WQ_, 1, fbB)                                                                                         \
+        if constexpr (sizeof(T) == 4) {                                                                         \
+            _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
+                _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) acc[a_][b_] += part[a_][b_];                  \
+        }                                                                                                       \
         {                                                                                                       \
             constexpr int nt_ = ((TAP_) + 3) % 9;                                                               \
             const int nk_ = kc + (((TAP_) + 3) >= 9 ? 1 : 0);                                                   \
@@ -610,6 +636,11 @@ int launch_tile(const gdrn_conv_params& p, int tw, int bn, int N, hipStream_t st
     return bn == 64 ? launch<bf16_t, 8, 8, 64, XF>(p, N, st) : launch<bf16_t, 8, 8, 128, XF>(p, N, st);
 }
 
+// fp32 (parity mode): the 64-channel tile, no operand transform
+int launch_tile_f32(const gdrn_conv_params& p, int tw, int N, hipStream_t st) {
+    return tw == 16 ? launch<float, 8, 16, 64, 0>(p, N, st) : launch<float, 8, 8, 64, 0>(p, N, st);
+}
+
 }  // namespace
 
 // second-generation kernel (conv3x3_v3.hip), selected by p->w_frag == 2
@@ -638,11 +669,13 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     if (p->w_frag == 2) { gdrn_v3_tile(p, th, tw, bn); return GDRN_OK; }
     if (p->mode != 0 || p->KH != 3 || p->KW != 3 || p->stride != 1 || p->pad != 1 || p->Hi != p->Ho || p->Wi != p->Wo) return GDRN_OK;
     if ((p->Ho % 8) || (p->Wo % 8)) return GDRN_OK;
-    if (p->dtype != GDRN_DT_H16) return GDRN_OK;  // parity (fp32) mode keeps the generic kernel: its per-stage partial
-                                                    // accumulators plus the weight ring do not fit the register file
+    if (p->dtype != GDRN_DT_H16 && p->dtype != GDRN_DT_F32) return GDRN_OK;
     *th = 8;
     *tw = (p->Wo % 16 == 0) ? 16 : 8;
-    *bn = p->Cout <= 64 ? 64 : 128;
+    // parity (fp32) mode: always the 64-channel tile -- its per-stage partial accumulators (see the kernel) double the accumulator
+    // registers, which the 128-channel tile cannot afford; v_mfma_f32_16x16x4_f32 is 16x slower than the 16-bit forms, so the tile's
+    // higher LDS / weight traffic per MFMA does not matter
+    *bn = (p->Cout <= 64 || p->dtype == GDRN_DT_F32) ? 64 : 128;
     // (measured and rejected: 4x16-pixel tiles -- 164 VGPRs, three workgroups per CU -- are 4 % slower over the step; 64-channel tiles
     //  for the small grids of the 8x8 / 16x16 maps: +0.1 ms.  The channel tile is a function of Cout alone: gdrn_pack_wfrag's row
     //  order depends on it.)
@@ -693,6 +726,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
         if ((unsigned long long)p.M * (unsigned long long)p.bnb_cs * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;
     }
     if ((unsigned long long)p.M * (unsigned long long)std::max(p.y_cs, p.add_cs) * 4ull >= (1ull << 32)) return GDRN_ERR_SHAPE;  // 32-bit offsets
+    if (p.dtype == GDRN_DT_F32 && (p.xf_mode || p.bnb_x)) return GDRN_ERR_ARG;   // transforms / fused BatchNorm-backward epilogue: 16-bit only
     if (p.xf_mode) {  // operand transform while staging
         if (p.xf_mode < 0 || p.xf_mode > 4 || !p.xf_c || p.Cin > XF_MAX_CIN || (p.Cin & 7)) return GDRN_ERR_ARG;
         if (p.xf_mode >= 2 && !p.xf_x2) return GDRN_ERR_ARG;
@@ -701,6 +735,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     }
     const int N = p.M / hw;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.dtype == GDRN_DT_F32) return launch_tile_f32(p, tw, N, st);
     switch (p.xf_mode) {
         case 0: return launch_tile<0>(p, tw, bn, N, st);
         case 1: return launch_tile<1>(p, tw, bn, N, st);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
                 else { kc = r % kch; r /= kch; }
                 tt = r % 9u;
                 {
-                    const unsigned cbq = r / 9u, rr = lane & 15u, fnp = k.A1 <= 64 ? 1u : 2u;
+                    const unsigned cbq = r / 9u, rr = lane & 15u, fnp = (k.A1 <= 64 || sizeof(T) == 4) ? 1u : 2u;
                     a1 = (cbq / fnp) * 16u * fnp + (rr >> 2) * (4u * fnp) + (cbq % fnp) * 4u + (rr & 3u);
                 }
                 a2 = 0;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
             const int kc = (int)(r % kch); r /= kch;
             tt = (int)(r % 9);
             {
-                const int cbq = (int)(r / 9), rr = lane & 15, fnp = k.A1 <= 64 ? 1 : 2;
+                const int cbq = (int)(r / 9), rr = lane & 15, fnp = (k.A1 <= 64 || sizeof(T) == 4) ? 1 : 2;
                 a1 = (cbq / fnp) * 16 * fnp + (rr >> 2) * (4 * fnp) + (cbq % fnp) * 4 + (rr & 3);
             }
             a2 = 0;

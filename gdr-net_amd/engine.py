@@ -67,7 +67,10 @@ class Engine:
         self.nreg = num_regions
         import os as _os
 
-        self.use_halo = self.h16  # 3x3 stride-1 convs on the halo-tiled kernel (bf16); the fp32 parity mode keeps the generic one
+        # 3x3 stride-1 convs (forward and data gradient) on the halo-tiled kernel: every arithmetic (fp32 parity mode since r4: 64-channel tile,
+        # v_mfma_f32_16x16x4_f32, per-stage partial accumulators; GDRN_HALO_F32=0 puts that mode back on the generic kernel); operand
+        # transforms and the fused BatchNorm-backward epilogue exist for the 16-bit formats only
+        self.use_halo = self.h16 or _os.environ.get("GDRN_HALO_F32", "1") != "0"
         # bucket-end work (grouped weight gradients, their reduction, gradient unpack) on a 2nd stream: it runs under the next bucket's chain of
         # small-map data-gradient kernels (one workgroup per CU, matrix pipe ~20 % busy); same-box A/B: 8.05 -> 7.85 ms/step with the LDS request
         # below, 7.77 with the optimizer update of a bucket behind its reduction on that stream (GDRN.train_step, GDRN_EARLY_OPT)
@@ -81,7 +84,7 @@ class Engine:
         self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
         # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
-        self.fuse_xf = self.use_halo and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
+        self.fuse_xf = self.h16 and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
         # BatchNorm-backward mask + sums also in the generic kernel's epilogue (1x1 output conv, stride-2 / transposed data gradients)
         self.gemm_bnb = self.h16 and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
@@ -231,7 +234,7 @@ class Engine:
         # operand layouts of the two halo operands: 1 = gdrn_pack_wfrag, 2 = gdrn_pack_wfrag32 (second-generation kernel); chosen by the
         # library per launch (gdrn_conv3x3_wfrag) when the first plan that uses the operand is built (Plan._conv)
         L.wfmt = {"f": 0, "d": 0}
-        if kind == "conv" and KK == 9 and not s2 and self.h16:  # halo-kernel operands (fragment-major)
+        if kind == "conv" and KK == 9 and not s2 and self.use_halo:  # halo-kernel operands (fragment-major)
             L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
         self.layers[key] = L
         return L
@@ -794,7 +797,7 @@ class Plan:
     def _fusable(self, L):
         """can the data gradient of layer L run on the halo kernel (and so carry a fused BN-backward reduction)?"""
         e = self.e
-        return e.use_halo and L.kind == "conv" and L.wfF is not None
+        return e.use_halo and e.h16 and L.kind == "conv" and L.wfF is not None
 
     def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False, apply=True):
         """BatchNorm(+ReLU) backward: [reduce -> coef ->] apply.  prereduced: dy arrives masked and the producing data-gradient

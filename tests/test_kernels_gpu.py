@@ -79,10 +79,11 @@ def _v3_small_grids(monkeypatch):
     monkeypatch.setenv("GDRN_V3_MINWG", "1")
 
 
-@pytest.mark.parametrize("dt", [BF16])
-@pytest.mark.parametrize("v3,case", [(False, c) for c in HALO_CASES] + [(True, c) for c in V3_CASES])
+@pytest.mark.parametrize("dt,v3,case", [(BF16, False, c) for c in HALO_CASES] + [(BF16, True, c) for c in V3_CASES] +
+                         ([] if IS_F16 else [(F32, False, c) for c in HALO_CASES]))
 def test_conv3x3_halo_forward_and_dgrad(H, dt, case, v3):
-    """halo-tiled 3x3 s1 kernels: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights)."""
+    """halo-tiled 3x3 s1 kernels: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights).  fp32 (parity
+    mode, r4): the 64-channel tile on v_mfma_f32_16x16x4_f32 with per-stage partial accumulators, against fp32 torch at 2e-5."""
     B, I, O, Hh = case
     x = H.rounded(H.randn(1, B, I, Hh, Hh), dt).requires_grad_(True)
     w = H.rounded(H.randn(2, O, I, 3, 3) / math.sqrt(I * 9), dt)
