@@ -103,7 +103,7 @@ extern "C" int gdrn_halo_set_dbg(unsigned long long* buf) { return hipMemcpyToSy
 #endif
 
 template <typename T, int TH, int TW, int BN, int XF>
-__global__ __launch_bounds__(256, (BN == 64 && TW == 16) ? 3 : 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
+__global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 : 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
     constexpr int EPS = ROWB / (int)sizeof(T);
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
@@ -638,7 +638,7 @@ int launch_tile(const gdrn_conv_params& p, int tw, int bn, int N, hipStream_t st
 
 // fp32 (parity mode): the 64-channel tile, no operand transform
 int launch_tile_f32(const gdrn_conv_params& p, int tw, int N, hipStream_t st) {
-    return tw == 16 ? launch<float, 8, 16, 64, 0>(p, N, st) : launch<float, 8, 8, 64, 0>(p, N, st);
+    return tw == 8 ? launch<float, 8, 8, 64, 0>(p, N, st) : GDRN_ERR_SHAPE;
 }
 
 }  // namespace
@@ -671,10 +671,10 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     if ((p->Ho % 8) || (p->Wo % 8)) return GDRN_OK;
     if (p->dtype != GDRN_DT_H16 && p->dtype != GDRN_DT_F32) return GDRN_OK;
     *th = 8;
-    *tw = (p->Wo % 16 == 0) ? 16 : 8;
-    // parity (fp32) mode: always the 64-channel tile -- its per-stage partial accumulators (see the kernel) double the accumulator
-    // registers, which the 128-channel tile cannot afford; v_mfma_f32_16x16x4_f32 is 16x slower than the 16-bit forms, so the tile's
-    // higher LDS / weight traffic per MFMA does not matter
+    *tw = (p->Wo % 16 == 0 && p->dtype != GDRN_DT_F32) ? 16 : 8;
+    // parity (fp32) mode: always the 8x8-pixel x 64-channel tile -- its per-stage partial accumulators (see the kernel) double the accumulator
+    // registers (the 8x16 tile spills 160+ registers with them, the 128-channel tile cannot hold them at all); v_mfma_f32_16x16x4_f32 is
+    // 16x slower than the 16-bit forms, so the small tile's higher LDS / weight traffic per MFMA does not matter
     *bn = (p->Cout <= 64 || p->dtype == GDRN_DT_F32) ? 64 : 128;
     // (measured and rejected: 4x16-pixel tiles -- 164 VGPRs, three workgroups per CU -- are 4 % slower over the step; 64-channel tiles
     //  for the small grids of the 8x8 / 16x16 maps: +0.1 ms.  The channel tile is a function of Cout alone: gdrn_pack_wfrag's row
