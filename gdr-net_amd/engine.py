@@ -567,7 +567,13 @@ class Plan:
         ref = C.byref(cp)
         if e.use_halo and L.kind == "conv" and L.wfF is not None:
             which = "e" if evalw else ("f" if w is None else "d")
+            # the operand's layout is a property of the LAYER, not of whichever plan happens to be built first (a bs = 4 smoke
+            # plan used to pin the first halo kernel's layout for the bs = 64 training plan): the library is asked at the canonical batch
+            # size of the path (64 RoIs) unless this plan is bigger
+            m_plan = cp.M
+            cp.M = max(cp.M, 64 * Ho * Wo)
             want = int(e.lib.gdrn_conv3x3_wfrag(ref))
+            cp.M = m_plan
             if not L.wfmt.get(which):
                 L.wfmt[which] = want if want in (1, 2) else 1
                 e._pack_dirty = True    # the operand copy is (re)built in that layout by the next repack
