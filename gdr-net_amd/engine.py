@@ -39,6 +39,10 @@ def _ru(a, b):
     return (a + b - 1) // b * b
 
 
+def _os_env(name, default):
+    return os.environ.get(name, default)
+
+
 class Engine:
     """Owns the packed (kernel-layout) weight copies and the per-batch-size plans for one GDRN module."""
 
@@ -1393,8 +1397,21 @@ class Plan:
         else:
             op, _ = self._conv(L1, g2act, 128, f1, 8, 8, 1, 1, 1, 0, bias=b1, act=2, cin=128, cout=1024)
             self.fwd.append(op)
-        op, _ = self._conv(L2, f1, 1024, f2, 1, 1, 1, 1, 1, 0, bias=b2, act=2, cin=1024, cout=256)
-        self.fwd.append(op)
+        if e.h16 and B <= 64 and e.fc_splitk and _os_env("GDRN_FC2_SPLITK", "1") != "0":
+            # fc2 (64 x 1024 -> 256) on the gather kernel is two workgroups walking K = 1024 serially (20 us for 34 MFLOP): the same split-K
+            # kernel, 16 column tiles x 8 K ranges (r4)
+            ws2 = e._zeros(16 * B * 256 + 64, dtype=F32t)
+            self.keep.append(ws2)
+
+            def fc2_fwd(st, ctx):
+                check(lib.gdrn_linear_splitk(ptr(f1), ptr(L2.wf), ptr(b2), ptr(f2), B, 1024, 256, 1024, 1024, 256, 2, ptr(ws2), e.dt, st),
+                      "linear_splitk fc2")
+
+            fc2_fwd.meta = dict(kernel="linear_splitk_kernel", flops=2.0 * B * 1024 * 256, layer="pnp_net.fc2")
+            self.fwd.append(fc2_fwd)
+        else:
+            op, _ = self._conv(L2, f1, 1024, f2, 1, 1, 1, 1, 1, 0, bias=b2, act=2, cin=1024, cout=256)
+            self.fwd.append(op)
         op, _ = self._conv(L3, f2, 256, self.fc_out, 1, 1, 1, 1, 1, 0, bias=e.rt_b, out_f32=1, cin=256, cout=9, y_cs=64)
         self.fwd.append(op)
         if T:

@@ -372,7 +372,10 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
         eng = model.engine()
         assert eng.fuse_xf == (fx == "1")
         plan = eng.plan(B, True, True)
-        n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith("conv3x3_halo") and not op.meta["kernel"].endswith(",0>"))
+        # (both halo kernels: since r4 a layer's operand layout -- hence its kernel -- is chosen at the canonical batch size, so the five
+        #  256-channel head launches with a transform run the second-generation kernel at bs = 4 as they do at bs = 64)
+        n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith(("conv3x3_halo", "conv3x3_v3"))
+                   and not op.meta["kernel"].endswith(",0>"))
         assert n_xf == (67 if fx == "1" else 0), n_xf
         res[fx] = (losses.cpu(), {k: v.float().cpu().clone() for k, v in plan.tensors.items()}, {n: g.cpu().clone() for n, g in eng.grads.items()},
                    plan.head_out.cpu().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
