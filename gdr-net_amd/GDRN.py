@@ -704,15 +704,20 @@ def _hub_dir():
 
 
 def _resolve_pretrained(pre):
-    """"torchvision://resnet34" / "open-mmlab://resnet34" (configs/_base_/gdrn_base.py:21) -> the file torch hub / mmcv would have downloaded,
-    if it is in the local hub cache ($TORCH_HOME/hub/checkpoints/resnet34-*.pth); None otherwise (no network access here)."""
+    """"torchvision://resnet34" (configs/_base_/gdrn_base.py:21) -> the file torch hub would have downloaded, if it is in the local hub cache
+    ($TORCH_HOME/hub/checkpoints/resnet34-<hash>.pth) and unambiguous; None otherwise (no network access here).  Only the torchvision scheme:
+    mmcv's "open-mmlab://" / "modelzoo://" zoo holds DIFFERENT (caffe-style) weights under the same model names -- mapping those names onto a
+    torchvision file would load the wrong backbone silently (strict=False), so they fall through to the FileNotFoundError."""
     import glob
 
-    for scheme in ("torchvision://", "open-mmlab://", "modelzoo://"):
-        if pre.startswith(scheme):
-            hits = sorted(glob.glob(os.path.join(_hub_dir(), "checkpoints", pre[len(scheme):] + "-*.pth")))
-            return hits[0] if hits else None
-    return None
+    scheme = "torchvision://"
+    if not pre.startswith(scheme):
+        return None
+    hits = sorted(glob.glob(os.path.join(_hub_dir(), "checkpoints", pre[len(scheme):] + "-*.pth")))
+    if len(hits) > 1:
+        logger.warning("several hub-cache files match %s: %s -- point PRETRAINED at the one you mean", pre, hits)
+        return None
+    return hits[0] if hits else None
 
 
 def build_optimizer_with_params(cfg, params):

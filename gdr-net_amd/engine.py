@@ -202,7 +202,7 @@ class Engine:
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
     # ------------------------------------------------------------------------------------------ layers
-    def _add_conv(self, key, kind, src_names, O, I, KH, KW, in_ch=None, out_ch=None, s2=False, hw=0):
+    def _add_conv(self, key, kind, src_names, O, I, KH, KW, in_ch=None, out_ch=None, s2=False):
         """kind: conv | convT | stem | fc1 | fc.  in_ch/out_ch: channel counts of the activation buffers
         (>= I / O, padded).  Packed operands:
           wf [rows_f][KK][cin_f]  forward operand          (rows = out channels)
@@ -251,17 +251,15 @@ class Engine:
         for li, (nb, pl) in enumerate(zip(RESNET34_LAYERS, RESNET34_PLANES), start=1):
             for b in range(nb):
                 p = f"backbone.layer{li}.{b}"
-                self._add_conv(p + ".conv1", "conv", [p + ".conv1.weight"], pl, inpl, 3, 3, s2=(b == 0 and li > 1), hw=64 >> (li - 1))
-                self._add_conv(p + ".conv2", "conv", [p + ".conv2.weight"], pl, pl, 3, 3, hw=64 >> (li - 1))
+                self._add_conv(p + ".conv1", "conv", [p + ".conv1.weight"], pl, inpl, 3, 3, s2=(b == 0 and li > 1))
+                self._add_conv(p + ".conv2", "conv", [p + ".conv2.weight"], pl, pl, 3, 3)
                 if (p + ".downsample.0.weight") in self.P:
                     self._add_conv(p + ".downsample.0", "conv", [p + ".downsample.0.weight"], pl, inpl, 1, 1, s2=True)
                 inpl = pl
         h = "rot_head_net.features."
         self._add_conv(h + "0", "convT", [h + "0.weight"], 256, 512, 3, 3)
-        hw = 16
         for ci, _, up in HEAD_CONVS:
-            hw = hw * 2 if up else hw
-            self._add_conv(h + str(ci), "conv", [h + f"{ci}.weight"], 256, 256, 3, 3, hw=hw)
+            self._add_conv(h + str(ci), "conv", [h + f"{ci}.weight"], 256, 256, 3, 3)
         self.head_c = 1 + 3 + self.nreg + 1
         self._add_conv(h + "23", "conv", [h + "23.weight"], self.head_c, 256, 1, 1, out_ch=128)
         q = "pnp_net.features."
@@ -466,6 +464,10 @@ def make_stream(dev, prio="normal"):
     default- and higher-priority streams): created with hipStreamCreateWithPriority and wrapped; its kernels are dispatched behind those
     of default-priority streams and it never shares a hardware queue with them."""
     global _hip_rt
+    # Streams made here live as long as the process (a raw HIP stream wrapped in an ExternalStream is never destroyed): one per engine /
+    # reducer, a handful per process.  Callbacks the engine invokes for a finished gradient bucket (`model._on_bucket`) run with the SIDE
+    # stream current, not the compute stream: work they enqueue is ordered behind the bucket's weight gradients, and whoever consumes its
+    # results on another stream has to wait for it (GradReducer.on_bucket records an event for that).
     if prio == "high":
         return torch.cuda.Stream(device=dev, priority=-1)
     if prio != "low":

@@ -220,6 +220,15 @@ def test_pretrained_backbone_is_resolved_from_the_hub_cache_or_refused(tmp_path,
     cfg2.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
     m, _ = GDRN.build_model_optimizer(cfg2)
     assert float(m.backbone.layer1[0].conv1.weight.mean()) == 0.25
+    # mmcv's zoo names are NOT torchvision's files (different, caffe-style weights under the same model name): refused, not mapped
+    cfg3 = lm13_cfg(device="cpu")
+    cfg3.MODEL.CDPN.BACKBONE.PRETRAINED = "open-mmlab://resnet34"
+    with pytest.raises(FileNotFoundError):
+        GDRN.build_model_optimizer(cfg3)
+    # two candidate files: ambiguous, refused
+    torch.save(sd, tmp_path / "hub" / "checkpoints" / "resnet34-333f7ec4.pth")
+    with pytest.raises(FileNotFoundError):
+        GDRN.build_model_optimizer(cfg2)
 
 
 def test_fp16_library_build_exports_the_same_abi():
