@@ -227,8 +227,10 @@ def test_pretrained_backbone_is_resolved_from_the_hub_cache_or_refused(tmp_path,
         GDRN.build_model_optimizer(cfg3)
     # two candidate files: ambiguous, refused
     torch.save(sd, tmp_path / "hub" / "checkpoints" / "resnet34-333f7ec4.pth")
+    cfg4 = lm13_cfg(device="cpu")   # (a built config is consumed: build_model_optimizer pops PNP_HEAD_CFG.type, as GDRN.py:658-659)
+    cfg4.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
     with pytest.raises(FileNotFoundError):
-        GDRN.build_model_optimizer(cfg2)
+        GDRN.build_model_optimizer(cfg4)
 
 
 def test_fp16_library_build_exports_the_same_abi():
