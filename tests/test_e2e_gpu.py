@@ -361,6 +361,10 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
     B = 4
     batch = to_dev(synth.make_batch(B, seed=5))
     res = {}
+    # both plans on the FIRST halo kernel: the second-generation kernel takes a launch only when it carries a transform, so with it the two
+    # plans would run five head convs on different kernels (different summation order, no bit equality to expect); its transforms are held
+    # to the same arithmetic by tools/v3check.py (xf_out bit-equal to the first kernel's) and by the teacher-forced test's all-v3 plans
+    monkeypatch.setenv("GDRN_V3", "0")
     for fx in ("0", "1"):
         monkeypatch.setenv("GDRN_FUSE_XF", fx)
         model, _ = build("bf16")
@@ -372,10 +376,7 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
         eng = model.engine()
         assert eng.fuse_xf == (fx == "1")
         plan = eng.plan(B, True, True)
-        # (both halo kernels: since r4 a layer's operand layout -- hence its kernel -- is chosen at the canonical batch size, so the five
-        #  256-channel head launches with a transform run the second-generation kernel at bs = 4 as they do at bs = 64)
-        n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith(("conv3x3_halo", "conv3x3_v3"))
-                   and not op.meta["kernel"].endswith(",0>"))
+        n_xf = sum(1 for op in plan.fwd + plan.bwd if getattr(op, "meta", {}).get("kernel", "").startswith("conv3x3_halo") and not op.meta["kernel"].endswith(",0>"))
         assert n_xf == (67 if fx == "1" else 0), n_xf
         res[fx] = (losses.cpu(), {k: v.float().cpu().clone() for k, v in plan.tensors.items()}, {n: g.cpu().clone() for n, g in eng.grads.items()},
                    plan.head_out.cpu().clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
