@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: measures switches (GDRN_BN_TAIL / GDRN_BN_SUMS) of the BatchNorm-table experiments that lived in commits 012ec22..e111f10 and were
+# removed again (all slower: profiles/r04_bn_statistics_variants.txt); kept as the record of what was run.  Check out e111f10 to re-run.
 # round 4: BatchNorm statistics finished in the halo conv's epilogue (csrc/bn_tail.h) -- kernel test, whole-step tests, A/B
 O=gpurun_out/r4_bntail
 mkdir -p $O
