@@ -288,3 +288,57 @@ def test_bench_gpus2_launches_its_own_ranks_dry_gloo():
 def test_bench_gpus2_without_two_gpus_is_one_json_error_line():
     rc, j = _bench("--gpus", "2", "--steps", "2", "--warmup", "1")
     assert rc != 0 and j["value"] is None and j["n_gpus"] == 2 and "needs 2 visible GPUs" in j["error"]
+
+
+# ---------------------------------------------------------------------------------------------- divergence safety net of the data-parallel step
+def _worker_divergence(rank, world, port, q):
+    """GDRN._dp_divergence_check (the per-bucket optimizer behind the all-reduce has only run with one real rank): ranks holding
+    bit-identical parameters pass, a rank whose parameters differ in ONE element makes every rank raise; after GDRN_DP_CHECK_STEPS checks
+    the function is a no-op (no host synchronisation in steady state)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace as NS
+
+    from gdrnet_amd import GDRN as G
+    from gdrnet_amd.cabi import GdrnHipError
+
+    try:
+        torch.manual_seed(0)
+        P = {"a.weight": torch.nn.Parameter(torch.randn(6, 5)), "b.bias": torch.nn.Parameter(torch.randn(7))}
+        eng = NS(P=P, param_names=list(P))
+        m = NS(_reducer=NS(world=world, group=None, active=True))
+        m.__dict__["_dp_checked"] = 0
+        G.GDRN._dp_divergence_check(m, eng)          # identical replicas: passes, one check consumed
+        assert m.__dict__["_dp_checked"] == 1
+        with torch.no_grad():
+            if rank == 1:
+                P["a.weight"][2, 3] += 1e-6           # one element on one rank
+        try:
+            G.GDRN._dp_divergence_check(m, eng)
+            raised = False
+        except GdrnHipError as ex:
+            raised = "diverged" in str(ex)
+        assert raised                                  # ... on EVERY rank (all of them see the gathered checksums)
+        assert m.__dict__["_dp_checked"] == 2
+        G.GDRN._dp_divergence_check(m, eng)          # the budget of checks (2) is used up: no-op even though the replicas still differ
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_divergence_check_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_divergence, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -565,6 +565,44 @@ def test_low_priority_side_stream_is_a_real_stream_of_lower_priority():
     assert float(z) == 4096.0 ** 2   # sum of (2 i + 1), exact in fp32
 
 
+def test_per_bucket_optimizer_counts_hooks_and_survives_a_failed_backward():
+    """ADVICE r3 on the per-bucket optimizer path of GDRN.train_step (Ranger.step_buckets_*): it must look like ONE optimizer.step() to
+    torch -- step pre / post hooks fire once, `_opt_called` is set (LR schedulers check it), every tensor's step counter advances by one --
+    and an exception inside the backward pass must leave the step counters where they were (they are committed in step_buckets_end)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 4
+    batch = to_dev(synth.make_batch(B, seed=31))
+    kw = synth.model_kwargs(batch, do_loss=True)
+    kw.pop("do_loss")
+    model, opt = build("bf16")
+    model.train()
+    calls = {"pre": 0, "post": 0}
+    opt.register_step_pre_hook(lambda o, a, k: calls.__setitem__("pre", calls["pre"] + 1))
+    opt.register_step_post_hook(lambda o, a, k: calls.__setitem__("post", calls["post"] + 1))
+    model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    torch.cuda.synchronize()
+    steps = {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]}
+    assert steps == {1} and calls == {"pre": 1, "post": 1} and getattr(opt, "_opt_called", False)
+    plan = model.engine().plan(B, True, True)
+    real = plan.run_backward
+
+    def boom(*a, **k):
+        raise RuntimeError("injected failure inside the backward pass")
+
+    plan.run_backward = boom
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    finally:
+        plan.run_backward = real
+    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {1}   # untouched
+    assert calls["post"] == 1 and not opt._bucket_launches                                  # no post hook, nothing left prepared
+    model.train_step(batch["roi_img"], optimizer=opt, **kw)                                 # ... and the next step is a normal one
+    torch.cuda.synchronize()
+    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {2} and calls["post"] == 2
+
+
 def test_per_bucket_optimizer_behind_the_allreduce_one_rank_rccl():
     """The data-parallel train step updates a gradient bucket on the reducer's stream right behind that bucket's all-reduce (and rebuilds the
     bucket's operand copies there), under the rest of the backward pass.  One-rank RCCL group with force=True: the exchange is the identity
