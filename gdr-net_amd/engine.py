@@ -14,7 +14,6 @@ import ctypes as C
 import math
 import os
 from collections import OrderedDict
-import weakref
 from types import SimpleNamespace as NS
 
 import torch
@@ -465,10 +464,12 @@ def make_stream(dev, prio="normal"):
     default- and higher-priority streams): created with hipStreamCreateWithPriority and wrapped; its kernels are dispatched behind those
     of default-priority streams and it never shares a hardware queue with them."""
     global _hip_rt
-    # A raw stream made here is destroyed when its wrapper object is collected (one per engine / reducer; hipStreamDestroy lets enqueued work
-    # finish), not at interpreter exit, where the runtime may already be gone.  Callbacks the engine invokes for a finished gradient bucket
-    # (`model._on_bucket`) run with the SIDE stream current, not the compute stream: work they enqueue is ordered behind the bucket's weight
-    # gradients, and whoever consumes its results on another stream has to wait for it (GradReducer.on_bucket records an event for that).
+    # Streams made here live as long as the process: one per engine / reducer, a handful per process.  (Destroying the raw stream when its
+    # wrapper object is collected was tried in r4 and is unsafe: RCCL keeps using a reducer's stream from its own threads, and objects
+    # collected during interpreter teardown would call into a HIP runtime that is already gone -- both ended in SIGSEGV in the GPU suite.)
+    # Callbacks the engine invokes for a finished gradient bucket (`model._on_bucket`) run with the SIDE stream current, not the compute
+    # stream: work they enqueue is ordered behind the bucket's weight gradients, and whoever consumes its results on another stream has to
+    # wait for it (GradReducer.on_bucket records an event for that).
     if prio == "high":
         return torch.cuda.Stream(device=dev, priority=-1)
     if prio != "low":
@@ -496,12 +497,7 @@ def make_stream(dev, prio="normal"):
 
         logging.getLogger(__name__).warning("low-priority HIP stream unavailable (%s): using a default-priority stream", ex)
         return torch.cuda.Stream(device=dev)
-    ext = torch.cuda.ExternalStream(h.value, device=dev)
-    try:
-        weakref.finalize(ext, _hip_rt.hipStreamDestroy, C.c_void_p(h.value)).atexit = False
-    except TypeError:   # (a torch whose stream objects take no weak references: the stream then lives as long as the process)
-        pass
-    return ext
+    return torch.cuda.ExternalStream(h.value, device=dev)
 
 
 def _probed(op, sink):

@@ -1,6 +1,6 @@
 """rocprofv3 PMC passes -> MFMA utilisation and HBM bandwidth per kernel (profiles/r03_mfma_util_hbm_bs64_bf16.{txt,json}).
 
-  python tools/pmc_util.py <sq_pass.csv> <fetch_pass.csv> <write_pass.csv> <plain_kernel_trace.csv> <calibration_sq_pass.csv> <out prefix>
+  python tools/pmc_util.py <sq_pass.csv> <fetch_pass.csv> <write_pass.csv> <plain_kernel_trace.csv> <calibration_sq_pass.csv> <out prefix> [what was profiled]
 
 * MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE): the counter adds up the cycles the matrix pipe of every SIMD is
   busy (= 32 x the number of v_mfma_f32_32x32x16_bf16, 16 x the 16x16x32 form -- checked against SQ_INSTS_MFMA), GRBM_GUI_ACTIVE the
@@ -80,7 +80,7 @@ def main():
     json.dump(out, open(prefix + ".json", "w"), indent=1, sort_keys=True)
     rows.sort(reverse=True)
     with open(prefix + ".txt", "w") as f:
-        f.write("# MFMA utilisation and HBM bandwidth per kernel of the bs=64 bf16 training step (tools/pmc_util.py; rocprofv3 --pmc passes:\n")
+        f.write("# MFMA utilisation and HBM bandwidth per kernel of the %s (tools/pmc_util.py; rocprofv3 --pmc passes:\n" % (sys.argv[7] if len(sys.argv) > 7 else "bs=64 bf16 training step"))
         f.write("#   SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE, each with --kernel-trace; durations from\n")
         f.write("#   a plain --kernel-trace run, last 4 steps).  mfma_util = MFMA-pipe busy cycles / (SIMDs x active cycles), normalised on a pure-MFMA loop\n")
         f.write("#   = busy / active / 128 (check: the pure-MFMA loop reads %.3f, %.1f busy cycles per MFMA instruction); HBM GB/s = (2 x FETCH_SIZE + WRITE_SIZE) / duration.\n" % (
