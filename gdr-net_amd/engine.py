@@ -141,7 +141,17 @@ class Engine:
         order = list(reversed(self.param_names))
         self.grad_offsets = {}
         off = 0
+        # fc_r | fc_t run as ONE 9-row layer (fc_rt): their bias gradients share one slot, fc_t's right behind fc_r's, so that the layer's single
+        # bias_grad launch writes both in place (every reader -- Ranger, the collectives, .grad -- takes offset + numel, not padded rows)
+        rb, tb = "pnp_net.fc_r.bias", "pnp_net.fc_t.bias"
+        paired = rb in self.P and tb in self.P
         for n in order:
+            if paired and n in (rb, tb):
+                if rb not in self.grad_offsets:
+                    self.grad_offsets[rb] = off
+                    self.grad_offsets[tb] = off + self.P[rb].numel()
+                    off += _ru(self.P[rb].numel() + self.P[tb].numel(), 4)
+                continue
             self.grad_offsets[n] = off
             off += _ru(self.P[n].numel(), 4)
         self.grad_flat = torch.zeros(off, dtype=torch.float32, device=self.dev)
@@ -1424,7 +1434,9 @@ class Plan:
             d_fc = E(B, 64)
             d_f2, d_f2p, d_f1, d_f1p = E(B, 256), E(B, 256), E(B, 1024), E(B, 1024)
             self.tensors.update({"d_fc": d_fc, "pnp_net.fc2.d_act": d_f2, "pnp_net.fc2.d_pre": d_f2p, "pnp_net.fc1.d_act": d_f1, "pnp_net.fc1.d_pre": d_f1p})
-            self._rt_gb_full = e._zeros(12, dtype=F32t)
+            o_rt = e.grad_offsets["pnp_net.fc_r.bias"]   # the two bias gradients' shared slot of the flat gradient buffer (Engine.__init__)
+            assert e.grad_offsets["pnp_net.fc_t.bias"] == o_rt + 6 and o_rt % 4 == 0
+            self._rt_gb_full = e.grad_flat[o_rt:o_rt + 12]
             self.rt_gb = self._rt_gb_full[:9]
             self._zero_regions += [self._rt_gb_full, self._grad16(e.grads["pnp_net.fc1.bias"]), self._grad16(e.grads["pnp_net.fc2.bias"])]
             g_b1, g_b2 = e.grads["pnp_net.fc1.bias"], e.grads["pnp_net.fc2.bias"]
@@ -1435,8 +1447,7 @@ class Plan:
                 lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
                 self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64),
                 self._unpack(L3),
-                lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt | PREZEROED, st), "bias_grad"),
-                lambda st, ctx: torch._foreach_copy_([e.grads["pnp_net.fc_r.bias"], e.grads["pnp_net.fc_t.bias"]], [self.rt_gb[:6], self.rt_gb[6:]]),
+                lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt | PREZEROED, st), "bias_grad"),   # = both .grad views
             ]
             op, _ = self._conv(L3, d_fc, 64, d_f2, 1, 1, 1, 1, 1, 0, w=L3.wd, rows=L3.rows_d, cin=64, cout=256)
             grp.append(op)
