@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
                                                               const float* __restrict__ extents, T* __restrict__ pnp, int pcs,
                                                               const float* __restrict__ gt_xyz, const float* __restrict__ mvis,
                                                               const float* __restrict__ mtr, const long long* __restrict__ gt_region,
-                                                              double* acc, int N, int HW, int write_pad) {
+                                                              double* acc, int N, int HW, int write_pad, int acc_rows) {
     __shared__ float red[6][16];
     const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long long M = (long long)N * HW;
@@ -94,9 +94,25 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
     for (long long m = g0; m < M; m += ng) {
         const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
         const float* h = head + m * hs;
-        float r[4];
+        // EVERY load of the iteration goes out here, by all 16 lanes of the pixel (same address: one request): issued where they are used --
+        // behind the softmax, inside the `q == 0` / `q == 14` branches -- the loss inputs cost a second memory round trip per iteration
+        // (train variant 65 us against 26 us for the eval variant, r4)
+        float r[4], h03[4];
         load4<float>(h + 4 + 4 * q, r);                       // classes 4q .. 4q+3
-        const float r64 = (q == 15) ? h[68] : -INFINITY;      // class 64
+        load4<float>(h, h03);                                 // mask, x, y, z
+        const float h68 = h[68];                              // class 64
+        const float c2x = coord2d[((size_t)n * 2 + 0) * HW + pix], c2y = coord2d[((size_t)n * 2 + 1) * HW + pix];
+        const float ex[3] = {extents[n * 3 + 0], extents[n * 3 + 1], extents[n * 3 + 2]};
+        float mv = 0.f, mt = 0.f, gx[3] = {0.f, 0.f, 0.f};
+        long long gr = 0;
+        if constexpr (LOSS) {
+            mv = mvis[m];
+            mt = mtr[m];
+            gr = gt_region[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gx[c] = gt_xyz[((size_t)n * 3 + c) * HW + pix];
+        }
+        const float r64 = (q == 15) ? h68 : -INFINITY;
         // softmax over classes 1..64 (region[:, 1:])
         float mx = fmaxf(fmaxf(q == 0 ? -INFINITY : r[0], r[1]), fmaxf(fmaxf(r[2], r[3]), r64));
         mx = row16_max(mx);
@@ -108,14 +124,13 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
         const float inv = 1.f / row16_sum(e[0] + e[1] + e[2] + e[3] + e64);
         T* o = pnp + m * pcs;
         float v[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
-        if (q == 0) v[0] = coord2d[((size_t)n * 2 + 1) * HW + pix];   // channel 4 = second roi_coord_2d channel
+        if (q == 0) v[0] = c2y;                                        // channel 4 = second roi_coord_2d channel
         store4<T>(o + 4 + 4 * q, v);                                   // channels 4 + 4q .. 7 + 4q
         if (q == 15) {
             const float w[4] = {e64 * inv, 0.f, 0.f, 0.f};             // channel 68 = class 64, 69..71 pad
             store4<T>(o + 68, w);
         } else if (q == 14) {
-            const float w[4] = {(h[1] - 0.5f) * extents[n * 3 + 0], (h[2] - 0.5f) * extents[n * 3 + 1], (h[3] - 0.5f) * extents[n * 3 + 2],
-                                coord2d[((size_t)n * 2 + 0) * HW + pix]};
+            const float w[4] = {(h03[1] - 0.5f) * ex[0], (h03[2] - 0.5f) * ex[1], (h03[3] - 0.5f) * ex[2], c2x};
             store4<T>(o, w);
         }
         if (write_pad) {
@@ -124,8 +139,7 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
         }
         if constexpr (LOSS) {
             // cross entropy over the 65 classes of logits * visib (GDRN.py:392-400)
-            const float mv = mvis[m];
-            const int tgt = (int)(gt_region[m] * (long long)mv);
+            const int tgt = (int)(gr * (long long)mv);
             float z[4], zt = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -142,9 +156,9 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
             if (q == 0) {
                 a[4] += (logf(es) + mz) - zt;
                 a[5] += mv;
-                a[3] += fabsf(h[0] - mtr[m]);
+                a[3] += fabsf(h03[0] - mt);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a[c] += fabsf(h[1 + c] * mv - gt_xyz[((size_t)n * 3 + c) * HW + pix] * mv);
+                for (int c = 0; c < 3; ++c) a[c] += fabsf(h03[1 + c] * mv - gx[c] * mv);
             }
         }
     }
@@ -157,7 +171,10 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
             double v = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) v += (double)red[threadIdx.x][i];
-            unsafeAtomicAdd(&acc[threadIdx.x], v);
+            // acc_rows: this workgroup's partial row (summed in a fixed order by gdrn_map_loss_finalize_rows) instead of 6 atomics per
+            // workgroup onto one cache line: 24 k same-line atomics across 8 XCDs cost the kernel 15 us
+            if (acc_rows) acc[8 + (size_t)blockIdx.x * 8 + threadIdx.x] = v;
+            else unsafeAtomicAdd(&acc[threadIdx.x], v);
         }
     }
 }
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restri
                                                            const float* __restrict__ gt_xyz,
                                                            const float* __restrict__ mvis, const float* __restrict__ mtr,
                                                            const long long* __restrict__ gt_region, int N, int HW, int nreg,
-                                                           double* acc) {
+                                                           double* acc, int acc_rows) {
     __shared__ float red[6][16];
     const int q = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long long M = (long long)N * HW;
@@ -212,7 +229,54 @@ __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restri
         double v = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v += (double)red[threadIdx.x][i];
-        unsafeAtomicAdd(&acc[threadIdx.x], v);
+        if (acc_rows) acc[8 + (size_t)blockIdx.x * 8 + threadIdx.x] = v;
+        else unsafeAtomicAdd(&acc[threadIdx.x], v);
+    }
+}
+
+// partial rows acc[8 + 8 r + k] (r < nrows, written by the loss kernels in GDRN_ACC_ROWS mode) -> totals acc[0..7] in a fixed order, then the
+// five map losses.  1024 threads: thread t sums column t & 7 over rows (t >> 3) + 128 i with all (<= 32) loads of a batch in flight
+// together (256 threads walking their rows one load at a time took 17 us for 4096 rows), 128 such sums per column are added in order.
+__global__ __launch_bounds__(1024) void map_loss_finalize_rows_kernel(double* acc, int nrows, double npix, float* losses) {
+    __shared__ double part[128][8], part2[8][8];
+    __shared__ double tot[8];
+    const int k = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    double v = 0.0;
+    for (int rb = 0; rb < nrows; rb += 128 * 32) {
+        double x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int r = rb + r0 + 128 * i;
+            x[i] = (r < nrows) ? acc[8 + (size_t)r * 8 + k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v += x[i];
+    }
+    part[r0][k] = (k < 6) ? v : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 64) {   // column t & 7, eight lanes per column: 16 rows each, then a fixed-order 8-way add through the LDS
+        const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[g * 16 + i][c];
+        part2[g][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += part2[i][threadIdx.x];
+        tot[threadIdx.x] = t;
+        acc[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double den = tot[5] < 1.0 ? 1.0 : tot[5];
+        losses[0] = (float)(tot[0] / den);
+        losses[1] = (float)(tot[1] / den);
+        losses[2] = (float)(tot[2] / den);
+        losses[3] = (float)(tot[3] / npix);
+        losses[4] = (float)(tot[4] / den);
     }
 }
 
@@ -321,15 +385,33 @@ __global__ __launch_bounds__(256) void head_tail_bwd64_kernel(const float* __res
     for (long long m = g0; m < M; m += ng) {
         const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
         const float* h = head + m * hs;
+        // every load of the iteration up front, by all 16 lanes of the pixel (see head_tail_fwd64_kernel): the ones that sat in the
+        // `q == 14` / `q == 15` branches behind the softmax cost a second memory round trip per iteration
         const float mv = mvis[m];
         const int tgt = (int)(gt_region[m] * (long long)mv);
-        float r[4];
+        float r[4], h03[4];
         load4<float>(h + 4 + 4 * q, r);
+        load4<float>(h, h03);                                  // mask, x, y, z
+        const float h68 = h[68];
+        const float mt = mtr[m];
+        float gt3[3], ex[3], d03[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gt3[c] = gt_xyz[((size_t)n * 3 + c) * HW + pix]; ex[c] = extents[n * 3 + c]; }
+        float sk[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f}, s64 = 0.f, d64 = 0.f;
+        if (dpnp != nullptr) {   // attention softmax chain: region class k (>= 1) <- pnp channel 4 + k
+            load4<T>(pnp + m * pcs + 4 + 4 * q, sk);
+            load4<T>(dpnp + m * pcs + 4 + 4 * q, dk);
+            load4<T>(dpnp + m * pcs, d03);                     // d/d(x, y, z scaled by the extents), channel 3 unused
+            s64 = ld1<T>(pnp + m * pcs + 68);
+            d64 = ld1<T>(dpnp + m * pcs + 68);
+            if (q == 0) { sk[0] = 0.f; dk[0] = 0.f; }   // channel 4 is roi_coord_2d, not a class
+            if (q != 15) { s64 = 0.f; d64 = 0.f; }
+        }
         // CE gradient: mv * (softmax(region*mv)_k - onehot_k) / den over the 65 classes
         float z[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = r[j] * mv;
-        const float z64 = (q == 15) ? h[68] * mv : -INFINITY;
+        const float z64 = (q == 15) ? h68 * mv : -INFINITY;
         float mz = fmaxf(fmaxf(z[0], z[1]), fmaxf(fmaxf(z[2], z[3]), z64));
         mz = row16_max(mz);
         float e[4];
@@ -337,14 +419,6 @@ __global__ __launch_bounds__(256) void head_tail_bwd64_kernel(const float* __res
         for (int j = 0; j < 4; ++j) e[j] = expf(z[j] - mz);
         const float e64 = (q == 15) ? expf(z64 - mz) : 0.f;
         const float inv = 1.f / row16_sum(e[0] + e[1] + e[2] + e[3] + e64);
-        // attention softmax chain: region class k (>= 1) <- pnp channel 4 + k
-        float sk[4] = {0.f, 0.f, 0.f, 0.f}, dk[4] = {0.f, 0.f, 0.f, 0.f}, s64 = 0.f, d64 = 0.f;
-        if (dpnp != nullptr) {
-            load4<T>(pnp + m * pcs + 4 + 4 * q, sk);
-            load4<T>(dpnp + m * pcs + 4 + 4 * q, dk);
-            if (q == 0) { sk[0] = 0.f; dk[0] = 0.f; }   // channel 4 is roi_coord_2d, not a class
-            if (q == 15) { s64 = ld1<T>(pnp + m * pcs + 68); d64 = ld1<T>(dpnp + m * pcs + 68); }
-        }
         const float dot = row16_sum(sk[0] * dk[0] + sk[1] * dk[1] + sk[2] * dk[2] + sk[3] * dk[3] + s64 * d64);
         T* o = dhead + m * dcs;
         const float cs = gce * mv * inv_den;
@@ -357,12 +431,11 @@ __global__ __launch_bounds__(256) void head_tail_bwd64_kernel(const float* __res
             store4<T>(o + 68, w);
         } else if (q == 14) {
             float w[4];
-            w[0] = gmask * inv_np * sgn(h[0] - mtr[m]);
+            w[0] = gmask * inv_np * sgn(h03[0] - mt);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float gt = gt_xyz[((size_t)n * 3 + c) * HW + pix];
-                float d = gx[c] * mv * inv_den * sgn(h[1 + c] * mv - gt * mv);
-                if (dpnp != nullptr) d += ld1<T>(dpnp + m * pcs + c) * extents[n * 3 + c];
+                float d = gx[c] * mv * inv_den * sgn(h03[1 + c] * mv - gt3[c] * mv);
+                if (dpnp != nullptr) d += d03[c] * ex[c];
                 w[1 + c] = d;
             }
             store4<T>(o, w);
@@ -617,16 +690,16 @@ inline bool ht64_ok(int nreg, int hs, int pcs) { return nreg == 64 && hs >= 72 &
 template <bool LOSS>
 int launch_ht_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs, const float* gt_xyz,
                   const float* mv, const float* mt, const long long* greg, double* acc, int N, int HW, int nreg, int dtype, hipStream_t st) {
-    const int dt = dtype & 0xff, write_pad = (dtype & GDRN_PREZEROED) ? 0 : 1;
+    const int dt = dtype & 0xff, write_pad = (dtype & GDRN_PREZEROED) ? 0 : 1, rows = (dtype & GDRN_ACC_ROWS) ? 1 : 0;
     const long long M = (long long)N * HW;
     const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
     if (ht64_ok(nreg, hs, pcs)) {
         if (dt == GDRN_DT_F32)
             hipLaunchKernelGGL((head_tail_fwd64_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs,
-                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad);
+                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad, rows);
         else
             hipLaunchKernelGGL((head_tail_fwd64_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs,
-                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad);
+                               gt_xyz, mv, mt, greg, acc, N, HW, write_pad, rows);
     } else {
         if (dt == GDRN_DT_F32)
             hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
@@ -634,13 +707,20 @@ int launch_ht_fwd(const float* head, int hs, const float* coord2d, const float* 
             hipLaunchKernelGGL(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
         if (LOSS) {
             const int lb = (int)std::min<long long>((M + 15) / 16, 2048);
-            hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(lb), dim3(256), 0, st, head, hs, gt_xyz, mv, mt, greg, N, HW, nreg, acc);
+            hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(lb), dim3(256), 0, st, head, hs, gt_xyz, mv, mt, greg, N, HW, nreg, acc, rows);
         }
     }
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 }  // namespace
+
+// partial rows gdrn_head_tail_loss_fwd writes behind acc[0..7] in GDRN_ACC_ROWS mode (= the workgroups of the kernel that carries the sums)
+extern "C" int gdrn_head_tail_loss_rows(int N, int HW, int nreg, int hs, int pcs) {
+    if (N <= 0 || HW <= 0 || nreg < 1 || nreg > 64) return GDRN_ERR_ARG;
+    const long long M = (long long)N * HW;
+    return (int)std::min<long long>((M + 15) / 16, ht64_ok(nreg, hs, pcs) ? 4096 : 2048);
+}
 
 extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
                                   int N, int HW, int nreg, int dtype, void* stream) {
@@ -658,7 +738,7 @@ extern "C" int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* c
     if (!head || !coord2d || !extents || !pnp_in || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || N <= 0 || HW <= 0 ||
         nreg < 1 || nreg > 64 || hs < nreg + 5 || pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_H16))
         return GDRN_ERR_ARG;
-    if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (!(dtype & GDRN_ACC_ROWS) && hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     return launch_ht_fwd<true>(head, hs, coord2d, extents, pnp_in, pcs, gt_xyz, mask_visib, mask_trunc, gt_region, acc, N, HW, nreg, dtype, ST);
 }
 
@@ -669,7 +749,7 @@ extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz,
     if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     const long long M = (long long)N * HW;
     const int blocks = (int)std::min<long long>((M + 15) / 16, 2048);
-    hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc);
+    hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc, 0);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -677,6 +757,13 @@ extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz,
 extern "C" int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* losses, void* stream) {
     if (!acc || !losses) return GDRN_ERR_ARG;
     hipLaunchKernelGGL(map_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, acc, (double)N * (double)HW, losses);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_map_loss_finalize_rows(double* acc, int nrows, int N, int HW, float* losses, void* stream) {
+    if (!acc || !losses || nrows <= 0 || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
+    hipLaunchKernelGGL(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -19,7 +19,7 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import cabi
-from .cabi import BF16, F16, F32, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
+from .cabi import ACC_ROWS, BF16, F16, F32, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
 
 RESNET34_LAYERS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
@@ -1330,12 +1330,18 @@ class Plan:
         self.keep.append(self.pnp_in)
         self.tensors.update({"head_out": self.head_out, "pnp_in": self.pnp_in})
         if WL:
-            self.acc = E(8, dtype=torch.float64)
+            # map-loss sums: totals in acc[0..7], behind them one partial row per workgroup of the kernel (ACC_ROWS: stored, then added in a fixed
+            # order by map_loss_finalize_rows -- no memset launch, no atomics, run-to-run identical losses)
+            rows_on = os.environ.get("GDRN_LOSS_ROWS", "1") == "1"   # ("0": memset + atomics into acc[0..7], the A/B partner)
+            self.acc_rows = int(lib.gdrn_head_tail_loss_rows(B, 4096, nreg, self.hs, 128)) if rows_on else 0
+            if rows_on and self.acc_rows <= 0:
+                check(self.acc_rows or -1, "head_tail_loss_rows")
+            self.acc = E(8 + 8 * self.acc_rows, dtype=torch.float64)
             self.losses = e._zeros(8, dtype=F32t)
             # head tail + map-loss sums in one pass over the logits (train mode)
             self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_loss_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"], ptr(self.pnp_in), 128,
                                                                               ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"], ctx["gt_region"], ptr(self.acc),
-                                                                              B, 4096, nreg, e.dt | PREZEROED, st), "head_tail_loss_fwd"))
+                                                                              B, 4096, nreg, e.dt | PREZEROED | (ACC_ROWS if self.acc_rows else 0), st), "head_tail_loss_fwd"))
         else:
             self.fwd.append(lambda st, ctx: check(lib.gdrn_head_tail_fwd(ptr(self.head_out), self.hs, ctx["coord2d"], ctx["extents"],
                                                                          ptr(self.pnp_in), 128, B, 4096, nreg, e.dt | PREZEROED, st), "head_tail_fwd"))
@@ -1487,7 +1493,10 @@ class Plan:
 
         self.fwd.append(pose)
         if WL:
-            self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize(ptr(self.acc), B, 4096, ptr(self.losses), st), "map_loss_finalize"))
+            if self.acc_rows:
+                self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize_rows(ptr(self.acc), self.acc_rows, B, 4096, ptr(self.losses), st), "map_loss_finalize_rows"))
+            else:
+                self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize(ptr(self.acc), B, 4096, ptr(self.losses), st), "map_loss_finalize"))
 
     # ---- execution ---------------------------------------------------------------------------
     def run_forward(self, ctx):

@@ -325,6 +325,13 @@ int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2d, const fl
 int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,
                             const float* gt_xyz, const float* mask_visib, const float* mask_trunc, const long long* gt_region,
                             double* acc, int N, int HW, int nreg, int dtype, void* stream);
+/* dtype | GDRN_ACC_ROWS (gdrn_head_tail_loss_fwd): acc is fp64 [8 + 8 * gdrn_head_tail_loss_rows(...)]; every workgroup STORES its partial
+ * sums as row acc[8 + 8 r .. 8 + 8 r + 5] (no memset, no atomics: 24 k atomic adds onto one cache line cost the kernel 15 us, and their
+ * order made the sums run-to-run different in the last bits); gdrn_map_loss_finalize_rows adds the rows in a fixed order into acc[0..7]
+ * (what gdrn_head_tail_bwd reads) and writes the five map losses. */
+#define GDRN_ACC_ROWS 0x200
+int gdrn_head_tail_loss_rows(int N, int HW, int nreg, int hs, int pcs);
+int gdrn_map_loss_finalize_rows(double* acc, int nrows, int N, int HW, float* losses, void* stream);
 /* Map losses (GDRN.py:345-400): acc[0..2] = sum|x*m-gt*m| per coordinate, acc[3] = sum|mask-trunc|,
  * acc[4] = CE_sum(region*m, gt_region*m), acc[5] = sum m  (acc: fp64 [8], zeroed inside). */
 int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,

@@ -843,6 +843,24 @@ def test_head_tail_and_map_losses(H, dt):
     check(lib.gdrn_map_loss_finalize(ptr(acc2), B, HW, ptr(losses2), st), "map_loss_finalize")
     assert torch.equal(pnp2[:, :72], pnp[:, :72]) and float((pnp2[:, 72:].float() - 7.0).abs().max()) == 0.0
     np.testing.assert_allclose(losses2[:5].cpu().numpy(), ref.numpy(), rtol=2e-5)
+    # GDRN_ACC_ROWS (what the engine calls): per-workgroup partial rows behind the totals instead of a memset + atomics; the rows are added
+    # in a fixed order -> the same bits on every run, the same sums as the atomics to fp64 rounding
+    nrows = lib.gdrn_head_tail_loss_rows(B, HW, nreg, hs, 128)
+    assert nrows == min(M // 16, 4096)
+    outs = []
+    for rep in range(2):
+        pnp3 = torch.full((M, 128), 7.0, dtype=H.tdt(dt), device=dev)
+        acc3 = torch.full((8 + 8 * nrows,), float("nan"), dtype=torch.float64, device=dev)   # (never read before it is written)
+        losses3 = torch.zeros(8, device=dev)
+        check(lib.gdrn_head_tail_loss_fwd(ptr(head_d), hs, ptr(c2d), ptr(ext), ptr(pnp3), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc3), B, HW,
+                                          nreg, dt | cabi.PREZEROED | cabi.ACC_ROWS, st), "head_tail_loss_fwd rows")
+        check(lib.gdrn_map_loss_finalize_rows(ptr(acc3), nrows, B, HW, ptr(losses3), st), "map_loss_finalize_rows")
+        assert torch.equal(pnp3[:, :72], pnp[:, :72])
+        outs.append((acc3[:8].cpu(), losses3.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][0][:6].numpy(), acc2[:6].cpu().numpy(), rtol=1e-12)
+    assert float(outs[0][0][6:].abs().max()) == 0.0
+    np.testing.assert_allclose(outs[0][1][:5].numpy(), ref.numpy(), rtol=2e-5)
     dpn = torch.zeros(M, 128, dtype=H.tdt(dt), device=dev)
     dpn[:, :69] = d_pnp.permute(0, 2, 3, 1).reshape(M, 69).to(dev).to(H.tdt(dt))
     dh = torch.full((M, 128), float("nan"), dtype=H.tdt(dt), device=dev)
@@ -882,6 +900,15 @@ def test_head_tail_generic_region_count(H):
         acc = torch.zeros(8, dtype=torch.float64, device=dev)
         check(lib.gdrn_head_tail_loss_fwd(ptr(hd), hs, ptr(c2d), ptr(ext), ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc), B, HW, nreg,
                                           dt, st), "head_tail_loss_fwd")
+        # the same sums through the partial rows (the generic path's loss kernel has 2048 workgroups at most, the 64-region one 4096)
+        nrows = lib.gdrn_head_tail_loss_rows(B, HW, nreg, hs, 128)
+        assert nrows == min(M // 16, 4096 if nreg == 64 else 2048)
+        accr = torch.full((8 + 8 * nrows,), float("nan"), dtype=torch.float64, device=dev)
+        lossr = torch.zeros(8, device=dev)
+        check(lib.gdrn_head_tail_loss_fwd(ptr(hd), hs, ptr(c2d), ptr(ext), ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(accr), B, HW, nreg,
+                                          dt | cabi.ACC_ROWS, st), "head_tail_loss_fwd rows")
+        check(lib.gdrn_map_loss_finalize_rows(ptr(accr), nrows, B, HW, ptr(lossr), st), "map_loss_finalize_rows")
+        np.testing.assert_allclose(accr[:6].cpu().numpy(), acc[:6].cpu().numpy(), rtol=1e-12)
         dh = torch.zeros(M, 128, device=dev)
         gw = torch.ones(5, device=dev)
         dpn = (H.randn(6, M, 128) * 0.01).to(dev)
