@@ -335,31 +335,34 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
         float acc[V], xv[V];
+        // windows containing iy: oy with 2*oy-1 <= iy <= 2*oy+1 -- one (even iy) or two (odd iy), likewise in x.  All four candidate windows
+        // are loaded up front from clamped addresses (a missing second window re-reads the first: an L1 hit) and masked afterwards: as a
+        // nested loop with `continue`s the 1..4 (dy, index) load pairs of a pixel were issued one memory round trip after the other.
+        // (the V tap indices of a vector are ONE 4- / 8-byte word, written that way by the forward kernel)
+        const int oyA = iy >> 1, oyBr = (iy + 1) >> 1, oxA = ix >> 1, oxBr = (ix + 1) >> 1;
+        const bool vBy = oyBr != oyA && oyBr < Ho, vBx = oxBr != oxA && oxBr < Wo;
+        const int oyB = min(oyBr, Ho - 1), oxB = min(oxBr, Wo - 1);
+        const int kyA = iy - 2 * oyA + 1, kyB = iy - 2 * oyBr + 1, kxA = ix - 2 * oxA + 1, kxB = ix - 2 * oxBr + 1;
+        const size_t rA = (size_t)(n * Ho + oyA) * Wo, rB = (size_t)(n * Ho + oyB) * Wo;
+        const size_t o4[4] = {(rA + oxA) * C + cv * V, (rA + oxB) * C + cv * V, (rB + oxA) * C + cv * V, (rB + oxB) * C + cv * V};
+        const int tap4[4] = {kyA * 3 + kxA, kyA * 3 + kxB, kyB * 3 + kxA, kyB * 3 + kxB};
+        const bool ok4[4] = {true, vBx, vBy, vBy && vBx};
+        float d4[4][V];
+        unsigned long long pk4[4];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = 0.f;
-        // windows containing iy: oy with 2*oy-1 <= iy <= 2*oy+1
-        const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
-        const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            if (oy >= Ho) continue;
-            const int ky = iy - 2 * oy + 1;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                if (ox >= Wo) continue;
-                const int kx = ix - 2 * ox + 1;
-                const int tap = ky * 3 + kx;
-                const size_t o = ((size_t)(n * Ho + oy) * Wo + ox) * C + cv * V;
-                float d[V];
-                Vec16<T>::load(dy + o, d);
-                // the V tap indices of the vector as ONE 4- / 8-byte load (written that way by the forward kernel; byte loads were 8 separate
-                // memory instructions per window, 32 per input pixel)
-                unsigned long long pk;
-                if constexpr (V == 8) pk = *reinterpret_cast<const unsigned long long*>(idx + o);
-                else pk = *reinterpret_cast<const unsigned int*>(idx + o);
-#pragma unroll
-                for (int j = 0; j < V; ++j) if ((int)((pk >> (8 * j)) & 0xffull) == tap) acc[j] += d[j];
-            }
+        for (int w = 0; w < 4; ++w) {
+            Vec16<T>::load(dy + o4[w], d4[w]);
+            if constexpr (V == 8) pk4[w] = *reinterpret_cast<const unsigned long long*>(idx + o4[w]);
+            else pk4[w] = *reinterpret_cast<const unsigned int*>(idx + o4[w]);
         }
         Vec16<T>::load(x + (size_t)i * V, xv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            acc[j] = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)   // (same order of additions as the windows were walked before: oy outer, ox inner)
+                acc[j] += (ok4[w] && (int)((pk4[w] >> (8 * j)) & 0xffull) == tap4[w]) ? d4[w][j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j)
             if (!(xv[j] * sc_s[cv * V + j] + sh_s[cv * V + j] > 0.f)) acc[j] = 0.f;
@@ -445,22 +448,48 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
-        // outputs whose source coordinate lies in (iy-1, iy+1)
-        const int oy_lo = max(0, (int)floorf((iy - 1) / sh)), oy_hi = min(Ho - 1, (int)ceilf((iy + 1) / sh));
-        const int ox_lo = max(0, (int)floorf((ix - 1) / sw)), ox_hi = min(Wo - 1, (int)ceilf((ix + 1) / sw));
+        // outputs whose source coordinate lies in (iy-1, iy+1): a candidate range of at most six per dimension, of which at most FOUR
+        // consecutive ones carry a weight (2x, align_corners).  The 4 x 4 block starting at the first weighted row / column is loaded from
+        // clamped addresses with zero weights where there is nothing -- all loads independent.  (Walking the candidate range with
+        // `continue` on zero weights issued the up to 16 loads of a pixel one memory round trip after the other.)
+        const int oy_lo = max(0, (int)floorf((iy - 1) / sh)), ox_lo = max(0, (int)floorf((ix - 1) / sw));
+        float wyc[6], wxc[6];
+        int fy = 5, fx = 5;
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            wyc[k] = (oy_lo + k < Ho) ? up_weight(oy_lo + k, iy, H, sh) : 0.f;
+            wxc[k] = (ox_lo + k < Wo) ? up_weight(ox_lo + k, ix, W, sw) : 0.f;
+            if (wyc[k] != 0.f) fy = k;
+            if (wxc[k] != 0.f) fx = k;
+        }
+        float wy4[4], wx4[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            wy4[a] = 0.f;
+            wx4[a] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (fy + a == k) wy4[a] = wyc[k];
+                if (fx + a == k) wx4[a] = wxc[k];
+            }
+        }
+        const int oy0 = oy_lo + fy, ox0 = ox_lo + fx;
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            const float wy = up_weight(oy, iy, H, sh);
-            if (wy == 0.f) continue;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const float w = wy * up_weight(ox, ix, W, sw);
-                if (w == 0.f) continue;
-                float d[V];
-                Vec16<T>::load(dy + ((size_t)(n * Ho + oy) * Wo + ox) * C + cv * V, d);
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] += w * d[j];
+        for (int a = 0; a < 4; ++a) {
+            const size_t row = (size_t)(n * Ho + min(oy0 + a, Ho - 1)) * Wo;
+            float d[4][V];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Vec16<T>::load(dy + (row + min(ox0 + b, Wo - 1)) * C + cv * V, d[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float w = wy4[a] * wx4[b];
+                if (w != 0.f) {   // (same order of additions as before: oy outer, ox inner, zero weights skipped)
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += w * d[b][j];
+                }
             }
         }
         Vec16<T>::store(dx + (size_t)i * V, acc);
