@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4: generic kernel, fused BatchNorm-backward epilogue with the loads of half the fragment rows in flight together: tests, one-stream kernel table, step
+# (the change it measured -- epilogue loads of conv_gemm.hip batched per half tile -- made no difference and was dropped: DESIGN.md section 4)
 O=$PWD/gpurun_out/r4_gemm_epi
 mkdir -p $O
 R=$PWD
