@@ -162,7 +162,7 @@ def kernel_source_hash():
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gdr-net_amd", "csrc")
-    for f in sorted(os.listdir(d)) + ["../../include/gdrn_hip.h"]:
+    for f in sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h")) and not n.startswith("_")) + ["../../include/gdrn_hip.h"]:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
