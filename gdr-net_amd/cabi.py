@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("GDRN_HIP_LIB") or os.path.join(_HERE, "lib", "libgdrn
 LIB_PATH_F16 = os.environ.get("GDRN_HIP_LIB_F16") or os.path.join(_HERE, "lib", "libgdrn_hip_f16.so")
 
 F32, BF16, F16 = 0, 1, 2
-PREZEROED = 0x100
-ACC_ROWS = 0x200   # gdrn_head_tail_loss_fwd: per-workgroup partial rows behind acc[0..7] instead of atomics (include/gdrn_hip.h)  # GDRN_PREZEROED
+PREZEROED = 0x100  # GDRN_PREZEROED
+ACC_ROWS = 0x200   # GDRN_ACC_ROWS (gdrn_head_tail_loss_fwd: per-workgroup partial rows behind acc[0..7] instead of atomics)
 P = C.c_void_p
 I = C.c_int
 LL = C.c_longlong
