@@ -483,6 +483,9 @@ class GDRN(nn.Module):
         eng, plan, kctx = self._prepare(x, True, a)
         plan.run_forward(kctx)
         eng = plan.e
+        # the returned losses (weighted like forward()'s loss_dict) are formed HERE, on the main stream in front of the backward chain, which
+        # ends ~0.1 ms before the side stream does: behind the final join the one small launch and its gap were the step's last 15 us
+        out = plan.losses * self._loss_w
         ls = eng.loss_scale   # fp16: static loss scale on dL/dloss, divided out where the optimizer reads the gradients
         if loss_weights is not None:
             plan.gw.copy_(self._loss_w * loss_weights * ls)
@@ -530,7 +533,7 @@ class GDRN(nn.Module):
                 self._dp_divergence_check(eng)
             if packed and all(packed):
                 eng.mark_packed()
-            return plan.losses * self._loss_w
+            return out
         plan.run_backward(kctx, on_bucket=self._on_bucket)
         gs = 1.0 / ls
         if red is not None:
@@ -548,7 +551,7 @@ class GDRN(nn.Module):
                 optimizer.step(grads=grads)
         elif gs != 1.0:
             plan.e.grad_flat.mul_(gs)
-        return plan.losses * self._loss_w  # weighted like forward()'s loss_dict
+        return out
 
     def _dp_divergence_check(self, eng):
         """Data-parallel safety net of the per-bucket optimizer (the update of a bucket runs on the reducer's stream right behind its all-reduce,
