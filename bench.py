@@ -180,10 +180,16 @@ def _cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline():
+def _pose_outputs(o):
+    return {k: o[k].detach().float().cpu() for k in ("rot6d", "t_", "rot", "trans")}
+
+
+def cpu_baseline(parity_bs=None):
     """the CPU restatement of the reference path (oracle/, stock PyTorch CPU kernels, fp32) on this box's host
     cores, same synthetic batch, B = 4 and B = 64, forward-only and the full training step (forward + 8 losses + backward + Ranger,
-    oracle/ranger_oracle.py), median of 5 timed iterations after 2 warm-ups.  A reported baseline, not a target."""
+    oracle/ranger_oracle.py), median of 5 timed iterations after 2 warm-ups.  A reported baseline, not a target.
+    parity_bs (4 | 64): the leg also keeps the oracle's pose outputs of its first train-mode forward at that batch size -- on the plain and on
+    the conditioned synthetic weights -- for the `parity` object of the bench line (second return value)."""
     import statistics
 
     import torch
@@ -206,6 +212,7 @@ def cpu_baseline():
         return statistics.median(ts)
 
     res = {}
+    ref_pose = None
     for bs in (4, 64):
         sd = synth.make_state_dict(0)
         names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
@@ -213,6 +220,10 @@ def cpu_baseline():
             sd[k].requires_grad_(True)
         batch = synth.make_batch(bs, seed=1)
         state = [dict() for _ in names]
+        if bs == parity_bs:
+            with torch.no_grad():
+                ref_pose = {"plain": _pose_outputs(O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})),
+                            "conditioned": _pose_outputs(O.gdrn_forward(synth.conditioned_state_dict(0), batch, do_loss=True, training=True, bufs={}))}
 
         def train_step(opt=True):
             out = O.gdrn_forward(sd, batch, do_loss=True, training=True, bufs={})
@@ -233,6 +244,7 @@ def cpu_baseline():
     t64, _, i64 = res[64]
     t4, n4, i4 = res[4]
     return {"value": round(64 / t64, 3), "unit": "RoI/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
+            "__ref_pose__": ref_pose,
             "sample": "oracle/ (CPU restatement of the reference path, torch CPU fp32): fwd + 8 losses + bwd + Ranger step at bs=64, median of 5 timed "
                       "steps after 2 warm-ups, %d threads" % cores,
             "train_step_bs4_roi_s": round(4 / t4, 3), "fwd_bwd_without_optimizer_bs4_roi_s": round(4 / n4, 3),
@@ -479,6 +491,30 @@ def main():
         model.train()
         gdist.attach(model, force=args.dist_force, comm_dtype=args.comm_dtype)
 
+    # parity of what is timed: the pose outputs of one train-mode forward of every arithmetic the line reports, on fresh
+    # weights, kept on the host until the cpu_baseline leg has the oracle's outputs for the same batch
+    want_parity = world == 1 and not args.fwd_only and not args.no_cpu_baseline and B in (4, 64)
+    probes = {}
+
+    def pose_probe(m):
+        m.train()
+        with torch.no_grad():
+            m(batch["roi_img"], do_loss=True, **kw)
+        pl = m.engine().plan(B, True, True)
+        fc = pl.fc_out.float().cpu()
+        return {"rot6d": fc[:, :6], "t_": fc[:, 6:9], "rot": pl.rot.float().cpu(), "trans": pl.trans.float().cpu()}
+
+    if want_parity:
+        cfgc = lm13_cfg(device=dev)
+        cfgc.MODEL.CDPN.HIP_DTYPE = args.dtype
+        mc, _ = GDRN.build_model_optimizer(cfgc)
+        mc.load_state_dict(synth.conditioned_state_dict(0))
+        probes["conditioned"] = pose_probe(mc)
+        del mc
+        torch.cuda.empty_cache()
+        probes["plain"] = pose_probe(model)
+        model.load_state_dict(synth.make_state_dict(0))   # (the probe's forward moved the BatchNorm running statistics)
+
     if args.fwd_only:
         model.eval()
 
@@ -558,6 +594,9 @@ def main():
             cfg32.MODEL.CDPN.HIP_DTYPE = "fp32"
             m32, o32 = GDRN.build_model_optimizer(cfg32)
             m32.load_state_dict(synth.make_state_dict(0))
+            if want_parity:
+                probes["fp32"] = pose_probe(m32)
+                m32.load_state_dict(synth.make_state_dict(0))
             m32.train()
             t32 = timed(lambda: m32.train_step(batch["roi_img"], optimizer=o32, **kw), 5)
             also["fp32_parity_mode"] = {"roi_s": round(B / t32, 1), "ms_per_step": round(t32 * 1e3, 3),
@@ -598,8 +637,34 @@ def main():
                                         "resize_ratios")}
             _, plan, kctx = model._prepare(batch["roi_img"], True, a)
             res["roofline"] = measure_roofline(model, plan, kctx, args.dtype)
+        if also is not None and "fp32_parity_mode" in also:
+            res["fp32_parity_mode"] = also.pop("fp32_parity_mode")   # a sibling of `roofline`: the arithmetic the 1e-4 pose bound belongs to
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline(parity_bs=B if want_parity else None)
+            ref = cb.pop("__ref_pose__")
+            res["cpu_baseline"] = cb
+            if ref is not None and probes:
+                def errs(got, want):
+                    return {k: float("%.3e" % float((got[k].double() - want[k].double()).norm() / want[k].double().norm())) for k in want}
+
+                e_plain, e_cond = errs(probes["plain"], ref["plain"]), errs(probes["conditioned"], ref["conditioned"])
+                f32 = args.dtype == "fp32"
+                res["parity"] = {
+                    "dtype": args.dtype, "against": "oracle/ (fp32 CPU restatement of the reference path, pinned to the reference's outputs by tests/golden)",
+                    "what": f"relative L2 error of the pose outputs of one train-mode forward at bs={B}, same seeded batch and weights as the timed step",
+                    f"pose_rel_err_vs_oracle_bs{B}": e_plain, "worst": max(e_plain.values()),
+                    "bound": 1e-4 if f32 else None, "within_north_star_1e-4": max(e_plain.values()) < 1e-4,
+                    f"conditioned_network_bs{B}": e_cond,
+                    "note": ("the mode the 1e-4 pose tolerance of BASELINE.json is claimed for" if f32 else
+                             "16-bit storage of ~100 chained tensors is OUTSIDE the 1e-4 tolerance (fp32_parity_mode.pose_rel_err is the mode inside it); on "
+                             "the random-init synthetic network a BatchNorm chain with batch statistics amplifies any rounding x700-1600 (the fp32 oracle "
+                             "itself sits 4-6e-5 from fp64), so no bound is claimed for this figure; the bounded checks of this arithmetic are the "
+                             "stage-by-stage test (tests/test_teacher_forced_gpu.py: every one of the 402 stages of this bs=64 step within 1e-3 of "
+                             "the reference's arithmetic on the same stage inputs) and the conditioned network (near-identity residual blocks, x80)")}
+                if "fp32" in probes and "fp32_parity_mode" in res:
+                    e32 = errs(probes["fp32"], ref["plain"])
+                    res["fp32_parity_mode"].update({f"pose_rel_err_vs_oracle_bs{B}": e32, "pose_rel_err": max(e32.values()), "bound": 1e-4,
+                                                    "within_north_star_1e-4": max(e32.values()) < 1e-4})
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -37,6 +37,7 @@ class ConvParams(C.Structure):
         ("M", I), ("w_rows", I), ("dtype", I),
         ("xf_mode", I), ("xf_relu", I),
         ("xf_x2", P), ("xf_a", P), ("xf_b", P), ("xf_c", P), ("xf_c2", P), ("xf_msc", P), ("xf_msh", P), ("xf_out", P),
+        ("halo_waves", I), ("pad1_", I),
     ]
 
 
@@ -116,6 +117,7 @@ _SIGS = {
     "gdrn_conv3x3_halo": [C.POINTER(ConvParams), P],
     "gdrn_conv3x3_tile": [C.POINTER(ConvParams), C.POINTER(I), C.POINTER(I), C.POINTER(I)],
     "gdrn_conv3x3_stats_rows": [C.POINTER(ConvParams)],
+    "gdrn_conv3x3_halo_waves": [C.POINTER(ConvParams)],
     "gdrn_conv_wgrad": [C.POINTER(WgradParams), P],
     "gdrn_conv3x3_wgrad": [C.POINTER(WgradParams), P],
     "gdrn_conv3x3_wgrad_ok": [C.POINTER(WgradParams)],

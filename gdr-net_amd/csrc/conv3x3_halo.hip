@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "halo_xf.h"
@@ -102,8 +103,14 @@ extern "C" int gdrn_halo_set_dbg(unsigned long long* buf) { return hipMemcpyToSy
 #define HALO_STAMP(i_)
 #endif
 
-template <typename T, int TH, int TW, int BN, int XF>
-__global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 : 2) void conv3x3_halo_kernel(const gdrn_conv_params p) {
+// KS = 2 (round 5): the EIGHT-wave form of the same tile for grids that give a CU one workgroup (8x8 - 16x16 maps at bs = 64: 256 workgroups =
+// one wave per SIMD, every LDS / L2 / MFMA latency exposed).  Waves 4-7 are a second copy of waves 0-3 -- same pixels, same channels, same
+// LDS patch -- that takes k-step 1 of every tap stage while the first copy takes k-step 0: each wave walks HALF the reduction (one 1 KiB
+// weight block and FM fragment reads per tap instead of two), the weight stream per CU is the same, the patch is staged once by all 512
+// threads, and the two partial accumulator tiles meet once, through LDS, in front of the epilogue.
+template <typename T, int TH, int TW, int BN, int XF, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : ((BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 : 2)) void conv3x3_halo_kernel(const gdrn_conv_params p) {
+    static_assert(KS == 1 || (KS == 2 && sizeof(T) == 2 && BN == 128), "the 8-wave form: 16-bit, 128-channel tile");
     constexpr int EPS = ROWB / (int)sizeof(T);
     constexpr int BM = TH * TW;
     constexpr int PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
@@ -115,10 +122,13 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     static_assert(XF == 0 || sizeof(T) == 2, "operand transforms are bf16 only");
     constexpr int FM = BM / 16;               // pixel fragments per wave (all pixels)
     constexpr int FN = BN / 64;               // 16-channel fragments per wave
-    constexpr int WQ = FN * 2;                // weight 1-KiB loads per wave per stage (FN frags x 2 k-steps)
+    constexpr int WQ = FN * 2 / KS;           // weight 1-KiB loads per wave per stage (FN frags x 2 k-steps; one k-step per wave group in the 8-wave form)
+    constexpr int NSL = KS == 2 ? 5 : 9;      // patch slices a thread moves per chunk (8-wave form: slices of the group's parity)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x patch
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = KS == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // wave group = k-step of every tap stage
+    const int tid = threadIdx.x & 255, wave = tid >> 6;    // tid: thread index inside the wave group
     const int g = lane >> 4, r16 = lane & 15;
 #ifdef HALO_DBG
     HaloDbg hdbg_;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     const char* xg = reinterpret_cast<const char*>(p.x);
     // this wave's fragment-major weight stream: block index ((cb*9 + tap)*kch + kc)*2 + ks, 1 KiB each
     const int cb0 = (co0 + wave * (BN / 4)) / 16;
-    const char* wl = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
+    const char* wl = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16 + (size_t)(grp << 10);
 
     // weight stream: stage s = kc*9 + tap; per stage WQ loads of 1 KiB
     auto wptr = [&](int kc, int tap, int a, int ks) -> const uint4* {
@@ -160,8 +170,10 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
 #define LOADW(dst, kc_, tap_)                                                   \
     {                                                                           \
         _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_) {                     \
-            dst[a_ * 2 + 0] = *wptr(kc_, tap_, a_, 0);                          \
-            dst[a_ * 2 + 1] = *wptr(kc_, tap_, a_, 1);                          \
+            if constexpr (KS == 1) {                                            \
+                dst[a_ * 2 + 0] = *wptr(kc_, tap_, a_, 0);                      \
+                dst[a_ * 2 + 1] = *wptr(kc_, tap_, a_, 1);                      \
+            } else dst[a_] = *wptr(kc_, tap_, a_, 0);                           \
         }                                                                       \
     }
     // the first three stages' weights go out before the patch geometry below is computed: their L2 latency hides under ~300
@@ -169,29 +181,34 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     LOADW(wq0, 0, 0) LOADW(wq1, 0, 1) LOADW(wq2, 0, 2)
 
     // ---- patch slice geometry of this thread (slice st = linear segment ids [st*PSLICE, (st+1)*PSLICE))
-    unsigned poff[9];
-    int pdst[9];
+    // (8-wave form: wave group grp moves the slices st = 2j + grp; arrays and masks are indexed by j)
+    unsigned poff[NSL];
+    int pdst[NSL];
     unsigned pokm = 0, pinm = 0, ppm = 0;  // slice st: input pixel inside the image / one of this tile's own (interior) pixels / slot exists
 #pragma unroll
-    for (int st = 0; st < 9; ++st) {
+    for (int sj = 0; sj < NSL; ++sj) {
+        const int st = KS == 2 ? 2 * sj + grp : sj;
         const int id = st * PSLICE + tid;
         const int pp = id >> 3, sg = id & 7;
         const int py = pp / PW, px = pp - py * PW;
         const int iy = y0 + py - 1, ix = x0 + px - 1;
-        const bool inpatch = tid < PSLICE && id < PSEG;
+        const bool inpatch = tid < PSLICE && id < PSEG && st < 9;
         const bool ok = inpatch && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
-        poff[st] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * (unsigned)sizeof(T) + sg * 16;
-        pdst[st] = inpatch ? (pp * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
-        pokm |= ok ? (1u << st) : 0u;
+        poff[sj] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * (unsigned)sizeof(T) + sg * 16;
+        pdst[sj] = inpatch ? (pp * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
+        pokm |= ok ? (1u << sj) : 0u;
         if constexpr (XF != 0) {
-            pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= TW) ? (1u << st) : 0u;
-            ppm |= inpatch ? (1u << st) : 0u;
+            pinm |= (inpatch && py >= 1 && py <= TH && px >= 1 && px <= TW) ? (1u << sj) : 0u;
+            ppm |= inpatch ? (1u << sj) : 0u;
         }
     }
     // PSLICE % 8 == 0 in the transform instantiations: the LDS slot of slice st is pdst0 + st * PDSTEP (no per-slice register)
     constexpr int PDSTEP = (PSLICE / 8) * PITCH;
-    const int pdst0 = (tid >> 3) * PITCH + (tid & 1) * HB + ((tid & 7) >> 1) * 16;
+    const int pdst0 = (tid >> 3) * PITCH + (tid & 1) * HB + ((tid & 7) >> 1) * 16 + grp * PDSTEP;
+    // slice st_ belongs to this thread's wave group / its index in the per-thread arrays and masks
+#define OWN(st_) (KS == 1 || (((st_) & 1) == grp))
+#define SJ(st_) (KS == 1 ? (st_) : ((st_) >> 1))
     // operand transform state: LDS table of the per-channel vectors (built below, behind the patch buffers), second input,
     // optional copy-out of the transformed tile (first channel tile of a pixel tile only)
     const float* xtab = nullptr;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     float xlo = 0.f;
     if constexpr (XF != 0) {
         float* tabw = reinterpret_cast<float*>(smem + (kch == 1 ? 1 : 2) * PBYTES);
-        for (int c = tid; c < p.Cin; c += 256) {
+        for (int c = (int)threadIdx.x; c < p.Cin; c += 256 * KS) {
             tabw[c] = p.xf_a ? p.xf_a[c] : 1.f;
             tabw[p.Cin + c] = p.xf_c[c];
             if constexpr (XF >= 2) tabw[2 * p.Cin + c] = p.xf_b ? p.xf_b[c] : 1.f;
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     int lbase;
     if constexpr (TW == 16) lbase = r16 * PITCH + (g & 1) * HB + (g >> 1) * 16;                        // oy = b, ox = r16
     else lbase = ((r16 >> 3) * PW + (r16 & 7)) * PITCH + (g & 1) * HB + (g >> 1) * 16;             // oy = 2b + (r16>>3)
+    lbase += grp * 32;   // 8-wave form: the group's k-step of every stage
     constexpr int FROW = (TW == 16) ? PW * PITCH : 2 * PW * PITCH;                    // byte step per fragment b
 
     f32x4_t acc[FN][FM];
@@ -239,23 +257,23 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
     // XF == 0: out-of-image granules are zeroed at the load; XF != 0: at the write, AFTER the transform (the padding is a
     // property of the conv's input v, and v(0) != 0)
 #define LOADP(dst, dst2, kc_, st_)                                              \
-    {                                                                           \
-        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + (poff[st_] + (unsigned)((kc_) * ROWB))); \
-        if constexpr (XF == 0) dst = ((pokm >> (st_)) & 1u) ? v_ : make_uint4(0, 0, 0, 0);            \
+    if (OWN(st_)) {                                                             \
+        const uint4 v_ = *reinterpret_cast<const uint4*>(xg + (poff[SJ(st_)] + (unsigned)((kc_) * ROWB))); \
+        if constexpr (XF == 0) dst = ((pokm >> SJ(st_)) & 1u) ? v_ : make_uint4(0, 0, 0, 0);          \
         else dst = v_;                                                          \
-        if constexpr (XF >= 2) dst2 = *reinterpret_cast<const uint4*>(xg2 + (poff[st_] + (unsigned)((kc_) * ROWB))); \
+        if constexpr (XF >= 2) dst2 = *reinterpret_cast<const uint4*>(xg2 + (poff[SJ(st_)] + (unsigned)((kc_) * ROWB))); \
     }
 #define WRITEP(src, src2, pb_, st_, kc_)                                        \
-    {                                                                           \
+    if (OWN(st_)) {                                                             \
         if constexpr (XF == 0) {                                                \
-            if (pdst[st_] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[st_]) = src; \
+            if (pdst[SJ(st_)] >= 0) *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst[SJ(st_)]) = src; \
         } else {                                                                \
-            if ((ppm >> (st_)) & 1u) {                                          \
+            if ((ppm >> SJ(st_)) & 1u) {                                        \
                 uint4 t_ = xf_apply<XF>(src, src2, xtab + (kc_) * EPS, p.Cin, xlo); \
-                t_ = ((pokm >> (st_)) & 1u) ? t_ : make_uint4(0, 0, 0, 0);     \
-                *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst0 + (st_) * PDSTEP) = t_; \
-                if (xo != nullptr && ((pinm >> (st_)) & 1u))                    \
-                    *reinterpret_cast<uint4*>(xo + (poff[st_] + (unsigned)((kc_) * ROWB))) = t_; \
+                t_ = ((pokm >> SJ(st_)) & 1u) ? t_ : make_uint4(0, 0, 0, 0);   \
+                *reinterpret_cast<uint4*>(smem + (pb_) * PBYTES + pdst0 + SJ(st_) * (PDSTEP * KS)) = t_; \
+                if (xo != nullptr && ((pinm >> SJ(st_)) & 1u))                  \
+                    *reinterpret_cast<uint4*>(xo + (poff[SJ(st_)] + (unsigned)((kc_) * ROWB))) = t_; \
             }                                                                   \
         }                                                                       \
     }
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
         } else {                                                                                                \
             _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
                 _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_)                                               \
-                    acc[a_][b_] = mma_step<T>(WQ_[a_ * 2 + (KS_)], src_[b_], acc[a_][b_]);                      \
+                    acc[a_][b_] = mma_step<T>(WQ_[a_ * (2 / KS) + (KS_)], src_[b_], acc[a_][b_]);               \
         }                                                                                                       \
     }
     // stage TAP_ of chunk kc: compute, refill the ring slot for stage +3, move one slice of the next patch
@@ -306,6 +324,12 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
             if constexpr ((TAP_) == 0) { LOADP(rp0, rq0, kc + 1, 0) LOADP(rp1, rq1, kc + 1, 1) }                \
             else if constexpr ((TAP_) <= 7) LOADP(RP((TAP_) + 1), RQ((TAP_) + 1), kc + 1, (TAP_) + 1)           \
         }                                                                                                       \
+        if constexpr (KS == 2) {   /* one k-step per tap and wave: fragments of even taps in fbA, of odd taps in fbB */      \
+            if constexpr ((TAP_) < 8) {                                                                         \
+                if constexpr ((TAP_) & 1) RD(fbA, (TAP_) + 1, 0) else RD(fbB, (TAP_) + 1, 0)                    \
+            }                                                                                                   \
+            if constexpr ((TAP_) & 1) MM(WQ_, 0, fbB) else MM(WQ_, 0, fbA)                                      \
+        } else {                                                                                                \
         RD(fbB, TAP_, 1)                                                                                        \
         if constexpr (sizeof(T) == 4) {                                                                         \
             _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
@@ -319,6 +343,7 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
         if constexpr (sizeof(T) == 4) {                                                                         \
             _Pragma("unroll") for (int a_ = 0; a_ < FN; ++a_)                                                   \
                 _Pragma("unroll") for (int b_ = 0; b_ < FM; ++b_) acc[a_][b_] += part[a_][b_];                  \
+        }                                                                                                       \
         }                                                                                                       \
         {                                                                                                       \
             constexpr int nt_ = ((TAP_) + 3) % 9;                                                               \
@@ -347,6 +372,30 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
 #undef STEP
 #undef RP
 #undef RQ
+#undef OWN
+#undef SJ
+
+    if constexpr (KS == 2) {
+        // the two halves of the reduction meet: group 1 parks its accumulator tile in LDS (the patch buffers are dead behind the loop's
+        // last barrier; [wave][fragment][lane] x 16 bytes = consecutive lanes on consecutive banks) and is done; group 0 adds it and runs
+        // the epilogue on the complete sums
+        float4* ex = reinterpret_cast<float4*>(smem) + wave * (FN * FM * 64) + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) ex[(a * FM + b) * 64] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const float4 o = ex[(a * FM + b) * 64];
+                acc[a][b][0] += o.x; acc[a][b][1] += o.y; acc[a][b][2] += o.z; acc[a][b][3] += o.w;
+            }
+    }
 
     // ---- epilogue: lane holds channels c0..c0+3 (c0 = co0 + wave*BN/4 + g*4*FN + a*4) of pixel b*16 + r16
     // Fast path for what the engine actually launches (full channel tiles, bf16 out, bias / ReLU / addend / statistics
@@ -611,27 +660,38 @@ __global__ __launch_bounds__(256, (BN == 64 && TW == 16 && sizeof(T) == 2) ? 3 :
 
 constexpr int XF_MAX_CIN = 512;  // channels of the operand-transform table
 
-template <typename T, int TH, int TW, int BN, int XF>
+template <typename T, int TH, int TW, int BN, int XF, int KS = 1>
 int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
     constexpr size_t smem = 2 * 2 * (size_t)half_bytes((TH + 2) * (TW + 2));
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN, XF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + xf_nk(XF) * XF_MAX_CIN * sizeof(float))) != hipSuccess)
-            return GDRN_ERR_LAUNCH;
-        attr_set = true;
-    }
+    constexpr size_t xbytes = KS == 2 ? (size_t)4 * (BN / 64) * (TH * TW / 16) * 64 * 16 : 0;   // accumulator exchange of the 8-wave form
+    constexpr size_t smem_max = std::max(smem + xf_nk(XF) * XF_MAX_CIN * sizeof(float), xbytes);
+    static std::once_flag attr_once;
+    static bool attr_ok = false;
+    std::call_once(attr_once, [] {
+        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, TW, BN, XF, KS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max) == hipSuccess;
+    });
+    if (!attr_ok) return GDRN_ERR_LAUNCH;
     const int grid = N * (p.Ho / TH) * (p.Wo / TW) * cdiv(p.Cout, BN);
     // a single 128-byte channel chunk (Cin = 64) never touches the second patch buffer: half the LDS -> a third workgroup per
     // CU on the 64-channel variants (142 VGPRs), whose runs are all prologue / one chunk / epilogue
-    const size_t smem_used = ((p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem) + (size_t)xf_nk(XF) * p.Cin * sizeof(float);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN, XF>), dim3(grid), dim3(256), smem_used, st, p);
+    const size_t smem_used = std::max(((p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem) + (size_t)xf_nk(XF) * p.Cin * sizeof(float), xbytes);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN, XF, KS>), dim3(grid), dim3(256 * KS), smem_used, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
+// 8-wave form (kernel comment): p.halo_waves = 8 asks for it, 4 forbids it, 0 leaves the choice to the grid -- a launch that gives no CU a
+// second workgroup (<= 256 workgroups of the 128-channel tile) runs it
+__host__ inline bool halo_split(const gdrn_conv_params& p, int th, int tw, int bn, int N) {
+    if (bn != 128 || p.dtype != GDRN_DT_H16 || p.halo_waves == 4) return false;
+    if (p.halo_waves == 8) return true;
+    return (long long)N * (p.Ho / th) * (p.Wo / tw) * cdiv(p.Cout, bn) <= 256;
+}
+
 template <int XF>
 int launch_tile(const gdrn_conv_params& p, int tw, int bn, int N, hipStream_t st) {
+    if (halo_split(p, 8, tw, bn, N)) return tw == 16 ? launch<bf16_t, 8, 16, 128, XF, 2>(p, N, st) : launch<bf16_t, 8, 8, 128, XF, 2>(p, N, st);
     if (tw == 16) return bn == 64 ? launch<bf16_t, 8, 16, 64, XF>(p, N, st) : launch<bf16_t, 8, 16, 128, XF>(p, N, st);
     return bn == 64 ? launch<bf16_t, 8, 8, 64, XF>(p, N, st) : launch<bf16_t, 8, 8, 128, XF>(p, N, st);
 }
@@ -682,6 +742,14 @@ extern "C" int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, in
     return GDRN_OK;
 }
 
+// waves per workgroup of the launch gdrn_conv3x3_halo makes for p (first halo kernel): 4, or 8 = the K-split form; 0: not a launch of that kernel
+extern "C" int gdrn_conv3x3_halo_waves(const gdrn_conv_params* p) {
+    if (!p || p->w_frag == 2) return 0;
+    int th, tw, bn;
+    if (gdrn_conv3x3_tile(p, &th, &tw, &bn) != GDRN_OK || th == 0) return 0;
+    return halo_split(*p, th, tw, bn, p->M / (p->Ho * p->Wo)) ? 8 : 4;
+}
+
 extern "C" int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p) {
     int th, tw, bn;
     if (gdrn_conv3x3_tile(p, &th, &tw, &bn) != GDRN_OK || th == 0) return GDRN_ERR_SHAPE;
@@ -720,6 +788,7 @@ extern "C" int gdrn_conv3x3_halo(const gdrn_conv_params* pp, void* stream) {
     if (p.w_rows < cdiv(p.Cout, bn) * bn) return GDRN_ERR_SHAPE;
     if (p.addend && (p.add_cs & 3)) return GDRN_ERR_SHAPE;
     if (p.w_frag < 0 || p.w_frag > 2) return GDRN_ERR_ARG;   // (ABI 1's padding field: an uninitialised value must not pick a kernel)
+    if (p.halo_waves != 0 && p.halo_waves != 4 && p.halo_waves != 8) return GDRN_ERR_ARG;
     if (p.bnb_x) {  // fused BatchNorm-backward statistics: fast epilogue only
         if (!p.bnb_mean || !p.bnb_invstd || !p.bnb_rows || (p.bnb_scale != nullptr) != (p.bnb_shift != nullptr)) return GDRN_ERR_ARG;
         if (p.bias || p.act || p.out_f32 || (p.Cout % bn) || (p.bnb_cs & 3) || p.bnb_cs < p.Cout) return GDRN_ERR_SHAPE;

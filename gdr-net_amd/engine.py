@@ -94,6 +94,7 @@ class Engine:
         # which transforms are fused, by xf mode (bit m-1 = mode m) and by the largest feature-map side they are used on (bring-up / tuning)
         # BatchNorm-backward mask + sums also in the generic kernel's epilogue (1x1 output conv, stride-2 / transposed data gradients)
         self.gemm_bnb = self.h16 and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
+        self.halo_waves = int(_os.environ.get("GDRN_HALO_WAVES", "0"))   # A/B: 4 / 8 force the four- / eight-wave form of the first halo kernel's 128-channel tile
         self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
         self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
         self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
@@ -581,6 +582,11 @@ class Plan:
             cp.bnb_mask = ptr(bnb[2])
         if xf is not None:
             cp.xf_mode = xf["mode"]     # (the library's kernel choice depends on addend, stored mask and operand transform)
+        # eight-wave form of the small-map tile (gdrn_hip.h, halo_waves): the library's choice in the forward pass and in inference (r5, isolated:
+        # 256@16x16 22.3 -> 21.7 us plain, 27.2 -> 24.6 with the BatchNorm-backward transform; 512@8x8 25.1 -> 23.8 / 30.5 -> 26.5; inference
+        # 1.98 -> 1.96 ms); the data gradients of a two-stream backward pass keep four waves -- two 235-register waves per SIMD leave the
+        # side stream's weight gradient no room on the CU (7.37 -> 7.70 ms per step with eight waves everywhere, 7.93 -> 7.85 on one stream)
+        cp.halo_waves = e.halo_waves or (4 if (w is not None and e.wgrad_stream) else 0)
         self.keep.append(cp)
         ref = C.byref(cp)
         if e.use_halo and L.kind == "conv" and L.wfF is not None:
@@ -665,7 +671,7 @@ class Plan:
         if use_halo and cp.w_frag == 2:
             kname = f"conv3x3_v3_kernel<{th.value},{hbn.value},{'2,4,1' if hbn.value == 256 else '2,2,2'},{cp.xf_mode}>"  # (the template's name in a trace)
         elif use_halo:
-            kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode}>"
+            kname = f"conv3x3_halo_kernel<{dn},{th.value},{tw.value},{hbn.value},{cp.xf_mode},{int(e.lib.gdrn_conv3x3_halo_waves(ref)) // 4}>"
         else:
             kname = f"conv_gemm_kernel<{dn},{bm.value},{bn.value}>"
         # algorithmic bytes (SURVEY 8(d) convention: activations in + out once, weights once, at the storage width)

@@ -28,7 +28,8 @@ extern "C" {
 
 /* 2: status / dtype enums renamed (GDRN_E_* -> GDRN_ERR_*, GDRN_F32 / GDRN_BF16 -> GDRN_DT_*; the old names stay as deprecated aliases),
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
-#define GDRN_ABI_VERSION 2
+/* 3: gdrn_conv_params grew halo_waves (appended; zero = the behaviour of version 2). */
+#define GDRN_ABI_VERSION 3
 /* `dtype` arguments.  The 16-bit format is a property of the library build: libgdrn_hip.so computes GDRN_DT_BF16, libgdrn_hip_f16.so (the same
  * sources compiled with -DGDRN_HALF_F16: v_mfma_f32_*_f16, IEEE-half storage -- the arithmetic of the reference's fp16 autocast,
  * core/gdrn_modeling/main_gdrn.py:53-56,141, gdrn_evaluator.py:568) computes GDRN_DT_F16; each rejects the other's code with GDRN_ERR_ARG,
@@ -97,6 +98,8 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
  */
 /* w_frag (gdrn_conv3x3_halo only): layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments, first halo kernel), 2: gdrn_pack_wfrag32
  * (second-generation kernel, see gdrn_pack_wfrag32 below). */
+/* halo_waves (gdrn_conv3x3_halo, w_frag 0 / 1; ABI 3): 0 = the library picks, 4 / 8 = force the four- / eight-wave form of the 128-channel tile
+ * (gdrn_conv3x3_halo_waves below); pad1_: 0. */
 typedef struct gdrn_conv_params {
     const void* x;
     const void* w;
@@ -127,6 +130,8 @@ typedef struct gdrn_conv_params {
     const float* xf_msc;
     const float* xf_msh;
     void* xf_out;
+    int halo_waves;
+    int pad1_;
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
@@ -178,6 +183,12 @@ int gdrn_conv3x3_wfrag(const gdrn_conv_params* p);
 int gdrn_conv3x3_halo(const gdrn_conv_params* p, void* stream);
 int gdrn_conv3x3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_conv3x3_stats_rows(const gdrn_conv_params* p);
+/* The first halo kernel's 128-channel tile exists in two forms: four waves, each walking the whole reduction of its 32 channels, and (ABI 3)
+ * eight waves -- a second copy of the four takes k-step 1 of every tap stage, the first k-step 0, the halves are added through LDS in front
+ * of the epilogue: two waves per SIMD for launches that give a CU a single workgroup (the 8x8 - 16x16 maps of resnet_backbone.py:53-80 at
+ * 64 RoIs).  p->halo_waves = 0 lets the library pick (eight when the grid has <= 256 workgroups), 4 / 8 force one.
+ * gdrn_conv3x3_halo_waves(p): waves per workgroup of the launch gdrn_conv3x3_halo makes for p (4 or 8; 0: w_frag = 2 or shape not covered). */
+int gdrn_conv3x3_halo_waves(const gdrn_conv_params* p);
 
 /* Weight gradient: dw[co][tap][ci] (fp32, packed, pre-zeroed by the caller) +=
  *   sum_m dy[m][co] * x[pix(m,tap)][ci]  (mode-0 gather; bf16 fragments through the LDS transpose read).  variant: 0 (only gdrn_conv3x3_wgrad* read it, see GDRN_WGRAD_W128).

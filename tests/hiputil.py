@@ -82,9 +82,12 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     """bnb (halo and generic kernel, bf16): dict(x, mask|None, mean, invstd, scale|None, shift|None) -> fused BatchNorm-backward statistics;
     the second return value is then the [tiles][2][Cout] rows buffer.
     xf (halo only): dict(mode, relu, x2, a, b, c, c2, msc, msh, out) device tensors -> operand transform while staging.
-    v3 (with halo): the second-generation kernel (operand of gdrn_pack_wfrag32, w_frag = 2).
+    v3 (with halo): True = the second-generation kernel (operand of gdrn_pack_wfrag32, w_frag = 2); 4 / 8 = the first kernel with
+    gdrn_conv_params.halo_waves forced (the default, 0, lets the library pick by grid size: the small test grids get the eight-wave form).
     reps > 0: also time `reps` back-to-back launches with HIP events; the average (ms) is returned as a third value."""
     lib = cabi.load(dt)
+    waves = v3 if (v3 is not True and v3 in (4, 8)) else 0   # v3 = 4 / 8: first halo kernel, forced four- / eight-wave form (halo_waves)
+    v3 = v3 is True
     if halo:  # the halo kernels take a fragment-major permutation of the same operand
         wf = torch.empty_like(w)
         check((lib.gdrn_pack_wfrag32 if v3 else lib.gdrn_pack_wfrag)(ptr(w), ptr(wf), w.shape[0], Cin, dt, stream()), "pack_wfrag")
@@ -103,6 +106,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     cp.M = B * (Ho // 2) * (Wo // 2) if mode == 1 else B * Ho * Wo
     cp.w_rows, cp.dtype = w.shape[0], dt
     cp.w_frag = 2 if (halo and v3) else 0
+    cp.halo_waves = waves if halo else 0
     # (every operand goes in before the tile / statistics-row queries: the second-generation kernel's tile depends on them)
     if bnb is not None:
         cp.bnb_mask = ptr(bnb.get("mask"))

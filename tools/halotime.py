@@ -17,6 +17,7 @@ from gdrnet_amd.cabi import BF16, ConvParams, check, ptr  # noqa: E402
 lib = cabi.load()
 B = 64
 modes = [int(m) for m in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4".split(","))]
+WAVES = int(os.environ.get("HALO_WAVES", "0"))   # gdrn_conv_params.halo_waves: 0 library's choice, 4 / 8 forced
 for (C_, Hh) in ((256, 64), (256, 32), (256, 16), (512, 8), (128, 32), (64, 64)):
     x = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
     x2 = torch.randn(B, Hh, Hh, C_, device="cuda").to(torch.bfloat16)
@@ -40,6 +41,7 @@ for (C_, Hh) in ((256, 64), (256, 32), (256, 16), (512, 8), (128, 32), (64, 64))
             cp.M = B * Hh * Hh
             cp.w_rows = C_
             cp.dtype = BF16
+            cp.halo_waves = WAVES
             rows = lib.gdrn_conv3x3_stats_rows(C.byref(cp))
             stats = torch.zeros(rows, 2, C_, device="cuda")
             cp.stats = ptr(stats)
