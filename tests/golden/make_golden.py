@@ -377,6 +377,7 @@ def main():
     np.savez_compressed(os.path.join(out_dir, "g7_postproc.npz"), **g)
     golden_g8(out_dir)
     golden_g9(out_dir)
+    golden_g10(out_dir)
     print("wrote goldens to", out_dir)
 
 
@@ -414,6 +415,63 @@ def golden_g8(out_dir):
     np.savez_compressed(os.path.join(out_dir, "g8_roi_targets.npz"), **g)
 
 
+def golden_g10(out_dir):
+    """G10: the reference's inference under autocast (gdrn_evaluator.py:568 `with autocast(enabled=amp_test)`; TEST.AMP_TEST,
+    configs/_base_/common_base.py:173).  The reference GDRN module in eval mode on the conditioned synthetic weights (synth.conditioned_state_dict)
+    with BatchNorm running statistics converged by 24 train-mode passes, B = 4: plain fp32 and under torch.autocast("cpu", dtype=float16).
+    (The reference runs CUDA autocast; the CPU autocast op policy -- conv / linear / matmul in the 16-bit format, everything else in the type
+    of its inputs or fp32 -- is the closest thing this container can execute.  Under bfloat16 autocast the reference's own test-time pose decode
+    raises -- pose_from_pred_centroid_z.py:129 calls .numpy() on a bf16 tensor -- so there is no bf16 reference output to store.)
+    Stored: the converged BatchNorm buffers (the GPU test must start from the same state), rot / trans and the 69-channel head maps of the
+    first two RoIs for both modes."""
+    from gdrnet_amd import synth
+    from gdrnet_amd.cfg import lm13_cfg
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cfg = lm13_cfg(device="cpu")
+    cfg.TEST.USE_PNP = True   # GDRN.forward then also returns the head maps (GDRN.py:183-190)
+    model, G = build_reference_model(cfg)
+    model.load_state_dict(synth.conditioned_state_dict(0), strict=True)
+    model.train()
+    with torch.no_grad():
+        for it in range(24):
+            wb = synth.make_batch(8, seed=50 + it % 4)
+            feat = model.backbone(wb["roi_img"])
+            model.rot_head_net(feat)
+    g = {}
+    for k, v in model.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            g["buf/" + k] = v.numpy().copy()
+    B = 4
+    batch = synth.make_batch(B, seed=77)
+    kw = synth.model_kwargs(batch, do_loss=False)
+    model.eval()
+    outs = {}
+    for tag, ctx in (("fp32", None), ("ac_fp16", torch.float16)):
+        with torch.no_grad():
+            if ctx is None:
+                od = model(batch["roi_img"], **kw)
+            else:
+                with torch.autocast("cpu", dtype=ctx):
+                    od = model(batch["roi_img"], **kw)
+        maps = torch.cat([od["mask"], od["coor_x"], od["coor_y"], od["coor_z"], od["region"]], 1)
+        outs[tag] = dict(rot=od["rot"].float(), trans=od["trans"].float(), maps=maps.float())
+        g[f"{tag}/rot"] = od["rot"].float().numpy()
+        g[f"{tag}/trans"] = od["trans"].float().numpy()
+        g[f"{tag}/maps_dtype"] = np.array(str(maps.dtype))
+        if True:
+            g[f"{tag}/maps2"] = maps[:2].numpy() if tag == "fp32" else maps[:2].to(torch.float16).numpy()
+        g[f"{tag}/maps_stats"] = tensor_stats(maps)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for tag in ("ac_fp16",):
+        d = {k: rel(outs[tag][k], outs["fp32"][k]) for k in ("rot", "trans", "maps")}
+        g[f"{tag}/dist_to_fp32"] = np.array([d["rot"], d["trans"], d["maps"]])
+        print("G10: reference under", tag, "vs its own fp32 inference (rot, trans, maps):", {k: "%.3e" % v for k, v in d.items()})
+    np.savez_compressed(os.path.join(out_dir, "g10_autocast.npz"), **g)
+    print("G10 written:", sorted(g.keys())[:6], "...")
+
+
 def golden_g9(out_dir):
     """G9: LR schedules of the reference trainer (lib/torch_utils/solver/lr_scheduler.py:137-263) sampled over a
     2000-iteration run: flat_and_anneal with every anneal method (the GDR-Net configs use cosine, a6_cPnP_lm13.py:22-32)
@@ -445,7 +503,11 @@ def golden_g9(out_dir):
 
 
 if __name__ == "__main__":
-    if "--g9-only" in sys.argv:
+    if "--g10-only" in sys.argv:
+        install_shims()
+        sys.path.insert(0, REF)
+        golden_g10(HERE)
+    elif "--g9-only" in sys.argv:
         install_shims()
         sys.path.insert(0, REF)
         golden_g9(HERE)

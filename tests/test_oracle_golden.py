@@ -85,6 +85,32 @@ def test_inference_vs_reference(g5, B, tag):
     assert rel(out["trans"], g5[f"{tag}/eval_trans"]) < 2e-5
 
 
+def g10_state_dict(g10):
+    """conditioned synthetic weights + the converged BatchNorm buffers stored in G10 (tests/golden/make_golden.py::golden_g10)"""
+    sd = synth.conditioned_state_dict(0)
+    for k in g10.files:
+        if k.startswith("buf/"):
+            sd[k[4:]] = torch.from_numpy(g10[k])
+    return sd
+
+
+def test_inference_on_converged_statistics_vs_reference_g10(golden_dir):
+    """G10's fp32 leg: the reference's eval-mode forward on the conditioned weights with converged running statistics (the state the
+    autocast comparison of tests/test_fp16_gpu.py starts from) -- oracle vs reference; and the stored distance of the reference under
+    fp16 autocast (gdrn_evaluator.py:568) to its own fp32 inference is what the golden says it is."""
+    g = np.load(os.path.join(golden_dir, "g10_autocast.npz"))
+    sd = g10_state_dict(g)
+    batch = synth.make_batch(4, seed=77)
+    with torch.no_grad():
+        out = O.gdrn_forward(sd, batch, do_loss=False, training=False)
+    maps = torch.cat([out["mask"], out["coor_x"], out["coor_y"], out["coor_z"], out["region"]], 1)
+    assert rel(out["rot"], g["fp32/rot"]) < 2e-5 and rel(out["trans"], g["fp32/trans"]) < 2e-5
+    assert rel(maps[:2], g["fp32/maps2"]) < 2e-5
+    d = [rel(g["ac_fp16/rot"], g["fp32/rot"]), rel(g["ac_fp16/trans"], g["fp32/trans"])]
+    np.testing.assert_allclose(d, g["ac_fp16/dist_to_fp32"][:2], rtol=1e-6)
+    assert 1e-3 < d[0] < 5e-2 and str(g["ac_fp16/maps_dtype"]) == "torch.float16"   # the autocast leg did run in half precision
+
+
 def test_fp64_noise_floor(g5):
     """The reference's own fp32 path sits ~4e-5 (rel. L2) from an fp64 evaluation of the same graph
     (SURVEY.md section 0); the 1e-4 target is judged with that headroom in mind."""
