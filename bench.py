@@ -157,15 +157,11 @@ def dry_main(args):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources + the C-ABI header: identifies the build a PMC traffic summary belongs to."""
-    import hashlib
+    """sha256 over the kernel sources + the C-ABI header: identifies the build a PMC traffic summary belongs to (the digest
+    gdrnet_amd.build stamps a built library with)."""
+    from gdrnet_amd import build
 
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "gdr-net_amd", "csrc")
-    for f in sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h")) and not n.startswith("_")) + ["../../include/gdrn_hip.h"]:
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
-    return h.hexdigest()[:16]
+    return build.source_hash()
 
 
 def _cpu_model():
@@ -349,17 +345,21 @@ def measure_roofline(model, plan, kctx, dtype):
     # committed summary (tools/pmc_util.py, tools/gpu_runs/r3_util.sh) carries the hash of the kernel sources it was measured on: any
     # other build reports null
     traffic, traffic_src, pmc = None, None, {}
-    tpath = os.path.join(ROOT, "profiles", "r04_mfma_util_hbm_bs64_bf16.json")
-    if dtype == "bf16" and plan.B == 64 and os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("__kernel_source_sha256_16__") == kernel_source_hash():
-            pmc = tj
-            traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
-            traffic = round(traffic) if traffic else None
-            traffic_src = "profiles/r04_mfma_util_hbm_bs64_bf16.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes of this build)"
-        else:
-            traffic_src = "null: the committed PMC summary belongs to another build of the kernels"
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util_hbm_bs64_bf16.json")), reverse=True)   # newest round first
+    if dtype == "bf16" and plan.B == 64 and cands:
+        traffic_src = "null: the committed PMC summaries belong to other builds of the kernels"
+        for tpath in cands:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("__kernel_source_sha256_16__") == kernel_source_hash():
+                pmc = tj
+                traffic = tj.get(dom, {}).get("traffic_bytes_per_launch")
+                traffic = round(traffic) if traffic else None
+                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE passes of this build)"
+                               % os.path.basename(tpath))
+                break
     # every conv / GEMM instantiation of the step, largest first (the dominant kernel above is row 0): the operand-transform variants of
     # the halo kernel are separate instantiations, and the per-launch figure of one averages over feature maps from 8x8 to 64x64
     table = []

@@ -296,7 +296,7 @@ class GDRN(nn.Module):
             if dev.type != "cuda":
                 raise cabi.GdrnHipError("GDRN runs on the HIP engine only: move the model to an MI355X (`model.to('cuda')`)")
             r, p = self.cfg.MODEL.CDPN.ROT_HEAD, self.cfg.MODEL.CDPN.PNP_NET
-            hit = (key, Engine(params, dict(self.named_buffers()), dtype=dtype, num_regions=r.NUM_REGIONS))
+            hit = (key, Engine(params, dict(self.named_buffers()), dtype=dtype, num_regions=r.NUM_REGIONS, bn_cell=self.__dict__.setdefault("_bn_cell", [0])))
             self._engs = {k: v for k, v in self._engs.items() if v[0] == key}   # engines of a re-allocated parameter set are dead
             self._engs[dtype] = hit
             lw = [r.XYZ_LW, r.XYZ_LW, r.XYZ_LW, r.MASK_LW, r.REGION_LW, p.PM_LW, p.CENTROID_LW, p.Z_LW]
@@ -490,16 +490,19 @@ class GDRN(nn.Module):
         if loss_weights is not None:
             plan.gw.copy_(self._loss_w * loss_weights * ls)
             plan._gw_key = None
-        elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version):
+        elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version, ls):
             plan.gw.copy_(self._loss_w * ls)  # dL/dloss_k = the config's loss weights: written once, not every step
-            plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version)
+            plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version, ls)
         red = getattr(self, "_reducer", None)
         # The optimizer update of a gradient bucket goes out as soon as the bucket is final, under the rest of the backward pass
         # (Ranger.step_buckets_*), instead of behind the whole pass: on one GPU on the engine's side stream right behind the bucket's
         # weight-gradient reduction; with a GradReducer attached (dist.attach) on the reducer's stream right behind the bucket's all-reduce,
         # with the 1/world factor folded into the update.  The bucket's operand copies for the next step follow on the same stream.
         mine = red is not None and self._on_bucket == red.on_bucket and red.defer_scale and (red.cuda or not red.active)
-        early = (optimizer is not None and (mine or (red is None and self._on_bucket is None)) and eng.wgrad_stream
+        # (fp16 with the dynamic loss scale: the update waits for the finite check over ALL gradients -- a bucket applied under the backward
+        #  pass could not be taken back when a later bucket overflows)
+        guard = optimizer is not None and eng.loss_scale_dynamic
+        early = (optimizer is not None and (mine or (red is None and self._on_bucket is None)) and eng.wgrad_stream and not guard
                  and hasattr(optimizer, "step_buckets_begin") and os.environ.get("GDRN_EARLY_OPT", "1") != "0")
         if early:
             if getattr(eng, "_bucket_of", None) is None or getattr(eng, "_bucket_of_bounds", None) != tuple(eng.bucket_bounds):
@@ -539,6 +542,8 @@ class GDRN(nn.Module):
         if red is not None:
             red.wait()
             gs = red.grad_scale / ls  # 1/world, folded into the fused optimizer's gradient read
+        if guard and self._overflowed(eng):
+            return out   # GradScaler.step: the optimizer step is skipped, the scale halved (the next step re-writes dL/dloss with it)
         if optimizer is not None:
             eng = plan.e
             grads = {eng.P[n]: eng.grads[n] for n in eng.param_names}
@@ -552,6 +557,27 @@ class GDRN(nn.Module):
         elif gs != 1.0:
             plan.e.grad_flat.mul_(gs)
         return out
+
+    def _overflowed(self, eng):
+        """fp16 arithmetic mode, the dynamic half of the reference's GradScaler (main_gdrn.py:53-56; engine.py:276-283 `scaler.step` /
+        `scaler.update`): one pass over the flat gradient buffer (gdrn_nonfinite_flag; after the all-reduce, so every rank decides alike),
+        one host read of its flag -- GradScaler.step reads its found_inf the same way.  Overflow: True (the caller skips the optimizer step),
+        loss scale x 0.5 (>= 1); otherwise False, and after loss_scale_growth clean steps the scale doubles (<= 65536)."""
+        if eng._nonfinite is None:
+            eng._nonfinite = torch.zeros(1, dtype=torch.int32, device=eng.dev)
+        cabi.check(eng.lib.gdrn_nonfinite_flag(eng.grad_flat.data_ptr(), eng.grad_flat.numel(), eng._nonfinite.data_ptr(), eng._stream()), "nonfinite_flag")
+        if int(eng._nonfinite.item()):
+            eng._nonfinite.zero_()
+            eng.loss_scale_skipped += 1
+            eng.loss_scale_good = 0
+            new = max(eng.loss_scale * 0.5, 1.0)
+            logger.warning("fp16 step %d skipped: inf / NaN in the gradients; loss scale %g -> %g", eng.loss_scale_skipped, eng.loss_scale, new)
+            eng.loss_scale = new
+            return True
+        eng.loss_scale_good += 1
+        if eng.loss_scale_good >= eng.loss_scale_growth and eng.loss_scale < 65536.0:
+            eng.loss_scale, eng.loss_scale_good = eng.loss_scale * 2.0, 0
+        return False
 
     def _dp_divergence_check(self, eng):
         """Data-parallel safety net of the per-bucket optimizer (the update of a bucket runs on the reducer's stream right behind its all-reduce,
@@ -586,6 +612,8 @@ class GDRN(nn.Module):
         replayed from then on; the optimizer step stays outside (its scalars change every step).  Returns None when the
         eager path has to run (warm-up, symmetric objects with a changing symmetry count, ...)."""
         B = int(x.shape[0])
+        if self.engine().loss_scale != 1.0 or self.engine().loss_scale_dynamic:
+            return None   # fp16: dL/dloss carries a loss scale that changes between steps and the optimizer waits for the finite check -- eager path
         st = self.__dict__.setdefault("_graph_state", {}).setdefault(B, dict(calls=0, staging={}, graph=None, plan=None, ok=True))
         if not st["ok"]:
             return None

@@ -19,11 +19,11 @@ import os as _os
 # alive, two of them can land on the queue of the compute stream and serialise with it (measured: the data-parallel step 8.45 instead of
 # 7.5 ms).  Ask for 8 queues -- effective when this package is imported before the process initialises HIP; the side / reducer streams are
 # additionally created at low priority (engine.make_stream), which keeps them off the default-priority queues either way.
-# A process-wide setting: applied only when the variable is unset, logged at INFO, and skipped altogether with GDRN_KEEP_HW_QUEUES=1.
-if "GPU_MAX_HW_QUEUES" not in _os.environ and _os.environ.get("GDRN_KEEP_HW_QUEUES", "0") != "1":
+# A process-wide setting: applied only when the variable is unset (export GPU_MAX_HW_QUEUES yourself to keep another value), logged at INFO.
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
     _os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import logging as _logging
 
-    _logging.getLogger(__name__).info("GPU_MAX_HW_QUEUES=8 set for this process (GDRN_KEEP_HW_QUEUES=1 leaves the HIP default)")
+    _logging.getLogger(__name__).info("GPU_MAX_HW_QUEUES=8 set for this process (export the variable to keep another value)")
 
 __version__ = "0.1.0"

@@ -18,18 +18,36 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """sha256 over the kernel sources + the C-ABI header (the same digest bench.py stamps its PMC summaries with): identifies the sources a
+    built library belongs to"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h")) and not n.startswith("_")) + ["../../include/gdrn_hip.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+STAMP = os.path.join(HERE, "lib", "source_hash.txt")   # written behind a successful build; git-ignored with the libraries, travels with them
+
+
 def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(LIB_F16):
+    """the libraries are rebuilt unless both exist AND were built from exactly these sources (content hash, not mtimes: a checkout, a copy to
+    another box or a restored file must not make a stale library look current -- VERDICT r4)"""
+    if not os.path.exists(LIB) or not os.path.exists(LIB_F16) or not os.path.exists(STAMP):
         return True
-    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_F16))
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "halo_xf.h"), os.path.join(INCLUDE, "gdrn_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if os.path.exists(STAMP):
+        os.remove(STAMP)   # no stamp while the objects are being replaced
     procs = []
     objs = {LIB: [], LIB_F16: []}
     for lib, tag, flags in ((LIB, "", []), (LIB_F16, "f16_", ["-DGDRN_HALF_F16"])):
@@ -48,6 +66,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

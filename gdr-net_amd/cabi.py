@@ -37,7 +37,7 @@ class ConvParams(C.Structure):
         ("M", I), ("w_rows", I), ("dtype", I),
         ("xf_mode", I), ("xf_relu", I),
         ("xf_x2", P), ("xf_a", P), ("xf_b", P), ("xf_c", P), ("xf_c2", P), ("xf_msc", P), ("xf_msh", P), ("xf_out", P),
-        ("halo_waves", I), ("pad1_", I),
+        ("halo_waves", I), ("v3_min_wg", I),
     ]
 
 
@@ -163,6 +163,7 @@ _SIGS = {
     "gdrn_pack_chunk": [],
     "gdrn_zero_chunk": [],
     "gdrn_zero_multi": [P, P, I, I, P],
+    "gdrn_nonfinite_flag": [P, LL, P, P],
     "gdrn_pack_multi": [P, P, I, I, I, P],
     "gdrn_unpack_multi": [P, P, I, I, P],
     "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, F, P],

@@ -710,11 +710,13 @@ int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn);
 int gdrn_v3_launch(const gdrn_conv_params* p, void* stream);
 
 // operand layout the library prefers for a shape: 2 = gdrn_pack_wfrag32 (v3 kernel), 1 = gdrn_pack_wfrag, 0 = no halo tiling
+// (p->w_frag carries the caller's policy INTO this query: 0 = the library's choice -- the second-generation kernel where it measured faster --,
+//  1 = never the second-generation kernel, 2 = wherever it covers the shape; A/B runs and the plan variants of the tests)
 extern "C" int gdrn_conv3x3_wfrag(const gdrn_conv_params* p) {
     if (!p) return GDRN_ERR_ARG;
-    const char* sel = getenv("GDRN_V3");   // "0": never, "2": wherever the kernel covers the shape (A/B, tests); default: where it measured faster
-    if (sel && sel[0] == '2' && gdrn_v3_config(p) > 0) return 2;
-    if (!(sel && sel[0] == '0') && gdrn_v3_preferred(p)) return 2;
+    if (p->w_frag < 0 || p->w_frag > 2) return GDRN_ERR_ARG;
+    if (p->w_frag == 2 && gdrn_v3_config(p) > 0) return 2;
+    if (p->w_frag == 0 && gdrn_v3_preferred(p)) return 2;
     gdrn_conv_params q = *p;
     q.w_frag = 0;
     int th, tw, bn;

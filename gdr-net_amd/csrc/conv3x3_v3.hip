@@ -707,12 +707,10 @@ int gdrn_v3_config(const gdrn_conv_params* p) {
     if (p->dtype != GDRN_DT_H16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
     if (p->act > 1 || p->out_f32) return 0;
     const int N = p->M / (p->Ho * p->Wo);
-    const char* force = getenv("GDRN_V3_CFG");   // bring-up: "ab" = configuration a for the large-map choice, b for the small-map one
-    const int f_big = (force && force[0] >= '1' && force[0] <= '4') ? force[0] - '0' : 1;
-    const int f_small = (force && force[0] && force[1] >= '2' && force[1] <= '4' && force[1] != '3') ? force[1] - '0' : 2;
+    constexpr int f_big = 1, f_small = 2;   // (configurations 3 / 4 -- four-wave forms of the two tiles -- were bring-up variants; launch_v3_cfg keeps them)
     // 256-channel tile when the grid still has at least one workgroup per CU: the patch (+ transform) is staged once per pixel tile
-    const char* mw = getenv("GDRN_V3_MINWG");   // tests: exercise the 256-channel tile on small grids
-    const long long min_wg = mw ? atoll(mw) : 256;
+    // (p->v3_min_wg > 0 lowers the threshold: the tests exercise the 256-channel tile on small grids with it)
+    const long long min_wg = p->v3_min_wg > 0 ? p->v3_min_wg : 256;
     if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= min_wg) {
         // LDS of the 16x16x256 tile: two patches + ring + raw staging (one or two inputs) + the transform's per-channel table
         const size_t need = (p->xf_mode >= 2 ? V3<16, 256, 2, 4, 1, 2>::OFF_TAB : V3<16, 256, 2, 4, 1, 0>::OFF_TAB) + (size_t)xf_nk(p->xf_mode) * p->Cin * sizeof(float);

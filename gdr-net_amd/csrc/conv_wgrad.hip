@@ -225,7 +225,7 @@ int launch(const gdrn_wgrad_params& p, hipStream_t st) {
         const int nst = cdiv(p.M, BKM);
         // every split adds one fp32 atomic per output element: keep >= 8 stages per block; ~2048 workgroups measured best
         // (256: +1.8 % step time, 1024: +0.4 %, 4096: equal) -- these small layers want parallelism more than few atomics
-        static const int target = [] { const char* e = getenv("GDRN_WGRAD_TARGET"); return e ? atoi(e) : 2048; }();
+        constexpr int target = 2048;
         splits = max(1, min(nst / 8 > 0 ? nst / 8 : 1, cdiv(target, tiles)));
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI>), dim3(tiles * splits), dim3(256), smem, st, p);

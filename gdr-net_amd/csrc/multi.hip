@@ -4,6 +4,8 @@
 // training step at bs=64; the work itself is a few hundred MB of HBM traffic.
 // Task tables live in device memory (built once by the host, see engine.py / ranger.py); a workgroup finds its
 // task by binary search in a prefix array.
+#include <algorithm>
+
 #include "common.h"
 #include "../../include/gdrn_hip.h"
 
@@ -307,6 +309,30 @@ extern "C" int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk
 }
 
 extern "C" int gdrn_zero_chunk(void) { return ZERO_CHUNK; }
+
+// inf / NaN detector of the fp16 arithmetic mode's dynamic loss scale (GradScaler's found_inf, main_gdrn.py:53-56): one pass over the flat
+// fp32 gradient buffer; a float4 with any all-ones exponent raises *flag (never cleared here: the host clears it after it has seen it)
+namespace {
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    const long long n4 = n >> 2;
+    unsigned bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + 4 * i);
+        bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+               ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) bad |= (__float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace
+
+extern "C" int gdrn_nonfinite_flag(const float* x, long long n, int* flag, void* stream) {
+    if (!x || !flag || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return GDRN_ERR_ARG;
+    const int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, ST, x, n, flag);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
 
 extern "C" int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;

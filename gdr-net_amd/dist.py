@@ -30,14 +30,14 @@ class GradReducer:
         if self.cuda:
             from .engine import make_stream
 
-            self.stream = make_stream(flat.device, os.environ.get("GDRN_RED_PRIO", "low"))
+            self.stream = make_stream(flat.device, "low")
         else:
             self.stream = None
         self.comm_dtype = comm_dtype
         self.stage = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if comm_dtype == "bf16" else None
         self.defer_scale = bool(defer_scale)
         self.active = self.world > 1 or self.force
-        self.trace = os.environ.get("GDRN_DIST_TRACE", "0") == "1" or force   # record a timing event per bucket (tests / tools/bucket_timeline.py)
+        self.trace = force   # record a timing event per bucket (tests / tools/bucket_timeline.py run with force=True)
         self.started = []  # per bucket: event recorded on the side stream when its collective was enqueued (trace mode only)
 
     @property
@@ -94,7 +94,7 @@ class GradReducer:
 def attach(model, group=None, average=True, force=False, comm_dtype="fp32"):
     """Overlap the gradient all-reduce with the model's backward; returns the GradReducer.  The 1/world factor is deferred
     to the consumer: ``GDRN.train_step`` hands it to the fused Ranger step, the autograd path applies it in ``finish()``."""
-    eng = model.engine()
+    eng = model.engine(model.hip_dtype)   # the TRAINING engine's gradient buffer whatever mode the model is in (cfg.TEST.AMP_TEST keeps a second, eval-only engine)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if not eng.buckets_from_env:
         # an engine built before init_process_group picked the one-GPU layout (4 buckets): data-parallel runs want the 5-bucket one

@@ -46,7 +46,15 @@ def _os_env(name, default):
 class Engine:
     """Owns the packed (kernel-layout) weight copies and the per-batch-size plans for one GDRN module."""
 
-    def __init__(self, params, buffers, dtype="bf16", num_regions=64, dry=False):
+    @property
+    def bn_epoch(self):
+        return self._bn_cell[0]
+
+    @bn_epoch.setter
+    def bn_epoch(self, v):
+        self._bn_cell[0] = v
+
+    def __init__(self, params, buffers, dtype="bf16", num_regions=64, dry=False, bn_cell=None):
         """params / buffers: dict name -> tensor with the reference's state_dict names.
         dry: build-only engine on host tensors for inspecting the launch lists without a GPU (tests); it cannot run."""
         # dtype: "bf16" | "fp16" | "fp32".  The 16-bit modes run the same kernels out of two builds of the library (cabi.load)
@@ -62,8 +70,17 @@ class Engine:
         # fp16 carries the reference's GradScaler idea (main_gdrn.py:53-56) as a STATIC factor on dL/dloss: the data-gradient chain is stored
         # in fp16 (6e-5 smallest normal), the fp32 parameter gradients come out multiplied by it and the optimizer's gradient read divides
         # it out again (Ranger.step(grad_scale=)); 1 for bf16 / fp32
+        # ... and its DYNAMIC part in the fused train step (GDRN.train_step, r5 / ADVICE r4): an inf / NaN anywhere in the step's gradients
+        # (gdrn_nonfinite_flag over the flat buffer) skips the optimizer update and halves the scale, `growth` clean steps in a row double it
+        # again up to 65536 (GradScaler's init_scale).  GDRN_LOSS_SCALE = "<initial scale>[:<growth interval> | :static]", default "1024:2000"
+        # (2000 = GradScaler's growth_interval); ":static" keeps the scale fixed and the optimizer update overlapped with the backward pass
         import os as _os0
-        self.loss_scale = float(_os0.environ.get("GDRN_LOSS_SCALE", "1024")) if self.dt == F16 else 1.0
+        ls_spec = (_os0.environ.get("GDRN_LOSS_SCALE", "1024:2000") + ":2000").split(":")
+        self.loss_scale = float(ls_spec[0]) if self.dt == F16 else 1.0
+        self.loss_scale_dynamic = self.dt == F16 and ls_spec[1] != "static"
+        self.loss_scale_growth = int(ls_spec[1]) if ls_spec[1] != "static" else 0
+        self.loss_scale_good, self.loss_scale_skipped = 0, 0   # clean steps since the last change / optimizer steps skipped so far
+        self._nonfinite = None                                  # int32 device flag (allocated by the first fp16 train step)
         self.dev = next(iter(params.values())).device
         self.dry = bool(dry)
         if self.dev.type != "cuda" and not self.dry:
@@ -71,23 +88,39 @@ class Engine:
         self.nreg = num_regions
         import os as _os
 
-        # 3x3 stride-1 convs (forward and data gradient) on the halo-tiled kernel: the 16-bit modes always; the fp32 parity mode on request
-        # (GDRN_HALO_F32=1: 8x8 x 64 tile, v_mfma_f32_16x16x4_f32, per-stage partial accumulators -- measured r4: 113-122 TFLOP/s per launch
-        # against the generic kernel's ~109, step 48.1 -> 45.7 ms, but two of the five bs=4 seeds then sit at 1.02e-4 / 1.17e-4 from the fp32
-        # oracle instead of <= 9.7e-5: the parity mode exists for the 1e-4 gate, so the default stays the generic kernel).  Operand transforms
-        # and the fused BatchNorm-backward epilogue exist for the 16-bit formats only
-        self.use_halo = self.h16 or _os.environ.get("GDRN_HALO_F32", "0") == "1"
+        # 3x3 stride-1 convs (forward and data gradient) on the halo-tiled kernel: the 16-bit modes always; the fp32 parity mode (8x8 x 64 tile,
+        # v_mfma_f32_16x16x4_f32, per-stage partial accumulators: 113-122 TFLOP/s per launch against the generic kernel's ~109, step 48.1 -> 45.7 ms
+        # at bs 64) in plans of >= halo_min_b RoIs.  GDRN_HALO_F32 = "auto" (default): halo_min_b = 32 -- at the BASELINE sizes (bs 64 / 32 / 64)
+        # its pose outputs sit 7.5e-5 / 8.1e-5 / 7.5e-5 from the fp32 oracle, inside the 1e-4 bound; at bs 4 two of five seeds measured 1.02e-4 /
+        # 1.17e-4 with it (generic kernel <= 9.7e-5: both at the amplified fp32 noise floor), so small plans keep the generic kernel and both
+        # operand layouts are maintained; "1": every plan, "0": none.  Operand transforms and the fused BatchNorm-backward epilogue exist for
+        # the 16-bit formats only
+        hf = _os.environ.get("GDRN_HALO_F32", "auto")
+        if hf not in ("auto", "0", "1"):
+            raise ValueError(f"GDRN_HALO_F32={hf!r}: auto, 0 or 1")
+        self.use_halo = self.h16 or hf != "0"
+        self.halo_min_b = 1 if (self.h16 or hf == "1") else 32
         # bucket-end work (grouped weight gradients, their reduction, gradient unpack) on a 2nd stream: it runs under the next bucket's chain of
         # small-map data-gradient kernels (one workgroup per CU, matrix pipe ~20 % busy); same-box A/B: 8.05 -> 7.85 ms/step with the LDS request
         # below, 7.77 with the optimizer update of a bucket behind its reduction on that stream (GDRN.train_step, GDRN_EARLY_OPT)
-        self.wgrad_stream = _os.environ.get("GDRN_WGRAD_STREAM", "1") == "1"
-        self.tail_overlap = _os.environ.get("GDRN_TAIL_OVERLAP", "1") == "1"  # last bucket's weight gradients under the stem's backward
-        self.side_small = _os.environ.get("GDRN_SIDE_SMALL", "1") == "1"  # generic weight gradients / bias gradients on the side stream too
-        self.wgrad_side_lds = int(_os.environ.get("GDRN_WGRAD_SIDE_LDS", str(84 * 1024)))  # LDS request of a side-stream weight-gradient launch
-        self.stem_direct = self.h16 and _os.environ.get("GDRN_STEM_DIRECT", "1") != "0"  # A/B: dedicated stem kernel
-        self.stem_wgrad = self.stem_direct and _os.environ.get("GDRN_STEM_WGRAD", "1") != "0"  # A/B: fused BN-backward + stem weight gradient
+        # GDRN_WGRAD_STREAM: "1" (default) two streams; "0" one stream; "serial" one stream with the two-stream step's launch configuration
+        # (768 workgroups per grouped weight-gradient launch, the side stream's LDS request = one workgroup per CU) -- the profiling mode:
+        # per-kernel counters and durations then describe the default step's launches without the overlap (tools/gpu_runs/r5_profiles.sh)
+        ws = _os.environ.get("GDRN_WGRAD_STREAM", "1")
+        if ws not in ("0", "1", "serial"):
+            raise ValueError(f"GDRN_WGRAD_STREAM={ws!r}: 1 (two streams), 0 (one stream) or serial (one stream, the two-stream launch configuration)")
+        self.wgrad_stream = ws == "1"
+        self.wgrad_force_lds = ws == "serial"
+        # settled by the A/B measurements of rounds 1-4 (their switches are gone with round 5): the last bucket's weight
+        # gradients run under the stem's backward, generic weight / bias gradients go to the side stream too, a side-stream weight-gradient
+        # launch asks for 84 KiB of LDS (one workgroup per CU), the 16-bit modes use the dedicated stem kernels and the split-K fc layers
+        self.tail_overlap = True
+        self.side_small = True
+        self.wgrad_side_lds = 84 * 1024
+        self.stem_direct = self.h16
+        self.stem_wgrad = self.stem_direct
         self.stem_w32 = torch.zeros(64 * 7 * 32, dtype=self.tdt, device=self.dev) if self.stem_direct else None
-        self.fc_splitk = _os.environ.get("GDRN_FC_SPLITK", "1") != "0"  # A/B switch: split-K fc1 vs gather kernel
+        self.fc_splitk = True
         # BatchNorm apply passes (forward scale/shift(+residual)+ReLU, backward dx = a*g + b*x + c) evaluated by the CONSUMER halo
         # conv while it stages its input patch (gdrn_conv_params.xf_*) instead of separate launches; "0" = separate passes (A/B, tests)
         self.fuse_xf = self.h16 and _os.environ.get("GDRN_FUSE_XF", "1") != "0"
@@ -95,28 +128,22 @@ class Engine:
         # BatchNorm-backward mask + sums also in the generic kernel's epilogue (1x1 output conv, stride-2 / transposed data gradients)
         self.gemm_bnb = self.h16 and _os.environ.get("GDRN_GEMM_BNB", "1") == "1"
         self.halo_waves = int(_os.environ.get("GDRN_HALO_WAVES", "0"))   # A/B: 4 / 8 force the four- / eight-wave form of the first halo kernel's 128-channel tile
-        self.xf_mask = int(_os.environ.get("GDRN_XF_MASK", "15"))
-        self.xf_maxhw = int(_os.environ.get("GDRN_XF_MAXHW", "64"))
-        self.xf_minc = int(_os.environ.get("GDRN_XF_MINC", "0"))  # ... and only into convs with at least that many input channels
+        self.xf_mask, self.xf_maxhw, self.xf_minc = 15, 64, 0   # every transform mode, on every map size (r2's policy sweep: all-fused won)
+        # second-generation halo kernel (conv3x3_v3.hip): GDRN_V3 = "0" never, "2" wherever it covers the shape (the 256-channel tile also on
+        # small grids) -- A/B and the plan variants of tests/test_teacher_forced_gpu.py; default: where the library measured it faster.  The
+        # library itself reads no environment: the policy travels in gdrn_conv_params (w_frag of the gdrn_conv3x3_wfrag query, v3_min_wg)
+        v3 = _os.environ.get("GDRN_V3", "")
+        if v3 not in ("", "0", "2"):
+            raise ValueError(f"GDRN_V3={v3!r}: 0 (never), 2 (wherever covered) or unset")
+        self.v3_policy = {"": 0, "0": 1, "2": 2}[v3]
+        self.v3_min_wg = 1 if v3 == "2" else 0
         # target workgroups of a grouped weight-gradient launch = three rounds of what is resident: one stream, 2 per CU = 512 per round
         # (measured 512: 8.70, 1024: 8.13, 1536: 8.09, 2048: 8.28 ms/step); side stream, 1 per CU = 256 per round (r3: 512: 8.02, 768: 7.575,
         # 1024: 7.54, 1280: 7.615, 1536: 7.58 -- 768 writes half the partial tiles of 1536 for the same step time)
-        self.wgrad_blocks = int(_os.environ.get("GDRN_WGRAD_BLOCKS", "768" if self.wgrad_stream else "1536"))
-        # extra cuts of the grouped weight-gradient launches inside a bucket (backward group indices in forward order; "22" = the two 64x64
-        # head layers get their own launch 1 ms before the head bucket is complete).  Measured r3: none 7.48-7.50, "22" 7.53, "23,22" 7.56-7.59,
-        # "22,14" 7.48-7.49, five cuts 7.62-7.64 ms/step: starting the side stream's work earlier only moves the sharing onto the dense
-        # 64x64 data gradients -- off by default
-        self.wgrad_cuts = tuple(int(c) for c in _os.environ.get("GDRN_WGRAD_CUTS", "").split(",") if c.strip())
-        # profiling aid: the side stream's launch configuration (LDS request = one workgroup per CU) on ONE stream, so that per-kernel
-        # counters and durations describe the launches of the default step without the overlap (tools/gpu_runs/r3_profiles.sh)
-        self.wgrad_force_lds = _os.environ.get("GDRN_WGRAD_FORCE_LDS", "0") == "1"
-        self.post_on = self.wgrad_stream and _os.environ.get("GDRN_POST_STREAM", "0") == "1"   # (measured r4: 7.42-7.45 against 7.36-7.37 ms without)
-        # 128 x 64 weight-gradient tile (conv3x3_wgrad.hip, GDRN_WGRAD_W128): 0 off, 1 stride-1 layers with Cout % 128 == 0, 2 stride-2 / ConvT too
-        self.wgrad_w128 = int(_os.environ.get("GDRN_WGRAD_W128", "0"))
-        self.wgrad_w128_blocks = int(_os.environ.get("GDRN_W128_BLOCKS", "256"))      # logical workgroups (= partial tiles) per launch
-        self.wgrad_w128_grid = int(_os.environ.get("GDRN_W128_GRID", "128"))           # resident workgroups of a launch that runs under a chain
-        self.wgrad_w128_grid_last = int(_os.environ.get("GDRN_W128_GRID_LAST", "0"))   # ... of the last bucket's launch (0: all)
-        self.wgrad_w128_only_last = _os.environ.get("GDRN_W128_ONLY_LAST", "0") == "1"  # the wide tile only where nothing runs beside it
+        #  Rejected by measurement and removed from the engine in round 5 (DESIGN.md section 4 has the figures): extra cuts of the grouped
+        #  launches inside a bucket, a third stream for the HBM-bound bucket tails, the 128 x 64 weight-gradient tile (the kernel stays in the
+        #  library behind gdrn_wgrad_params.variant, with its kernel tests)
+        self.wgrad_blocks = 768 if (self.wgrad_stream or self.wgrad_force_lds) else 1536
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
@@ -131,8 +158,10 @@ class Engine:
         self.layers = OrderedDict()
         self._versions = {}
         self.bn_fold = {}  # bn key -> NS(scale, shift, layer): eval-mode BatchNorm folded into the preceding conv
-        self.fold_bn = _os.environ.get("GDRN_FOLD_BN", "1") != "0"  # A/B switch: conv + bn_apply launches in eval mode
-        self.bn_epoch = 0  # bumped by every training forward (running statistics changed)
+        self.fold_bn = True
+        # bumped by every training forward (running statistics changed).  Shared by the engines of one model (bn_cell; ADVICE r4: the fp16
+        # inference engine of cfg.TEST.AMP_TEST must see the statistics its bf16 training twin moved through raw pointers)
+        self._bn_cell = bn_cell if bn_cell is not None else [0]
         self._build_layers()
         self.plans = OrderedDict()   # (batch size, train-mode BatchNorm, losses) -> Plan, least recently used first
         self.max_plans = int(_os.environ.get("GDRN_MAX_PLANS", "8"))
@@ -182,18 +211,8 @@ class Engine:
 
     def side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = make_stream(self.dev, os.environ.get("GDRN_SIDE_PRIO", "low"))
+            self._side = make_stream(self.dev, "low")
         return self._side
-
-    def post_stream(self):
-        """third stream (low priority): the HBM-bound tail of a gradient bucket -- partial-tile reduction, gradient unpack, the bucket's Ranger
-        update and operand re-pack -- behind an event of the side stream, so that the side stream goes straight on to the next bucket's
-        MFMA-bound weight gradient instead of serialising ~0.5 ms of streaming kernels between them (GDRN_POST_STREAM=0: on the side stream)"""
-        if not self.post_on:
-            return None
-        if getattr(self, "_post", None) is None:
-            self._post = make_stream(self.dev, os.environ.get("GDRN_SIDE_PRIO", "low"))
-        return self._post
 
     def _empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.tdt, device=self.dev)
@@ -338,7 +357,7 @@ class Engine:
             for bnkey, f in self.bn_fold.items():
                 L = f.layer
                 src = self.P[L.src[0]]
-                halo_only = self.use_halo and L.wfF is not None
+                halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None
                 for dst, frag in ((L.wf_e, 0), (L.wfF_e, L.wfmt.get("e", 0) or 1)):
                     if dst is None or (halo_only and not frag):
                         continue
@@ -367,7 +386,7 @@ class Engine:
             if L.kind == "stem":
                 continue
             src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
-            halo_only = self.use_halo and L.wfF is not None  # both conv passes read the fragment-major copies
+            halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None  # both conv passes read the fragment-major copies
             for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, L.wfmt["f"] or 1), ("d", L.wdF, L.wfmt["d"] or 1)):
                 if dst is None or (halo_only and not frag):
                     continue
@@ -587,15 +606,18 @@ class Plan:
         # 1.98 -> 1.96 ms); the data gradients of a two-stream backward pass keep four waves -- two 235-register waves per SIMD leave the
         # side stream's weight gradient no room on the CU (7.37 -> 7.70 ms per step with eight waves everywhere, 7.93 -> 7.85 on one stream)
         cp.halo_waves = e.halo_waves or (4 if (w is not None and e.wgrad_stream) else 0)
+        cp.v3_min_wg = e.v3_min_wg
         self.keep.append(cp)
         ref = C.byref(cp)
-        if e.use_halo and L.kind == "conv" and L.wfF is not None:
+        halo_on = e.use_halo and self.B >= e.halo_min_b   # (fp32 parity mode: only plans of the BASELINE sizes, see Engine.__init__)
+        if halo_on and L.kind == "conv" and L.wfF is not None:
             which = "e" if evalw else ("f" if w is None else "d")
             # the operand's layout is a property of the LAYER, not of whichever plan happens to be built first (a bs = 4 smoke
             # plan used to pin the first halo kernel's layout for the bs = 64 training plan): the library is asked at the canonical batch
             # size of the path (64 RoIs) unless this plan is bigger
             m_plan = cp.M
             cp.M = max(cp.M, 64 * Ho * Wo)
+            cp.w_frag = e.v3_policy   # (the query reads the policy from w_frag; the answer goes back into it below)
             want = int(e.lib.gdrn_conv3x3_wfrag(ref))
             cp.M = m_plan
             if not L.wfmt.get(which):
@@ -605,8 +627,8 @@ class Plan:
         # 3x3 stride-1 layers (forward and data-gradient) run on the halo-tiled kernel
         th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
         e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
-        use_halo = e.use_halo and th.value > 0 and L.kind == "conv" and L.wfF is not None
-        if e.use_halo and L.wfF is not None and not use_halo:
+        use_halo = halo_on and th.value > 0 and L.kind == "conv" and L.wfF is not None
+        if halo_on and L.wfF is not None and not use_halo:
             raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
         if evalw:      # eval-mode operand with the BatchNorm scale folded in (Engine.fold)
             assert w is None
@@ -904,9 +926,8 @@ class Plan:
         bucket_of = lambda gi: next(i for i, g0 in enumerate(first_group) if gi >= g0)
         # ---- grouped halo weight gradients: a common number of 8x8 pixel patches per workgroup within a bucket, chosen so
         # that the bucket's grid has ~wgrad_blocks workgroups (2 per CU resident); longest-running tasks first
-        # launch groups = the buckets, optionally cut further at e.wgrad_cuts (side stream only): a cut launches the layers in front of it as
-        # soon as THEIR data gradients exist instead of behind the bucket's last one
-        cuts = sorted(set(first_group) | (set(e.wgrad_cuts) if e.wgrad_stream else set()), reverse=True)
+        # launch groups = the buckets
+        cuts = sorted(set(first_group), reverse=True)
         cut_of = lambda gi: next(c for c in cuts if gi >= c)
         wg_bucket = {c: [] for c in cuts}
         for gi, L, wp, fb in self._wgrad_deferred:
@@ -917,69 +938,49 @@ class Plan:
                 continue
             bkt = bucket_of(cut)
             last_bucket = bkt == len(first_group) - 1
-            # two kernels: layers with Cout % 128 == 0 can take the 128 x 64 tile (one wave per SIMD, accumulators in the AGPRs: a resident
-            # workgroup owns its CU), the others the 64 x 64 tile; one grouped launch per kind and bucket
-            wide = [it for it in items_all if e.wgrad_w128 and it[1].Cout % 128 == 0 and (e.wgrad_w128 > 1 or it[1].stride == 1)
-                    and (last_bucket or not e.wgrad_w128_only_last)]
-            for kind, items in ((1, wide), (0, [it for it in items_all if it not in wide])):
-                if not items:
-                    continue
-                cot = 128 if kind else 64
-                nblocks_target = e.wgrad_w128_blocks if kind else e.wgrad_blocks
-                # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
-                geo = []
-                for L, wp, flops in items:
-                    s2 = wp.stride == 2
-                    npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
-                    geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // cot) * (wp.Cin // 64)))
-                per = max(16, sum(u * t for _, u, t in geo) // nblocks_target)   # k-steps per workgroup
-                tasks = []
-                for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
-                    wp.variant = kind
-                    wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
-                    wp.splits = max(1, units // per)
-                    wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
-                    assert wp.splits >= 1, (L.key, kind)
-                    ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
-                    self.keep.append(ws)
-                    wp.ws, wp.dw = ptr(ws), None
-                    # the kernel's "Cin" role = the parameter's input channels for a conv (69 real of 128 for Patch-PnP's first conv), its
-                    # second dimension for the ConvTranspose (weight [Cin_w][Cout_w][3][3] with x = output gradient, dy = input)
-                    self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin, L.O if L.kind == "convT" else L.I)
-                    tasks.append((-(units // wp.splits), len(tasks), wp, tiles, flops))
-                tasks.sort(key=lambda t: t[:2])
-                starts = [0]
-                for _, _, wp, tiles, _ in tasks:
-                    starts.append(starts[-1] + tiles * wp.splits)
-                tab = to_device_table([t[2] for t in tasks], e.dev)
-                stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
-                self._wgrad_tables.append((tab, stt))
-                nt, nb = len(tasks), starts[-1]
+            items, kind, cot, nblocks_target = items_all, 0, 64, e.wgrad_blocks   # one grouped launch of the 64 x 64 tile per bucket
+            # work of a layer in 32-pixel k-steps: an 8x8-pixel stage (stride 1) is two, a 4x8-pixel stage (stride 2) one
+            geo = []
+            for L, wp, flops in items:
+                s2 = wp.stride == 2
+                npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
+                geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // cot) * (wp.Cin // 64)))
+            per = max(16, sum(u * t for _, u, t in geo) // nblocks_target)   # k-steps per workgroup
+            tasks = []
+            for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
+                wp.variant = kind
+                wp.ws = ptr(e.dwp_flat)  # non-null placeholder for the split query
+                wp.splits = max(1, units // per)
+                wp.splits = int(lib.gdrn_conv3x3_wgrad_splits(C.byref(wp)))  # normalised: no empty split
+                assert wp.splits >= 1, (L.key, kind)
+                ws = e._empty(wp.splits * wp.Cout * wp.Cin * 9, dtype=torch.float32)
+                self.keep.append(ws)
+                wp.ws, wp.dw = ptr(ws), None
+                # the kernel's "Cin" role = the parameter's input channels for a conv (69 real of 128 for Patch-PnP's first conv), its
+                # second dimension for the ConvTranspose (weight [Cin_w][Cout_w][3][3] with x = output gradient, dy = input)
+                self._wreduce[L.key] = (ws, wp.splits, wp.Cout, wp.Cin, L.O if L.kind == "convT" else L.I)
+                tasks.append((-(units // wp.splits), len(tasks), wp, tiles, flops))
+            tasks.sort(key=lambda t: t[:2])
+            starts = [0]
+            for _, _, wp, tiles, _ in tasks:
+                starts.append(starts[-1] + tiles * wp.splits)
+            tab = to_device_table([t[2] for t in tasks], e.dev)
+            stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
+            self._wgrad_tables.append((tab, stt))
+            nt, nb = len(tasks), starts[-1]
 
-                if kind:
-                    # resident workgroups: under a data-gradient chain only part of the CUs (the chain's workgroups cannot share a CU with
-                    # this kernel), the whole chip when nothing runs beside it
-                    grid = e.wgrad_w128_grid_last if last_bucket else e.wgrad_w128_grid
+            def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
+                # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
+                # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
+                check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
 
-                    def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, grid=grid):
-                        check(lib.gdrn_conv3x3_wgrad_multi_w128(ptr(tab), ptr(stt), nt, nb, grid if (e.wgrad_stream or e.wgrad_force_lds) else 0, st),
-                              "conv3x3_wgrad_multi_w128")
-
-                    run.meta = dict(kernel="conv3x3_wgrad_w128_multi_kernel", flops=sum(t[4][0] for t in tasks), bytes=sum(t[4][1] for t in tasks),
-                                    layer=f"bucket{bkt}@{cut}:wgrad128 x{nt} ({nb} wg, grid {grid or nb})")
-                else:
-                    def run(st, ctx, tab=tab, stt=stt, nt=nt, nb=nb, lds=(0 if last_bucket else e.wgrad_side_lds)):
-                        # on the side stream (wgrad_stream) a bucket's weight gradients run under the NEXT bucket's data-gradient chain with one
-                        # workgroup per CU (LDS request), so that the chain's workgroups find room on every CU; the last bucket has nothing to hide under
-                        check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab), ptr(stt), nt, nb, lds if (e.wgrad_stream or e.wgrad_force_lds) else 0, st), "conv3x3_wgrad_multi")
-
-                    run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4][0] for t in tasks), bytes=sum(t[4][1] for t in tasks),
-                                    layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
-                run.side = True
-                if cut in first_group:
-                    self._bucket_end(bkt, run)
-                else:
-                    self.bwd_groups[cut].append(run)   # behind the data gradients of group `cut`, the last-executed one of this launch
+            run.meta = dict(kernel="conv3x3_wgrad_multi_kernel", flops=sum(t[4][0] for t in tasks), bytes=sum(t[4][1] for t in tasks),
+                            layer=f"bucket{bkt}@{cut}:wgrad x{nt} ({nb} wg)")
+            run.side = True
+            if cut in first_group:
+                self._bucket_end(bkt, run)
+            else:
+                self.bwd_groups[cut].append(run)   # behind the data gradients of group `cut`, the last-executed one of this launch
 
         per_bucket = {i: [] for i in range(len(first_group))}
         red_bucket = {i: [] for i in range(len(first_group))}
@@ -1011,7 +1012,6 @@ class Plan:
                 check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), nt, nb, st), "unpack_multi")
 
             unpack.side = True
-            unpack.post = True   # HBM-bound bucket tail: third stream (Engine.post_stream)
             self._bucket_end(bkt, unpack)
         for bkt, tasks in red_bucket.items():
             if not tasks:
@@ -1027,7 +1027,6 @@ class Plan:
                 check(lib.gdrn_wgrad_reduce_multi(ptr(tab), ptr(stt), nt, nb, st), "wgrad_reduce_multi")
 
             wreduce.side = True
-            wreduce.post = True
             self._bucket_end(bkt, wreduce)
 
     # ---- graph -------------------------------------------------------------------------------
@@ -1338,7 +1337,7 @@ class Plan:
         if WL:
             # map-loss sums: totals in acc[0..7], behind them one partial row per workgroup of the kernel (ACC_ROWS: stored, then added in a fixed
             # order by map_loss_finalize_rows -- no memset launch, no atomics, run-to-run identical losses)
-            rows_on = os.environ.get("GDRN_LOSS_ROWS", "1") == "1"   # ("0": memset + atomics into acc[0..7], the A/B partner)
+            rows_on = True
             self.acc_rows = int(lib.gdrn_head_tail_loss_rows(B, 4096, nreg, self.hs, 128)) if rows_on else 0
             if rows_on and self.acc_rows <= 0:
                 check(self.acc_rows or -1, "head_tail_loss_rows")
@@ -1423,7 +1422,7 @@ class Plan:
         else:
             op, _ = self._conv(L1, g2act, 128, f1, 8, 8, 1, 1, 1, 0, bias=b1, act=2, cin=128, cout=1024)
             self.fwd.append(op)
-        if e.h16 and B <= 64 and e.fc_splitk and _os_env("GDRN_FC2_SPLITK", "1") != "0":
+        if e.h16 and B <= 64 and e.fc_splitk:
             # fc2 (64 x 1024 -> 256) on the gather kernel is two workgroups walking K = 1024 serially (20 us for 34 MFLOP): the same split-K
             # kernel, 16 column tiles x 8 K ranges (r4)
             ws2 = e._zeros(16 * B * 256 + 64, dtype=F32t)
@@ -1537,8 +1536,7 @@ class Plan:
         # the RCCL exchange: it goes to a second stream behind an event, so the next bucket's dependent chain of short
         # data-gradient / BatchNorm kernels (one workgroup per CU on the small feature maps) shares the CUs with it.
         side = e.side_stream() if e.wgrad_stream else None
-        post = e.post_stream() if side is not None else None
-        used_side = in_side = in_post = used_post = False
+        used_side = in_side = False
         probe = getattr(self, "op_events", None)   # bench.py: [(start, end, meta, on_side)] HIP events around the conv launches of THIS pass
         for i, op in enumerate(self.bwd):
             if probe is not None and getattr(op, "meta", None) is not None:
@@ -1547,41 +1545,22 @@ class Plan:
                 if not in_side:
                     side.wait_stream(main)  # everything enqueued so far on the main stream
                     in_side = used_side = True
-                tail = side
-                if post is not None and getattr(op, "post", False):
-                    if not in_post:
-                        post.wait_stream(side)   # ... and on the side stream (this bucket's weight gradients)
-                        in_post = used_post = True
-                    tail = post
-                else:
-                    in_post = False
-                op(tail.cuda_stream, ctx)
+                op(side.cuda_stream, ctx)
                 if i in marks:
-                    if post is not None and tail is not post:
-                        post.wait_stream(side)
-                        used_post = True
-                        tail = post
-                    with torch.cuda.stream(tail):
+                    with torch.cuda.stream(side):
                         on_bucket(marks[i])
             else:
-                in_side = in_post = False
+                in_side = False
                 op(st, ctx)
                 if i in marks:
                     if used_side:     # the bucket's side-stream work (weight-gradient reduction) is part of the bucket
                         side.wait_stream(main)
-                        tail = side
-                        if post is not None:
-                            post.wait_stream(side)
-                            used_post = True
-                            tail = post
-                        with torch.cuda.stream(tail):
+                        with torch.cuda.stream(side):
                             on_bucket(marks[i])
                     else:
                         on_bucket(marks[i])
         if used_side:
             main.wait_stream(side)  # the optimizer (or the caller) sees complete gradients on the main stream
-        if used_post:
-            main.wait_stream(post)
 
     def walk_backward(self, on_bucket, before_bucket=None):
         """The backward launch list WITHOUT launching (works on a dry engine): calls before_bucket(i) / on_bucket(i) where

@@ -78,6 +78,11 @@ class Ranger(Optimizer):
         self.use_gc = use_gc
         self.gc_gradient_threshold = 3 if gc_conv_only else 1
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._buckets_poisoned = False   # (see step_buckets_abort)
+        self.__dict__.pop("_multi_cache", None)   # the task tables hold the old state tensors' addresses
+
     def _init_state(self, p):
         state = self.state[p]
         if len(state) == 0:
@@ -119,9 +124,9 @@ class Ranger(Optimizer):
     # as that bucket's gradients are complete, under the rest of the backward pass, instead of three launches behind it
     @torch.no_grad()
     def step_buckets_begin(self, grads, bucket_of, nbuckets, grad_scale=1.0):
-        """grads: dict param -> fp32 gradient; bucket_of(param) -> bucket index.  Advances the step counters and prepares one
-        gdrn_ranger_multi launch per (param group, bucket).  False: the per-bucket path does not apply (mixed step counts, CPU
-        parameters, ...) and nothing was changed -- call step()."""
+        """grads: dict param -> fp32 gradient; bucket_of(param) -> bucket index.  Prepares one gdrn_ranger_multi launch per (param group,
+        bucket) for the NEXT step index; the step counters themselves advance in step_buckets_end.  False: the per-bucket path does not
+        apply (mixed step counts, CPU parameters, ...) and nothing was changed -- call step()."""
         plan = []
         for gi, group in enumerate(self.param_groups):
             items = [(p, grads[p].detach()) for p in group["params"] if grads.get(p) is not None]
@@ -134,7 +139,11 @@ class Ranger(Optimizer):
                 return False
             plan.append((gi, group, items, states))
         lib = cabi.load()
+        if getattr(self, "_buckets_poisoned", False):
+            raise cabi.GdrnHipError("a per-bucket optimizer step was aborted after some buckets had been updated: parameters and moments of those "
+                                    "buckets are one step ahead of the rest -- reload the optimizer / model state before training on")
         self._bucket_launches = [[] for _ in range(nbuckets)]
+        self._bucket_done = 0
         self._bucket_params = []
         self._bucket_states = []   # their step counters advance in step_buckets_end: an exception inside the backward pass leaves them alone
         for hook in list(_global_pre_hooks()) + list(getattr(self, "_optimizer_step_pre_hooks", {}).values()):
@@ -158,6 +167,7 @@ class Ranger(Optimizer):
     def step_bucket(self, b):
         """launch the updates of bucket b on the current stream"""
         st = torch.cuda.current_stream().cuda_stream
+        self._bucket_done += 1
         for (tab, stt, nt, nrows, beta1, beta2, eps, wd, step_size, adaptive, lookahead, gs) in self._bucket_launches[b]:
             cabi.check(self._bucket_lib.gdrn_ranger_multi(tab.data_ptr(), stt.data_ptr(), nt, nrows, beta1, beta2, eps, wd, step_size, adaptive, lookahead,
                                                           self.alpha, gs, st), "ranger_multi")
@@ -175,9 +185,15 @@ class Ranger(Optimizer):
             hook(self, (), {})
 
     def step_buckets_abort(self):
-        """the backward pass raised before every bucket went out: forget the prepared launches, the step counters never moved.  (Updates
-        already enqueued for earlier buckets stay applied -- the caller's exception says the step is incomplete.)"""
+        """the backward pass raised before every bucket went out: forget the prepared launches; the step counters never moved.  If no bucket
+        had been updated yet the optimizer is exactly where it was (a retry is a clean step).  Otherwise some buckets' parameters and moments
+        are one step ahead of their counters and of the other buckets: the state is marked invalid and the next per-bucket step raises
+        instead of re-applying them.  The step post-hooks fire either way: the pre-hooks of step_buckets_begin have a partner."""
+        if getattr(self, "_bucket_done", 0) > 0:
+            self._buckets_poisoned = True
         self._bucket_launches, self._bucket_params, self._bucket_states = [], [], []
+        for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
+            hook(self, (), {})
 
     @torch.no_grad()
     def step(self, closure=None, grads=None, grad_scale=1.0):

@@ -99,7 +99,7 @@ int gdrn_device_info(int dev, char* name, int* cus, char* arch);
 /* w_frag (gdrn_conv3x3_halo only): layout of w -- 0 / 1: gdrn_pack_wfrag (16-row fragments, first halo kernel), 2: gdrn_pack_wfrag32
  * (second-generation kernel, see gdrn_pack_wfrag32 below). */
 /* halo_waves (gdrn_conv3x3_halo, w_frag 0 / 1; ABI 3): 0 = the library picks, 4 / 8 = force the four- / eight-wave form of the 128-channel tile
- * (gdrn_conv3x3_halo_waves below); pad1_: 0. */
+ * (gdrn_conv3x3_halo_waves below); v3_min_wg (w_frag 2): smallest grid the second-generation kernel gives its 16x16x256 tile, 0 = the default 256. */
 typedef struct gdrn_conv_params {
     const void* x;
     const void* w;
@@ -131,7 +131,7 @@ typedef struct gdrn_conv_params {
     const float* xf_msh;
     void* xf_out;
     int halo_waves;
-    int pad1_;
+    int v3_min_wg;
 } gdrn_conv_params;
 int gdrn_conv_gemm(const gdrn_conv_params* p, void* stream);
 int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
@@ -177,7 +177,9 @@ int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, int dtype, vo
  * lane l of a block holds fragment row l & 31, k = 16*ks + 8*(l >> 5) .. +7.  Fragment f, row r is operand row
  * (f>>1)*64 + ((r>>2)&1)*32 + (f&1)*16 + (r>>3)*4 + (r&3): an MFMA result lane then holds 32 contiguous output channels per fragment
  * pair (64-byte epilogue accesses).  rows must be a multiple of 64.
- * gdrn_conv3x3_wfrag(p): operand layout the library prefers for the shape in p (p->w_frag ignored): 2, 1, or 0 = no halo tiling. */
+ * gdrn_conv3x3_wfrag(p): operand layout for the shape in p: 2, 1, or 0 = no halo tiling.  p->w_frag is the caller's policy here: 0 = the
+ * library's preference (the second-generation kernel where it measured faster), 1 = never that kernel, 2 = wherever it covers the shape.
+ * The library reads no environment variables and keeps no configuration state: every choice it makes is a function of the params. */
 int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, int dtype, void* stream);
 int gdrn_conv3x3_wfrag(const gdrn_conv_params* p);
 int gdrn_conv3x3_halo(const gdrn_conv_params* p, void* stream);
@@ -449,6 +451,10 @@ typedef struct gdrn_zero_task {
 } gdrn_zero_task;
 int gdrn_zero_chunk(void);
 int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
+/* gdrn_nonfinite_flag: *flag |= 1 if any of the n floats at x (16-byte aligned) is inf or NaN; *flag is never cleared by the library.  The
+ * found_inf test of torch.cuda.amp.GradScaler (core/gdrn_modeling/main_gdrn.py:53-56, engine.py:276-283) for the fp16 arithmetic mode: the
+ * host skips the optimizer step and backs the loss scale off when it is raised (ABI 3). */
+int gdrn_nonfinite_flag(const float* x, long long n, int* flag, void* stream);
 /* OR-ed into the `dtype` argument of gdrn_gn_relu_bwd / gdrn_bias_grad / gdrn_stem_wgrad: the gradient outputs they accumulate
  * into with atomics were zeroed by the caller (gdrn_zero_multi) -- skip the internal hipMemsetAsync (one launch each). */
 #define GDRN_PREZEROED 0x100

@@ -107,6 +107,7 @@ def conv_gemm(x, w, B, Hi, Wi, Cin, x_cs, Ho, Wo, Cout, KH, KW, stride, pad, dt,
     cp.w_rows, cp.dtype = w.shape[0], dt
     cp.w_frag = 2 if (halo and v3) else 0
     cp.halo_waves = waves if halo else 0
+    cp.v3_min_wg = 1   # the 256-channel tile of the second-generation kernel also on the small grids of these tests
     # (every operand goes in before the tile / statistics-row queries: the second-generation kernel's tile depends on them)
     if bnb is not None:
         cp.bnb_mask = ptr(bnb.get("mask"))

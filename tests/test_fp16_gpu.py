@@ -206,3 +206,45 @@ def test_fp16_inference_vs_the_reference_under_autocast_g10(golden_dir):
     for k in ("rot", "trans", "maps"):
         assert res["fp16"]["vs_fp32"][k] < 1.5 * d_ref[k], (k, res["fp16"]["vs_fp32"][k], d_ref[k])          # no farther from fp32 than the reference's AMP
         assert res["fp16"]["vs_autocast"][k] < 2.2 * d_ref[k], (k, res["fp16"]["vs_autocast"][k], d_ref[k])  # two independent fp16 realisations: ~sqrt(2) x
+
+
+def test_fp16_overflow_skips_the_optimizer_step_and_backs_the_loss_scale_off():
+    """the dynamic half of the reference's GradScaler (main_gdrn.py:53-56; engine.py:276-283) in the fused fp16 train step.
+    A loss scale far too large overflows the fp16 gradient chain: the step's gradients hold inf / NaN, the optimizer step must be SKIPPED
+    (parameters, Ranger moments and step counters untouched), the scale halved; with a sane scale the next step updates normally; after
+    the growth interval of clean steps (GDRN_LOSS_SCALE = "1024:2" here) the scale doubles.  The per-bucket optimizer (updates under the backward pass) is off in this mode."""
+    B = 4
+    batch = E.to_dev(synth.make_batch(B, seed=5))
+    kw = synth.model_kwargs(batch, do_loss=True)
+    kw.pop("do_loss")
+    os.environ["GDRN_LOSS_SCALE"] = "1024:2"
+    try:
+        model, opt = E.build("fp16")
+        model.load_state_dict(synth.conditioned_state_dict(0))
+        model.train()
+        eng = model.engine()   # (the engine reads the switch when it is built)
+    finally:
+        os.environ.pop("GDRN_LOSS_SCALE", None)
+    assert eng.loss_scale_dynamic and eng.loss_scale == 1024.0
+    model.train_step(batch["roi_img"], optimizer=opt, **kw)          # a normal step (moments exist afterwards)
+    torch.cuda.synchronize()
+    assert eng.loss_scale_skipped == 0 and {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {1}
+    snap = {n: p.detach().clone() for n, p in model.named_parameters()}
+    mom = {n: opt.state[p]["exp_avg"].clone() for n, p in model.named_parameters()}
+    eng.loss_scale = 2.0 ** 60                                       # dL/dloss beyond fp16's range: the chain overflows
+    out = model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()                                 # the losses themselves are fp32 forward results
+    assert eng.loss_scale_skipped == 1 and eng.loss_scale == 2.0 ** 59
+    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {1}
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), snap[n]), n
+        assert torch.equal(opt.state[p]["exp_avg"], mom[n]), n
+    eng.loss_scale = 1024.0
+    for _ in range(2):
+        model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    torch.cuda.synchronize()
+    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {3}
+    assert eng.loss_scale == 2048.0 and eng.loss_scale_skipped == 1   # two clean steps (growth interval 2): doubled
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert not torch.equal(dict(model.named_parameters())["backbone.conv1.weight"].detach(), snap["backbone.conv1.weight"])

@@ -69,14 +69,9 @@ def test_conv_forward(H, dt, case):
 
 HALO_CASES = [(2, 64, 64, 16), (1, 128, 128, 32), (3, 256, 256, 16), (2, 512, 512, 8), (1, 256, 256, 64), (2, 64, 128, 24)]
 # second-generation kernel (conv3x3_v3.hip, v3=True): Cout % 128 == 0, W % 16 == 0.  The library gives the 16x16x256 tile only grids of
-# >= 256 workgroups; GDRN_V3_MINWG=1 (fixture below) lets the 256-channel cases of these lists run it on small grids, the other cases run
-# the 8x16x128 K-split tile
+# >= 256 workgroups; gdrn_conv_params.v3_min_wg = 1 (tests/hiputil.py) lets the 256-channel cases of these lists run it on small grids, the
+# other cases run the 8x16x128 K-split tile
 V3_CASES = [(1, 128, 128, 32), (3, 256, 256, 16), (1, 128, 256, 32), (2, 512, 128, 16), (2, 256, 256, 32), (1, 512, 256, 48)]
-
-
-@pytest.fixture(autouse=True)
-def _v3_small_grids(monkeypatch):
-    monkeypatch.setenv("GDRN_V3_MINWG", "1")
 
 
 # 4: the four-wave form of the 128-channel tile forced (halo_waves; False = the library picks: eight waves on these small grids)
@@ -1082,3 +1077,21 @@ def test_stem_wgrad_fused_bn_backward(H, B, fused):
     if fused:
         assert H.rel(dbet.cpu(), s1) < 1e-5 and H.rel(dgam.cpu(), s2) < 1e-5
     assert lib.gdrn_stem_wgrad(ptr(canvas), ptr(gd), None, ptr(dgam), None, None, B, ptr(ws), ptr(grad), dt, H.stream()) == -1
+
+
+def test_nonfinite_flag(H):
+    """gdrn_nonfinite_flag: raises the flag for an inf or a NaN anywhere in the buffer (incl. the last n % 4 elements), leaves it alone otherwise"""
+    lib = cabi.load(BF16)
+    n = 1_000_003
+    x = torch.randn(n + 1, device=H.DEV)[:n]
+    flag = torch.zeros(1, dtype=torch.int32, device=H.DEV)
+    run = lambda: (check(lib.gdrn_nonfinite_flag(ptr(x), n, ptr(flag), H.stream()), "nonfinite"), torch.cuda.synchronize(), int(flag.item()))[2]
+    assert run() == 0
+    for pos, val in ((n - 1, float("inf")), (12345, float("nan")), (0, float("-inf"))):
+        old = float(x[pos])
+        x[pos] = val
+        flag.zero_()
+        assert run() == 1, pos
+        x[pos] = old
+    flag.zero_()
+    assert run() == 0
