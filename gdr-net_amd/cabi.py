@@ -99,6 +99,7 @@ def to_device_table(structs, device):
 # name -> argtypes (all return int status, except the two tile queries which return ints too)
 _SIGS = {
     "gdrn_version": [],
+    "gdrn_last_hip_error": [C.c_char_p, I],
     "gdrn_workspace_bytes": [I, P],
     "gdrn_device_info": [I, C.c_char_p, C.POINTER(I), C.c_char_p],
     "gdrn_conv_gemm": [C.POINTER(ConvParams), P],
@@ -187,6 +188,12 @@ def load(dtype=BF16):
     kind = F16 if dtype == F16 else BF16
     if kind in _libs:
         return _libs[kind]
+    # The library shares the host framework's HIP runtime: streams and device pointers cross the boundary.  torch ships its own libamdhip64
+    # and must map it FIRST, so that the loader binds libgdrn_hip.so to that copy (same SONAME) -- dlopen'ed before `import torch`, the library
+    # pulls /opt/rocm's runtime in instead, torch then runs on a runtime it was not built with and the first kernel launch of the process fails
+    # with hipErrorNoDevice (r5: `python __graft_entry__.py smoke`, where build() loads the libraries before anything imported torch).
+    import torch  # noqa: F401
+
     path = lib_path(kind)
     if not os.path.exists(path):
         raise GdrnHipError(
@@ -207,7 +214,15 @@ def load(dtype=BF16):
 def check(status, what=""):
     if status != 0:
         names = {-1: "invalid argument", -2: "unsupported shape", -3: "launch failure"}
-        raise GdrnHipError(f"libgdrn_hip: {what} failed: {names.get(status, status)}")
+        detail = ""
+        if status == -3:   # which HIP error the launch reported (whichever build of the library made the call: ask both that are loaded)
+            for lib in _libs.values():
+                buf = C.create_string_buffer(64)
+                code = lib.gdrn_last_hip_error(buf, 64)
+                if code:
+                    detail = f" (HIP error {code}: {buf.value.decode(errors='replace')})"
+                    break
+        raise GdrnHipError(f"libgdrn_hip: {what} failed: {names.get(status, status)}{detail}")
 
 
 def ptr(t):

@@ -44,10 +44,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define GDRN_DT_H16 GDRN_DT_BF16
 #endif
 
+// Every kernel launch of the library goes through GDRN_LAUNCH + GDRN_CHECK_LAUNCH.  hipLaunchKernelGGL returns nothing: the launch status is what
+// hipGetLastError() says behind it -- and that call ALSO returns (and clears) an error some earlier HIP call of this host thread left behind,
+// the host framework's included (a pointer-attribute probe on a host pointer, a failed attribute query of another library, ...): r5's smoke run
+// reported "launch failure" for the first launch of a process that way.  The stale error is not this library's: drop it before the launch.
+#define GDRN_LAUNCH(...)                  \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+
+// (the HIP error code behind the most recent GDRN_ERR_LAUNCH of this host thread, for the caller's error message: gdrn_last_hip_error)
+extern thread_local int gdrn_tls_hip_error;
 #define GDRN_CHECK_LAUNCH()                                  \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
-        if (e__ != hipSuccess) return GDRN_ERR_LAUNCH;       \
+        if (e__ != hipSuccess) {                             \
+            gdrn_tls_hip_error = (int)e__;                   \
+            return GDRN_ERR_LAUNCH;                          \
+        }                                                    \
     } while (0)
 
 #ifdef GDRN_HALF_F16

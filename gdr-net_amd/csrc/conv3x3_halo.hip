@@ -676,7 +676,7 @@ int launch(const gdrn_conv_params& p, int N, hipStream_t st) {
     // a single 128-byte channel chunk (Cin = 64) never touches the second patch buffer: half the LDS -> a third workgroup per
     // CU on the 64-channel variants (142 VGPRs), whose runs are all prologue / one chunk / epilogue
     const size_t smem_used = std::max(((p.Cin * (int)sizeof(T) == ROWB) ? smem / 2 : smem) + (size_t)xf_nk(XF) * p.Cin * sizeof(float), xbytes);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, TW, BN, XF, KS>), dim3(grid), dim3(256 * KS), smem_used, st, p);
+    GDRN_LAUNCH((conv3x3_halo_kernel<T, TH, TW, BN, XF, KS>), dim3(grid), dim3(256 * KS), smem_used, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -766,8 +766,8 @@ extern "C" int gdrn_pack_wfrag(const void* src, void* dst, int rows, int Cin, in
     const long long n = (long long)rows * 9 * Cin * esz / 16;
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_wfrag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Cin);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_wfrag_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(pack_wfrag_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, rows, Cin);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(pack_wfrag_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

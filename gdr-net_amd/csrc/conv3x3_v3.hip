@@ -685,7 +685,7 @@ int launch_v3(const gdrn_conv_params& p, int N, hipStream_t st) {
         attr_set = true;
     }
     const int grid = N * (p.Ho / TH) * (p.Wo / 16) * (p.Cout / BN);
-    hipLaunchKernelGGL((conv3x3_v3_kernel<TH, BN, WM, WN, WK, XF>), dim3(grid), dim3(K::NT), smem, st, p);
+    GDRN_LAUNCH((conv3x3_v3_kernel<TH, BN, WM, WN, WK, XF>), dim3(grid), dim3(K::NT), smem, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -745,7 +745,7 @@ extern "C" int gdrn_pack_wfrag32(const void* src, void* dst, int rows, int Cin, 
     if (dtype != GDRN_DT_H16) return GDRN_ERR_ARG;
     const long long n = (long long)rows * 9 * Cin / 8;
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_wfrag32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
+    GDRN_LAUNCH(pack_wfrag32_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)src, (bf16_t*)dst, rows, Cin);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

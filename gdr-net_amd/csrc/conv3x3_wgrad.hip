@@ -471,7 +471,7 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
             attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_w128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         });
         if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv3x3_wgrad_w128_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch, splits);
+        GDRN_LAUNCH(conv3x3_wgrad_w128_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch, splits);
         GDRN_CHECK_LAUNCH();
         return GDRN_OK;
     }
@@ -482,7 +482,7 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
     if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch,
+    GDRN_LAUNCH(conv3x3_wgrad_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch,
                        splits);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -508,7 +508,7 @@ extern "C" int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, 
             attr_set = smem;
         }
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(nblocks), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev,
+    GDRN_LAUNCH(conv3x3_wgrad_multi_kernel, dim3(nblocks), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev,
                        blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -532,7 +532,7 @@ extern "C" int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev,
     if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
     if (grid <= 0 || grid > nblocks) grid = nblocks;
     if (grid < nblocks && grid >= 8) grid &= ~7;
-    hipLaunchKernelGGL(conv3x3_wgrad_w128_multi_kernel, dim3(grid), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev, blk_start_dev,
+    GDRN_LAUNCH(conv3x3_wgrad_w128_multi_kernel, dim3(grid), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev, blk_start_dev,
                        ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -540,7 +540,7 @@ extern "C" int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev,
 
 extern "C" int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tasks_dev,
+    GDRN_LAUNCH(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tasks_dev,
                        blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

@@ -548,7 +548,7 @@ int launch(const gdrn_conv_params& p, hipStream_t st) {
     }
     const int NT = cdiv(p.Cout, BN);
     const int MT = (p.mode == 1) ? 4 * cdiv(p.M, BM) : cdiv(p.M, BM);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(MT * NT), dim3(256), smem, st, p);
+    GDRN_LAUNCH((conv_gemm_kernel<T, BM, BN>), dim3(MT * NT), dim3(256), smem, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

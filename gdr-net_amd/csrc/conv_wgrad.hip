@@ -228,7 +228,7 @@ int launch(const gdrn_wgrad_params& p, hipStream_t st) {
         constexpr int target = 2048;
         splits = max(1, min(nst / 8 > 0 ? nst / 8 : 1, cdiv(target, tiles)));
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BCO, BCI>), dim3(tiles * splits), dim3(256), smem, st, p);
+    GDRN_LAUNCH((conv_wgrad_kernel<T, BCO, BCI>), dim3(tiles * splits), dim3(256), smem, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

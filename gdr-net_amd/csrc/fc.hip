@@ -107,9 +107,9 @@ extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bia
     while (S > 1 && (K % (128 * S))) --S;
     const int kper = K / S;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(linear_splitk_kernel, dim3(ntile, S), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, M, K, N, x_rs, w_rs,
+    GDRN_LAUNCH(linear_splitk_kernel, dim3(ntile, S), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, M, K, N, x_rs, w_rs,
                        kper, ws);
-    hipLaunchKernelGGL(linear_finish_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, ws, S, bias, (bf16_t*)y, M, N, y_rs, act);
+    GDRN_LAUNCH(linear_finish_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, ws, S, bias, (bf16_t*)y, M, N, y_rs, act);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -695,19 +695,19 @@ int launch_ht_fwd(const float* head, int hs, const float* coord2d, const float* 
     const int blocks = (int)std::min<long long>((M + 15) / 16, 4096);
     if (ht64_ok(nreg, hs, pcs)) {
         if (dt == GDRN_DT_F32)
-            hipLaunchKernelGGL((head_tail_fwd64_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs,
+            GDRN_LAUNCH((head_tail_fwd64_kernel<float, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs,
                                gt_xyz, mv, mt, greg, acc, N, HW, write_pad, rows);
         else
-            hipLaunchKernelGGL((head_tail_fwd64_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs,
+            GDRN_LAUNCH((head_tail_fwd64_kernel<bf16_t, LOSS>), dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs,
                                gt_xyz, mv, mt, greg, acc, N, HW, write_pad, rows);
     } else {
         if (dt == GDRN_DT_F32)
-            hipLaunchKernelGGL(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
+            GDRN_LAUNCH(head_tail_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (float*)pnp_in, pcs, N, HW, nreg);
         else
-            hipLaunchKernelGGL(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
+            GDRN_LAUNCH(head_tail_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, head, hs, coord2d, extents, (bf16_t*)pnp_in, pcs, N, HW, nreg);
         if (LOSS) {
             const int lb = (int)std::min<long long>((M + 15) / 16, 2048);
-            hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(lb), dim3(256), 0, st, head, hs, gt_xyz, mv, mt, greg, N, HW, nreg, acc, rows);
+            GDRN_LAUNCH(map_loss_fwd_kernel, dim3(lb), dim3(256), 0, st, head, hs, gt_xyz, mv, mt, greg, N, HW, nreg, acc, rows);
         }
     }
     GDRN_CHECK_LAUNCH();
@@ -749,21 +749,21 @@ extern "C" int gdrn_map_loss_fwd(const float* head, int hs, const float* gt_xyz,
     if (hipMemsetAsync(acc, 0, 8 * sizeof(double), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     const long long M = (long long)N * HW;
     const int blocks = (int)std::min<long long>((M + 15) / 16, 2048);
-    hipLaunchKernelGGL(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc, 0);
+    GDRN_LAUNCH(map_loss_fwd_kernel, dim3(blocks), dim3(256), 0, ST, head, hs, gt_xyz, mask_visib, mask_trunc, gt_region, N, HW, nreg, acc, 0);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
 extern "C" int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* losses, void* stream) {
     if (!acc || !losses) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(map_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, acc, (double)N * (double)HW, losses);
+    GDRN_LAUNCH(map_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, acc, (double)N * (double)HW, losses);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
 extern "C" int gdrn_map_loss_finalize_rows(double* acc, int nrows, int N, int HW, float* losses, void* stream) {
     if (!acc || !losses || nrows <= 0 || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses);
+    GDRN_LAUNCH(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -782,18 +782,18 @@ extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in,
     const bool fast = ht64_ok(nreg, hs, dcs) && (d_pnp_in == nullptr || ht64_ok(nreg, hs, pcs));
     if (dt == GDRN_DT_F32) {
         if (fast)
-            hipLaunchKernelGGL(head_tail_bwd64_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in, (const float*)d_pnp_in, pcs,
+            GDRN_LAUNCH(head_tail_bwd64_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in, (const float*)d_pnp_in, pcs,
                                extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw, (float*)d_head, dcs, N, HW, write_pad);
         else
-            hipLaunchKernelGGL(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
+            GDRN_LAUNCH(head_tail_bwd_kernel<float>, dim3(blocks), dim3(256), 0, ST, head, hs, (const float*)pnp_in,
                                (const float*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
                                (float*)d_head, dcs, N, HW, nreg);
     } else {
         if (fast)
-            hipLaunchKernelGGL(head_tail_bwd64_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in, (const bf16_t*)d_pnp_in,
+            GDRN_LAUNCH(head_tail_bwd64_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in, (const bf16_t*)d_pnp_in,
                                pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw, (bf16_t*)d_head, dcs, N, HW, write_pad);
         else
-            hipLaunchKernelGGL(head_tail_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in,
+            GDRN_LAUNCH(head_tail_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, head, hs, (const bf16_t*)pnp_in,
                                (const bf16_t*)d_pnp_in, pcs, extents, gt_xyz, mask_visib, mask_trunc, gt_region, acc, gw,
                                (bf16_t*)d_head, dcs, N, HW, nreg);
     }
@@ -807,14 +807,14 @@ extern "C" int gdrn_pose_loss(const gdrn_pose_params* p, void* stream) {
     if (p->train && (!p->losses || !p->gt_rot || !p->gt_trans_ratio || !p->points || !p->extents || p->npts <= 0))
         return GDRN_ERR_ARG;
     if (p->losses && hipMemsetAsync(p->losses, 0, 3 * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
-    hipLaunchKernelGGL(pose_loss_kernel, dim3(p->N), dim3(256), 0, ST, *p);
+    GDRN_LAUNCH(pose_loss_kernel, dim3(p->N), dim3(256), 0, ST, *p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
 extern "C" int gdrn_combine3(const float* in, const float* w, float* out, int n, void* stream) {
     if (!in || !w || !out || n <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(combine3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, in, w, out, n);
+    GDRN_LAUNCH(combine3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, in, w, out, n);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

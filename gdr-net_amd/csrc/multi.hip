@@ -294,8 +294,8 @@ extern "C" int gdrn_pack_chunk(void) { return PACK_CHUNK; }
 
 extern "C" int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(pack_multi_kernel<float>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(pack_multi_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -303,7 +303,7 @@ extern "C" int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_s
 
 extern "C" int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(unpack_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    GDRN_LAUNCH(unpack_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -329,14 +329,14 @@ __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __rest
 extern "C" int gdrn_nonfinite_flag(const float* x, long long n, int* flag, void* stream) {
     if (!x || !flag || n <= 0 || (reinterpret_cast<uintptr_t>(x) & 15)) return GDRN_ERR_ARG;
     const int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
-    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, ST, x, n, flag);
+    GDRN_LAUNCH(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, ST, x, n, flag);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
 
 extern "C" int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(zero_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
+    GDRN_LAUNCH(zero_multi_kernel, dim3(nblocks), dim3(256), 0, ST, tasks_dev, blk_start_dev, ntasks);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -345,7 +345,7 @@ extern "C" int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* r
                                  float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha, float grad_scale,
                                  void* stream) {
     if (!tasks_dev || !row_start_dev || ntasks <= 0 || total_rows <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(ranger_multi_kernel, dim3(total_rows), dim3(256), 0, ST, tasks_dev, row_start_dev, ntasks, beta1, beta2, eps,
+    GDRN_LAUNCH(ranger_multi_kernel, dim3(total_rows), dim3(256), 0, ST, tasks_dev, row_start_dev, ntasks, beta1, beta2, eps,
                        weight_decay, step_size, adaptive, lookahead, alpha, grad_scale);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

@@ -740,7 +740,7 @@ extern "C" int gdrn_bn_finalize(const float* partial, int rows, int C, double co
                                 float* mean, float* invstd, float* scale, float* shift, double* ws, void* stream) {
     (void)ws;  // no workspace any more: one launch whatever the row count
     if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || (C & 3)) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3(C / 4), dim3(256), 0, ST, partial, rows, C, count, gamma, beta, running_mean,
+    GDRN_LAUNCH(bn_finalize_rows_kernel, dim3(C / 4), dim3(256), 0, ST, partial, rows, C, count, gamma, beta, running_mean,
                        running_var, nbt, momentum, eps, mean, invstd, scale, shift);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -750,7 +750,7 @@ extern "C" int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long n
                                 const float* invstd, float* a, float* b, float* c, float* dgamma, float* dbeta, void* stream) {
     if (!rows || !gamma || !mean || !invstd || !a || !b || !c || nrows <= 0 || C <= 0 || (C & 3) || npix <= 0) return GDRN_ERR_ARG;
     if ((dgamma != nullptr) != (dbeta != nullptr)) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(C / 4), dim3(256), 0, ST, rows, nrows, C, (float)(1.0 / (double)npix), gamma, mean,
+    GDRN_LAUNCH(bn_bwd_coef_kernel, dim3(C / 4), dim3(256), 0, ST, rows, nrows, C, (float)(1.0 / (double)npix), gamma, mean,
                        invstd, a, b, c, dgamma, dbeta);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -759,7 +759,7 @@ extern "C" int gdrn_bn_bwd_coef(const float* rows, int nrows, int C, long long n
 extern "C" int gdrn_bn_eval_params(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                                    float* scale, float* shift, void* stream) {
     if (!gamma || !beta || !rm || !rv || !scale || !shift || C <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, gamma, beta, rm, rv, eps, C, scale, shift);
+    GDRN_LAUNCH(bn_eval_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, gamma, beta, rm, rv, eps, C, scale, shift);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -772,9 +772,9 @@ extern "C" int gdrn_bn_apply(const void* x, const float* scale, const float* shi
     int rpb, blocks;
     ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)x, scale,
+             GDRN_LAUNCH(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)x, scale,
                                 shift, (const float*)residual, (float*)y, npix, C, relu, rpb),
-             hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)x,
+             GDRN_LAUNCH(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)x,
                                 scale, shift, (const bf16_t*)residual, (bf16_t*)y, npix, C, relu, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -810,9 +810,9 @@ extern "C" int gdrn_bn_bwd_reduce(const void* dy, const void* ymask, const void*
     int rpb, blocks;
     bwd_reduce_grid(npix, C, dtype, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
+             GDRN_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
                                 (const float*)ymask, (const float*)x, mean, invstd, mask_scale, mask_shift, npix, C, rows, rpb),
-             hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
+             GDRN_LAUNCH(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
                                 (const bf16_t*)ymask, (const bf16_t*)x, mean, invstd, mask_scale, mask_shift, npix, C, rows, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -828,10 +828,10 @@ extern "C" int gdrn_bn_bwd_apply(const void* dy, const void* ymask, const void* 
     int rpb, blocks;
     ew_rows(npix, C / V, &rpb, &blocks);
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
+             GDRN_LAUNCH(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy,
                                 (const float*)ymask, (const float*)x, a, b, c, mask_scale, mask_shift, npix, C,
                                 (float*)dx, (float*)g_out, rpb),
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
+             GDRN_LAUNCH(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy,
                                 (const bf16_t*)ymask, (const bf16_t*)x, a, b, c, mask_scale, mask_shift, npix, C,
                                 (bf16_t*)dx, (bf16_t*)g_out, rpb));
     GDRN_CHECK_LAUNCH();
@@ -844,9 +844,9 @@ extern "C" int gdrn_bn_relu_maxpool_fwd(const void* x, const float* scale, const
     if (C > 512 || (long long)N * H * W * C / 4 >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * (H / 2) * (W / 2) * C;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x,
+             GDRN_LAUNCH(bn_relu_maxpool_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x,
                                 scale, shift, (float*)y, idx, N, H, W, C),
-             hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x,
+             GDRN_LAUNCH(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x,
                                 scale, shift, (bf16_t*)y, idx, N, H, W, C));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -870,9 +870,9 @@ extern "C" int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const 
     }
     const long long n = (long long)N * H * W * C;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, idx,
+             GDRN_LAUNCH(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, idx,
                                 (const float*)x, scale, shift, (float*)g, N, H, W, C, mean, invstd, rows),
-             hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, idx,
+             GDRN_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, idx,
                                 (const bf16_t*)x, scale, shift, (bf16_t*)g, N, H, W, C, mean, invstd, rows));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -883,8 +883,8 @@ extern "C" int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, 
     if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;  // 4x upsampled element count / 4 per thread, 32-bit index math
     const long long n = (long long)N * 4 * H * W * C;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C),
-             hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
+             GDRN_LAUNCH(upsample2x_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C),
+             GDRN_LAUNCH(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -894,8 +894,8 @@ extern "C" int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W
     if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * H * W * C;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (float*)dx, N, H, W, C),
-             hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
+             GDRN_LAUNCH(upsample2x_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (float*)dx, N, H, W, C),
+             GDRN_LAUNCH(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -916,8 +916,8 @@ extern "C" int gdrn_gn_relu_fwd(const void* x, const float* gamma, const float* 
     const int CS = gn_slab(C, G, V);
     if (256 % (CS / V)) return GDRN_ERR_SHAPE;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(gn_relu_fwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)x, gamma, beta, (float*)y, mean_rstd, HW, C, G, eps, CS),
-             hipLaunchKernelGGL(gn_relu_fwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, HW, C, G, eps, CS));
+             GDRN_LAUNCH(gn_relu_fwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)x, gamma, beta, (float*)y, mean_rstd, HW, C, G, eps, CS),
+             GDRN_LAUNCH(gn_relu_fwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, HW, C, G, eps, CS));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -937,9 +937,9 @@ extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, co
         if (hipMemsetAsync(dbeta, 0, C * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     }
     DISPATCH(dtype,
-             hipLaunchKernelGGL(gn_relu_bwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)dy, (const float*)y,
+             GDRN_LAUNCH(gn_relu_bwd_kernel<float>, dim3(N, C / CS), dim3(256), 0, ST, (const float*)dy, (const float*)y,
                                 (const float*)x, gamma, mean_rstd, (float*)dx, dgamma, dbeta, HW, C, G, CS),
-             hipLaunchKernelGGL(gn_relu_bwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y,
+             GDRN_LAUNCH(gn_relu_bwd_kernel<bf16_t>, dim3(N, C / CS), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y,
                                 (const bf16_t*)x, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, HW, C, G, CS));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -948,8 +948,8 @@ extern "C" int gdrn_gn_relu_bwd(const void* dy, const void* y, const void* x, co
 extern "C" int gdrn_leaky_bwd(const void* dy, const void* y, void* dx, long long n, int dtype, void* stream) {
     if (!dy || !y || !dx || n <= 0 || (n % 8)) return GDRN_ERR_ARG;
     DISPATCH(dtype,
-             hipLaunchKernelGGL(leaky_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (const float*)y, (float*)dx, n / 4),
-             hipLaunchKernelGGL(leaky_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8));
+             GDRN_LAUNCH(leaky_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (const float*)y, (float*)dx, n / 4),
+             GDRN_LAUNCH(leaky_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -966,8 +966,8 @@ extern "C" int gdrn_bias_grad(const void* dy, int cs, int rows, int C, float* db
     int blocks = cdiv(rows, rpb);
     if (blocks > 1024) { rpb = cdiv(cdiv(rows, 1024), rpp) * rpp; blocks = cdiv(rows, rpb); }
     DISPATCH(dtype,
-             hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy, cs, rows, C, db, rpb),
-             hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy, cs, rows, C, db, rpb));
+             GDRN_LAUNCH(bias_grad_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy, cs, rows, C, db, rpb),
+             GDRN_LAUNCH(bias_grad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy, cs, rows, C, db, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

@@ -152,6 +152,18 @@ inline int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<lo
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 extern "C" int gdrn_version(void) { return GDRN_ABI_VERSION; }
+
+thread_local int gdrn_tls_hip_error = 0;
+extern "C" int gdrn_last_hip_error(char* name, int cap) {
+    const int e = gdrn_tls_hip_error;
+    if (name && cap > 0) {
+        const char* s = hipGetErrorName((hipError_t)e);
+        int i = 0;
+        for (; s && s[i] && i < cap - 1; ++i) name[i] = s[i];
+        name[i] = 0;
+    }
+    return e;
+}
 extern "C" int gdrn_half_format(void) { return GDRN_DT_H16; }
 
 extern "C" int gdrn_device_info(int dev, char* name, int* cus, char* arch) {
@@ -168,9 +180,9 @@ extern "C" int gdrn_pack4(const float* src, void* dst, int A1, int A2, int T, in
     if (!src || !dst || A1 <= 0 || A2 <= 0 || T <= 0 || B <= 0 || A1v > A1 || A2v > A2 || Bv > B) return GDRN_ERR_ARG;
     const long long n = (long long)A1 * A2 * T * B;
     if (dtype == GDRN_DT_F32)
-        hipLaunchKernelGGL(pack4_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
+        GDRN_LAUNCH(pack4_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
     else if (dtype == GDRN_DT_H16)
-        hipLaunchKernelGGL(pack4_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
+        GDRN_LAUNCH(pack4_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
     else
         return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
@@ -181,7 +193,7 @@ extern "C" int gdrn_unpack4(const float* packed, float* dst, int A1, int A2, int
                             long long s2, long long st, long long sb, int flip, void* stream) {
     if (!packed || !dst || A1 <= 0 || A2 <= 0 || T <= 0 || B <= 0 || A1v > A1 || A2v > A2 || Bv > B) return GDRN_ERR_ARG;
     const long long n = (long long)A1v * A2v * T * Bv;
-    hipLaunchKernelGGL(unpack4_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, packed, dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
+    GDRN_LAUNCH(unpack4_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, packed, dst, A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, flip);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -189,8 +201,8 @@ extern "C" int gdrn_unpack4(const float* packed, float* dst, int A1, int A2, int
 extern "C" int gdrn_pack_stem_w(const float* w, void* dst, int dtype, void* stream) {
     if (!w || !dst) return GDRN_ERR_ARG;
     const int n = 64 * 7 * 64;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_stem_w_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (float*)dst);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_stem_w_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (bf16_t*)dst);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(pack_stem_w_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (float*)dst);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(pack_stem_w_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, ST, w, (bf16_t*)dst);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -198,7 +210,7 @@ extern "C" int gdrn_pack_stem_w(const float* w, void* dst, int dtype, void* stre
 
 extern "C" int gdrn_unpack_stem_w(const float* packed, float* dw, void* stream) {
     if (!packed || !dw) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(unpack_stem_w_kernel, dim3(cdiv(64 * 147, 256)), dim3(256), 0, ST, packed, dw);
+    GDRN_LAUNCH(unpack_stem_w_kernel, dim3(cdiv(64 * 147, 256)), dim3(256), 0, ST, packed, dw);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -206,8 +218,8 @@ extern "C" int gdrn_unpack_stem_w(const float* packed, float* dw, void* stream) 
 extern "C" int gdrn_pack_image(const float* img, void* dst, int N, int H, int W, int Hp, int Wp, int dtype, void* stream) {
     if (!img || !dst || N <= 0 || Hp < H + 6 || Wp < W + 6) return GDRN_ERR_ARG;
     const long long n = (long long)N * Hp * Wp;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(pack_image_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (float*)dst, N, H, W, Hp, Wp);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(pack_image_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (bf16_t*)dst, N, H, W, Hp, Wp);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(pack_image_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (float*)dst, N, H, W, Hp, Wp);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(pack_image_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, img, (bf16_t*)dst, N, H, W, Hp, Wp);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -215,8 +227,8 @@ extern "C" int gdrn_pack_image(const float* img, void* dst, int N, int H, int W,
 
 extern "C" int gdrn_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream) {
     if (!src || !dst || n <= 0) return GDRN_ERR_ARG;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, n);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, n);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(cast_from_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (float*)dst, n);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(cast_from_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, src, (bf16_t*)dst, n);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -224,8 +236,8 @@ extern "C" int gdrn_cast_from_f32(const float* src, void* dst, long long n, int 
 
 extern "C" int gdrn_cast_to_f32(const void* src, float* dst, long long n, int dtype, void* stream) {
     if (!src || !dst || n <= 0) return GDRN_ERR_ARG;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, dst, n);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, dst, n);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(cast_to_f32_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, dst, n);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(cast_to_f32_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, dst, n);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -234,8 +246,8 @@ extern "C" int gdrn_cast_to_f32(const void* src, float* dst, long long n, int dt
 extern "C" int gdrn_nhwc_to_nchw_f32(const void* src, int cs, int c0, int C, float* dst, int N, int HW, int dtype, void* stream) {
     if (!src || !dst || N <= 0 || HW <= 0 || C <= 0 || c0 < 0 || c0 + C > cs) return GDRN_ERR_ARG;
     const long long n = (long long)N * C * HW;
-    if (dtype == GDRN_DT_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, cs, c0, C, dst, N, HW);
-    else if (dtype == GDRN_DT_H16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, cs, c0, C, dst, N, HW);
+    if (dtype == GDRN_DT_F32) GDRN_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, ST, (const float*)src, cs, c0, C, dst, N, HW);
+    else if (dtype == GDRN_DT_H16) GDRN_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, ST, (const bf16_t*)src, cs, c0, C, dst, N, HW);
     else return GDRN_ERR_ARG;
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -245,7 +257,7 @@ extern "C" int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float*
                                 int gc, float lr, float beta1, float beta2, float eps, float weight_decay, float step_size,
                                 int adaptive, int lookahead, float alpha, void* stream) {
     if (!p || !g || !exp_avg || !exp_avg_sq || !slow || rows <= 0 || cols <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(ranger_kernel, dim3(rows), dim3(256), 0, ST, p, g, exp_avg, exp_avg_sq, slow, cols, gc, lr, beta1, beta2,
+    GDRN_LAUNCH(ranger_kernel, dim3(rows), dim3(256), 0, ST, p, g, exp_avg, exp_avg_sq, slow, cols, gc, lr, beta1, beta2,
                        eps, weight_decay, step_size, adaptive, lookahead, alpha);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

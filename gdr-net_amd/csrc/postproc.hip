@@ -94,7 +94,7 @@ extern "C" int gdrn_correspondences(const float* mask, const float* coor_x, cons
     if (!mask || !coor_x || !coor_y || !coor_z || !extents || !im_hw || N <= 0 || HW <= 0 || pix_stride <= 0) return GDRN_ERR_ARG;
     if ((img_pts != nullptr) != (model_pts != nullptr)) return GDRN_ERR_ARG;
     if (img_pts && !coord2d) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(correspondences_kernel, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mask, coor_x, coor_y, coor_z,
+    GDRN_LAUNCH(correspondences_kernel, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mask, coor_x, coor_y, coor_z,
                        roi_stride, pix_stride, coord2d, extents, im_hw, mask_thr, HW, out_mask, out_xyz, img_pts, model_pts, counts);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

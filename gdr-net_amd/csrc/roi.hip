@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(const gdrn_roi_task* _
 extern "C" int gdrn_roi_affine(const gdrn_roi_task* tasks_dev, int B, int in_res, int out_res, double* minv, float* roi_wh,
                                float* resize_ratio, float* trans_ratio, void* stream) {
     if (!tasks_dev || !minv || B <= 0 || in_res <= 0 || out_res <= 0) return GDRN_ERR_ARG;
-    hipLaunchKernelGGL(roi_affine_kernel, dim3(cdiv(B * 2, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tasks_dev, B, in_res,
+    GDRN_LAUNCH(roi_affine_kernel, dim3(cdiv(B * 2, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tasks_dev, B, in_res,
                        out_res, minv, roi_wh, resize_ratio, trans_ratio);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -284,12 +284,12 @@ extern "C" int gdrn_roi_crop_inputs(const gdrn_roi_task* tasks_dev, const double
     if (roi_img && (!pixel_mean || !pixel_std)) return GDRN_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (roi_img) {
-        hipLaunchKernelGGL(roi_crop_image_kernel, dim3(cdiv(in_res * in_res, 256), B), dim3(256), 0, st, tasks_dev, minv, in_res, pixel_mean[0],
+        GDRN_LAUNCH(roi_crop_image_kernel, dim3(cdiv(in_res * in_res, 256), B), dim3(256), 0, st, tasks_dev, minv, in_res, pixel_mean[0],
                            pixel_mean[1], pixel_mean[2], pixel_std[0], pixel_std[1], pixel_std[2], roi_img);
         GDRN_CHECK_LAUNCH();
     }
     if (roi_coord_2d) {
-        hipLaunchKernelGGL(roi_crop_coord_kernel, dim3(cdiv(out_res * out_res, 256), B), dim3(256), 0, st, tasks_dev, minv, out_res, roi_coord_2d);
+        GDRN_LAUNCH(roi_crop_coord_kernel, dim3(cdiv(out_res * out_res, 256), B), dim3(256), 0, st, tasks_dev, minv, out_res, roi_coord_2d);
         GDRN_CHECK_LAUNCH();
     }
     return GDRN_OK;
@@ -303,7 +303,7 @@ extern "C" int gdrn_roi_targets(const gdrn_roi_task* tasks_dev, const double* mi
     if ((roi_region != nullptr) != (fps_points != nullptr)) return GDRN_ERR_ARG;
     if (roi_region && (nfps <= 0 || nfps > 1024)) return GDRN_ERR_ARG;
     const size_t lds = roi_region ? (size_t)nfps * 3 * sizeof(double) : 0;
-    hipLaunchKernelGGL(roi_targets_kernel, dim3(cdiv(out_res * out_res, 256), B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), tasks_dev,
+    GDRN_LAUNCH(roi_targets_kernel, dim3(cdiv(out_res * out_res, 256), B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), tasks_dev,
                        minv, out_res, fps_points, nfps, extents, roi_xyz, roi_mask_trunc, roi_mask_visib, roi_mask_obj, roi_region);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

@@ -278,11 +278,11 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
     const int per = cdiv(nstages, SW_PARTS);
     const int parts = cdiv(nstages, per);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(parts), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(g),
+    GDRN_LAUNCH(stem_wgrad_kernel, dim3(parts), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(g),
                        reinterpret_cast<const bf16_t*>(raw), a, b, c, nstages, per, ws);
     GDRN_CHECK_LAUNCH();
     if (!prezeroed && hipMemsetAsync(grad, 0, 64 * 147 * sizeof(float), st) != hipSuccess) return GDRN_ERR_LAUNCH;
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64, SW_SLICES), dim3(256), 0, st, ws, parts, grad);
+    GDRN_LAUNCH(stem_wgrad_reduce_kernel, dim3(64, SW_SLICES), dim3(256), 0, st, ws, parts, grad);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -290,7 +290,7 @@ extern "C" int gdrn_stem_wgrad(const void* canvas, const void* g, const void* ra
 extern "C" int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream) {
     if (!w || !dst) return GDRN_ERR_ARG;
     if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
-    hipLaunchKernelGGL(pack_stem_w32_kernel, dim3(cdiv(64 * 7 * 32, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+    GDRN_LAUNCH(pack_stem_w32_kernel, dim3(cdiv(64 * 7 * 32, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
                        reinterpret_cast<bf16_t*>(dst));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
@@ -312,7 +312,7 @@ extern "C" int gdrn_stem_conv(const void* canvas, const void* w32, void* y, floa
     const int ntiles = N * 128 * 8;
     const int tpw = cdiv(ntiles, STEM_WAVES);
     const int waves = cdiv(ntiles, tpw);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    GDRN_LAUNCH(stem_conv_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(w32), reinterpret_cast<bf16_t*>(y), stats,
                        ntiles, tpw);
     GDRN_CHECK_LAUNCH();

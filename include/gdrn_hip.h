@@ -43,6 +43,9 @@ enum { GDRN_F32 = GDRN_DT_F32, GDRN_BF16 = GDRN_DT_BF16, GDRN_E_ARG = GDRN_ERR_A
 enum { GDRN_WGRAD_T64 = 0, GDRN_WGRAD_W128 = 1 };
 
 int gdrn_version(void);
+/* Diagnostics: the HIP error code (hipError_t) behind the calling thread's most recent GDRN_ERR_LAUNCH, its name copied into `name` (cap bytes,
+ * may be NULL); 0 if no launch of this thread has failed.  (ABI 3) */
+int gdrn_last_hip_error(char* name, int cap);
 int gdrn_half_format(void);   /* GDRN_DT_BF16 or GDRN_DT_F16: the 16-bit dtype code this library build accepts */
 /* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
  * memory, no initialisation needed unless stated): `op` selects the buffer, `params` points at the arguments that determine its
