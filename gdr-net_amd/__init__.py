@@ -5,7 +5,8 @@ Imported as ``gdrnet_amd`` (see ``gdrnet_amd/__init__.py``).  Sub-modules:
 * ``cabi``    -- ctypes loader of the C-ABI HIP library ``libgdrn_hip.so`` (include/gdrn_hip.h)
 * ``cfg``     -- attribute-dict config with the reference's ``MODEL.CDPN`` keys
 * ``synth``   -- repo-owned hash RNG, deterministic weights, synthetic RoI batches
-* ``engine``  -- forward / backward executor of the path on HIP kernels
+* ``engine``  -- forward / backward executor of the path on HIP kernels: per-model state (operand copies, gradient buckets, streams)
+* ``plan``    -- its per-batch-size launch lists (static buffers + pre-bound C-ABI calls), forward and backward
 * ``GDRN``    -- drop-in for ``core/gdrn_modeling/models/GDRN.py`` (GDRN, build_model_optimizer)
 * ``ranger``  -- fused Ranger optimizer step on HIP
 * ``dist``    -- RCCL gradient all-reduce for the one-process-per-GPU data-parallel path

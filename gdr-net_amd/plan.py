@@ -88,7 +88,7 @@ class Plan:
         # 256@16x16 22.3 -> 21.7 us plain, 27.2 -> 24.6 with the BatchNorm-backward transform; 512@8x8 25.1 -> 23.8 / 30.5 -> 26.5; inference
         # 1.98 -> 1.96 ms); the data gradients of a two-stream backward pass keep four waves -- two 235-register waves per SIMD leave the
         # side stream's weight gradient no room on the CU (7.37 -> 7.70 ms per step with eight waves everywhere, 7.93 -> 7.85 on one stream)
-        cp.halo_waves = e.halo_waves or (4 if (w is not None and e.wgrad_stream) else 0)
+        cp.halo_waves = e.halo_waves or (4 if (w is not None and (e.wgrad_stream or e.wgrad_force_lds)) else 0)   # ("serial": the two-stream step's launches)
         cp.v3_min_wg = e.v3_min_wg
         self.keep.append(cp)
         ref = C.byref(cp)
