@@ -107,6 +107,7 @@ _SIGS = {
     "gdrn_pack_stem_w32": [P, P, I, P],
     "gdrn_stem_stats_rows": [I],
     "gdrn_stem_conv": [P, P, P, P, I, I, P],
+    "gdrn_stem_conv_pool": [P, P, P, P, P, I, I, P],
     "gdrn_stem_wgrad_parts": [I],
     "gdrn_stem_wgrad": [P, P, P, P, P, P, I, P, P, I, P],
     "gdrn_linear_splitk": [P, P, P, P, I, I, I, I, I, I, I, P, I, P],

@@ -100,6 +100,119 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
 constexpr int STEM_WAVES = 4096;  // 1024 workgroups
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Eval-mode stem in ONE kernel (r5): conv 7x7 s2 -> BatchNorm with running statistics (per-channel scale / shift) -> ReLU -> max-pool 3x3 s2 pad 1
+// (resnet_backbone.py:69-72 with module.eval()).  As two kernels the 134 MB conv output is written and fetched 1.5 times again by the pool
+// (53 + 43 us at bs = 64); here it never leaves the registers.  A wave owns a vertical strip -- 16 conv columns x 33 conv rows of one image =
+// 7 x 16 pooled pixels -- and walks it downwards:
+//   * columns: the strip starts at the ODD conv column 14k - 1, so that the seven pooling windows centred on conv columns 14k, 14k + 2, ..
+//     lie inside it (result-lane column r16 = 1, 3, .. 13 with its neighbours r16 +- 1: two DPP row shifts, no LDS); strips advance by 14;
+//   * rows: consecutive conv rows share five of their seven canvas rows -- a sliding window of seven 16-byte fragments per lane, two new
+//     loads per conv row instead of seven; the vertical max runs on the way: h(row) = horizontal 3-max, even row 2p: m = max(h(2p-1), h(2p)),
+//     odd row 2p+1: pooled row p = max(m, h(2p+1)) is stored and h(2p+1) kept for p + 1;
+//   * arithmetic: the accumulator is rounded to the 16-bit format before the affine, exactly where the two-kernel path stores it, so the
+//     pooled tensor is bit-identical to gdrn_stem_conv -> gdrn_bn_relu_maxpool_fwd (post-ReLU values are >= 0: padding contributes 0).
+constexpr int SP_BAND = 16;     // pooled rows per wave
+constexpr int SP_STRIPS = 10;   // strips per row: pooled columns 7k .. 7k + 6 (the last strip holds column 63 alone)
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {   // lane i <- lane i - 1 of its 16-lane row, 0 at the row's first lane
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_shl1(float v) {   // lane i <- lane i + 1, 0 at the row's last lane
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(256) void stem_conv_pool_kernel(const bf16_t* __restrict__ canvas, const bf16_t* __restrict__ w32,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             bf16_t* __restrict__ y, int nwaves) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= nwaves) return;
+    const int strip = gw % SP_STRIPS, band = (gw / SP_STRIPS) % (64 / SP_BAND), n = gw / (SP_STRIPS * (64 / SP_BAND));
+    uint4 wq[4][7];   // as stem_conv_kernel: fragment t, row r16 <-> channel (r16 >> 2) * 16 + t * 4 + (r16 & 3)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+            wq[t][ky] = *reinterpret_cast<const uint4*>(w32 + ((((r16 >> 2) * 16 + t * 4 + (r16 & 3)) * 7 + ky) * 32) + g * 8);
+    float sc[4][4], sh[4][4];   // the lane's 16 result channels g*16 + t*4 + j
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(scale + g * 16 + t * 4), b = *reinterpret_cast<const float4*>(shift + g * 16 + t * 4);
+        sc[t][0] = a.x; sc[t][1] = a.y; sc[t][2] = a.z; sc[t][3] = a.w;
+        sh[t][0] = b.x; sh[t][1] = b.y; sh[t][2] = b.z; sh[t][3] = b.w;
+    }
+    const int ox = 14 * strip - 1 + r16;                 // this lane's conv column
+    const bool col_ok = (unsigned)ox < 128u;
+    const int oxc = min(max(ox, 0), 127);
+    const int pb = band * SP_BAND;                       // first pooled row
+    const int oy0 = 2 * pb - 1, oy1 = 2 * pb + 2 * SP_BAND - 1;   // conv rows oy0 (halo: feeds pooled row pb only) .. oy1
+    const int oys = max(oy0, 0);
+    // canvas row r, this lane's 8 pixels x 4 channels starting at canvas column 2*ox (+ 2*g pixels for k-group g)
+    const bf16_t* cbase = canvas + ((size_t)n * HP * WP + 2 * oxc + 2 * g) * 4;
+    auto crow = [&](int r) { return *reinterpret_cast<const uint4*>(cbase + (size_t)r * WP * 4); };
+    uint4 xr[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) xr[ky] = crow(2 * oys + ky);
+    float hprev[4][4], m[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hprev[t][j] = 0.f; m[t][j] = 0.f; }
+    const int px = 7 * strip + (r16 >> 1);               // pooled column of an odd result lane
+    const bool store_lane = (r16 & 1) && r16 <= 13 && px < 64;
+    for (int oy = oys; oy <= oy1; ++oy) {
+        uint4 n0 = xr[0], n1 = xr[1];
+        if (oy < oy1) { n0 = crow(2 * oy + 7); n1 = crow(2 * oy + 8); }   // the next conv row's two new canvas rows, under this row's MFMAs
+        f32x4_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, wq[t][ky]), __builtin_bit_cast(bf16x8_t, xr[ky]), acc[t]);
+        float h[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t p01 = pack_bf2(acc[t][0], acc[t][1]), p23 = pack_bf2(acc[t][2], acc[t][3]);   // the stored conv output
+            const float x[4] = {h16lo(p01), h16hi(p01), h16lo(p23), h16hi(p23)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = fmaxf(x[j] * sc[t][j] + sh[t][j], 0.f);
+                v = col_ok ? v : 0.f;
+                h[t][j] = fmaxf(v, fmaxf(dpp_row_shr1(v), dpp_row_shl1(v)));
+            }
+        }
+        if (oy & 1) {
+            if (oy > oy0 && store_lane) {   // pooled row (oy - 1) / 2 is complete
+                uint32_t o[8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[2 * t] = pack_bf2(fmaxf(m[t][0], h[t][0]), fmaxf(m[t][1], h[t][1]));
+                    o[2 * t + 1] = pack_bf2(fmaxf(m[t][2], h[t][2]), fmaxf(m[t][3], h[t][3]));
+                }
+                bf16_t* yp = y + ((size_t)(n * 64 + (oy >> 1)) * 64 + px) * 64 + g * 16;
+                *reinterpret_cast<uint4*>(yp) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(yp + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hprev[t][j] = h[t][j];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[t][j] = fmaxf(hprev[t][j], h[t][j]);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) xr[ky] = xr[ky + 2];
+        xr[5] = n0;
+        xr[6] = n1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Stem weight gradient fused with the BatchNorm-backward "apply" that precedes it.  The stem has no data gradient, so the
 // gradient w.r.t. the conv output, dy = a*g + (b*x + c) per channel (bn_bwd_apply_kernel's formula, rounded to bf16 as that
 // kernel stores it), is consumed by this weight gradient only: it is evaluated here while the tile is staged, instead of
@@ -305,6 +418,19 @@ extern "C" int gdrn_stem_stats_rows(int N) {
 
 // canvas: [N][262][272][4] bf16 (gdrn_pack_image of 256x256 images); w32: gdrn_pack_stem_w32; y: [N][128][128][64] bf16;
 // stats (nullable): [gdrn_stem_stats_rows(N)][2][64] fp32 partial sums / sums of squares for gdrn_bn_finalize.
+// eval mode: conv + BatchNorm (scale / shift of the running statistics) + ReLU + 3x3 s2 max-pool in one pass; y: [N][64][64][64], bit-identical
+// to gdrn_stem_conv -> gdrn_bn_relu_maxpool_fwd
+extern "C" int gdrn_stem_conv_pool(const void* canvas, const void* w32, const float* scale, const float* shift, void* y, int N, int dtype, void* stream) {
+    if (!canvas || !w32 || !scale || !shift || !y || N <= 0) return GDRN_ERR_ARG;
+    if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
+    if ((long long)N * HP * WP * 8 >= (1ll << 40)) return GDRN_ERR_SHAPE;
+    const int nwaves = N * (64 / SP_BAND) * SP_STRIPS;
+    GDRN_LAUNCH(stem_conv_pool_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                reinterpret_cast<const bf16_t*>(canvas), reinterpret_cast<const bf16_t*>(w32), scale, shift, reinterpret_cast<bf16_t*>(y), nwaves);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
 extern "C" int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, int N, int dtype, void* stream) {
     if (!canvas || !w32 || !y || N <= 0) return GDRN_ERR_ARG;
     if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;

@@ -538,11 +538,14 @@ class Plan:
         # ---------------- stem
         Ls = e.layers["backbone.conv1"]
         self.img_p = e._zeros(B, 262, 272, 4)
-        raw0 = E(B, 128, 128, 64)
+        fused_stem = e.stem_direct and not S   # eval mode: conv + bn1 + ReLU + max-pool in one kernel (gdrn_stem_conv_pool): no raw0 / idx0
+        raw0 = None if fused_stem else E(B, 128, 128, 64)
         p0 = E(B, 64, 64, 64)
-        idx0 = E(B, 64, 64, 64, dtype=torch.uint8)
+        idx0 = None if fused_stem else E(B, 64, 64, 64, dtype=torch.uint8)
         self.fwd.append(lambda st, ctx: check(lib.gdrn_pack_image(ctx["img"], ptr(self.img_p), B, 256, 256, 262, 272, e.dt, st), "pack_image"))
-        if e.stem_direct:
+        if fused_stem:
+            cp = None
+        elif e.stem_direct:
             cp = NS(_stats_rows=int(lib.gdrn_stem_stats_rows(B)))
 
             def stem(st, ctx):
@@ -556,9 +559,16 @@ class Plan:
             self.fwd.append(op)
         self.fwd += self._bn_fwd("backbone.bn1", raw0, cp, 64, B * 128 * 128, None)
         s0 = self.bn["backbone.bn1"]
-        self.fwd.append(lambda st, ctx: check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw0), ptr(s0.scale), ptr(s0.shift), ptr(p0), ptr(idx0),
-                                                                           B, 128, 128, 64, e.dt, st), "bn_relu_maxpool"))
-        self.tensors.update({"stem.raw": raw0, "stem.pool": p0})
+        if fused_stem:
+            def stem_pool(st, ctx):
+                check(lib.gdrn_stem_conv_pool(ptr(self.img_p), ptr(e.stem_w32), ptr(s0.scale), ptr(s0.shift), ptr(p0), B, e.dt, st), "stem_conv_pool")
+
+            stem_pool.meta = dict(kernel="stem_conv_pool_kernel", flops=2.0 * B * 128 * 128 * 64 * 147, layer="backbone.conv1+bn1+relu+maxpool")
+            self.fwd.append(stem_pool)
+        else:
+            self.fwd.append(lambda st, ctx: check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw0), ptr(s0.scale), ptr(s0.shift), ptr(p0), ptr(idx0),
+                                                                               B, 128, 128, 64, e.dt, st), "bn_relu_maxpool"))
+        self.tensors.update({"stem.pool": p0} if fused_stem else {"stem.raw": raw0, "stem.pool": p0})
         if T:
             d_p0 = E(B, 64, 64, 64)
             g_stem = E(B, 128, 128, 64)

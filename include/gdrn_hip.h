@@ -145,6 +145,10 @@ int gdrn_conv_tile(const gdrn_conv_params* p, int* bm, int* bn);
 int gdrn_pack_stem_w32(const float* w, void* dst, int dtype, void* stream);
 int gdrn_stem_stats_rows(int N);
 int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, int N, int dtype, void* stream);
+/* Eval mode (module.eval(): BatchNorm on its running statistics): the stem conv, bn1 as per-channel scale / shift (gdrn_bn_eval_params), ReLU and
+ * the 3x3 stride-2 max-pool of resnet_backbone.py:69-72 in one pass -- y = [N][64][64][64], bit-identical to gdrn_stem_conv followed by
+ * gdrn_bn_relu_maxpool_fwd, without the 134 MB round trip of the conv output (ABI 3). */
+int gdrn_stem_conv_pool(const void* canvas, const void* w32, const float* scale, const float* shift, void* y, int N, int dtype, void* stream);
 /* Stem weight gradient (backward-weight of nn.Conv2d(3, 64, 7, 2, 3), resnet_backbone.py:23, implicit in engine.py:279) fused with
  * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel
  * (gdrn_bn_bwd_apply's formula, rounded to bf16) is evaluated while the tile is staged instead of being written and re-read.

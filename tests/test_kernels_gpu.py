@@ -1095,3 +1095,33 @@ def test_nonfinite_flag(H):
         x[pos] = old
     flag.zero_()
     assert run() == 0
+
+
+@pytest.mark.parametrize("N", [1, 3])
+def test_stem_conv_pool_eval_equals_the_two_kernel_path_bit_for_bit(H, N):
+    """gdrn_stem_conv_pool (eval mode: conv 7x7 s2 + BatchNorm scale / shift + ReLU + 3x3 s2 max-pool in one kernel, r5) against
+    gdrn_stem_conv -> gdrn_bn_relu_maxpool_fwd: the pooled tensor bit-identical (the fused kernel rounds the conv output to the 16-bit format
+    where the two-kernel path stores it), and against torch on the rounded operands."""
+    lib, dev, dt = cabi.load(BF16), H.DEV, BF16
+    img = torch.rand(N, 3, 256, 256, generator=torch.Generator().manual_seed(7)).to(dev)
+    w = H.randn(8, 64, 3, 7, 7) / math.sqrt(147.0)
+    scale = (torch.rand(64, generator=torch.Generator().manual_seed(9)) + 0.5).to(dev)
+    shift = (H.randn(10, 64) * 0.3).to(dev)
+    canvas = torch.zeros(N, 262, 272, 4, dtype=HT, device=dev)
+    check(lib.gdrn_pack_image(ptr(img), ptr(canvas), N, 256, 256, 262, 272, dt, H.stream()), "pack_image")
+    w32 = torch.zeros(64 * 7 * 32, dtype=HT, device=dev)
+    wd = w.to(dev).contiguous()
+    check(lib.gdrn_pack_stem_w32(ptr(wd), ptr(w32), dt, H.stream()), "pack_stem_w32")
+    raw = torch.empty(N, 128, 128, 64, dtype=HT, device=dev)
+    check(lib.gdrn_stem_conv(ptr(canvas), ptr(w32), ptr(raw), None, N, dt, H.stream()), "stem_conv")
+    want = torch.empty(N, 64, 64, 64, dtype=HT, device=dev)
+    idx = torch.empty(N, 64, 64, 64, dtype=torch.uint8, device=dev)
+    check(lib.gdrn_bn_relu_maxpool_fwd(ptr(raw), ptr(scale), ptr(shift), ptr(want), ptr(idx), N, 128, 128, 64, dt, H.stream()), "bn_relu_maxpool")
+    got = torch.full((N, 64, 64, 64), float("nan"), dtype=HT, device=dev)
+    check(lib.gdrn_stem_conv_pool(ptr(canvas), ptr(w32), ptr(scale), ptr(shift), ptr(got), N, dt, H.stream()), "stem_conv_pool")
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), float((got.float() - want.float()).abs().max())
+    ref = F.max_pool2d(F.relu(H.rounded(F.conv2d(H.rounded(img.cpu(), dt), H.rounded(w, dt), None, 2, 3), dt) * scale.cpu().view(1, -1, 1, 1)
+                              + shift.cpu().view(1, -1, 1, 1)), 3, 2, 1)
+    assert H.rel(H.nchw(got, 64), ref) < TOL[dt]
