@@ -179,6 +179,108 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------ eval mode: 1x1 output conv + head tail, nreg == 64
+// The head's last layer -- nn.Conv2d(256, 69, 1) of cdpn_rot_head_region.py:127-135 -- and the glue behind it (GDRN.py:156-169: slice, softmax
+// over region[:, 1:], concat with roi_coord_2d, extent scaling) in ONE pass over the 256-channel activation (r5, inference only: in train mode the
+// BatchNorm in front of the conv needs the whole tensor's statistics and the losses want the logits).  As two launches the fp32 logits
+// (75 MB at bs = 64) are written by a generic 128 x 128 GEMM tile of which 59 columns are padding and read back by the tail (70 + 28 us).
+// Here: the 69 x 256 weights sit in LDS in MFMA fragment order (5 fragments of 16 channels x 8 k-steps = 40 KB, shared by the four waves); a
+// wave takes 16 pixels at a time, its B fragments (pixel r16, 8 input channels per k-group) straight from global memory, 40 MFMAs with the bias as
+// the accumulator's initial value, then parks the 16 x 80 logit tile in its own 5 KB of LDS and re-reads it in the tail's lane map (16 lanes per
+// pixel, four classes per lane): the softmax and the stores are head_tail_fwd64_kernel's.  `head` (nullable) still receives the fp32 logits for
+// callers that return the maps (cfg.TEST.USE_PNP, gdrn_correspondences).
+constexpr int HCT_PITCH = 84;   // floats per pixel row of the wave's logit tile (80 + 4: consecutive pixels 16 bytes apart in the bank map)
+template <typename T>
+__global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __restrict__ x, int x_cs, const bf16_t* __restrict__ w,
+                                                               const float* __restrict__ bias, const float* __restrict__ coord2d,
+                                                               const float* __restrict__ extents, float* __restrict__ head, int hs,
+                                                               T* __restrict__ pnp, int pcs, int N, int HW, int ngroups) {
+    __shared__ __attribute__((aligned(16))) uint4 wl[5 * 8 * 64];            // [fragment][k-step][lane]: one ds_read_b128 per A operand, conflict-free
+    __shared__ __attribute__((aligned(16))) float tile[4][16 * HCT_PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    for (int i = threadIdx.x; i < 5 * 8 * 64; i += 256) {   // A operand: row = output channel 16f + (l & 15), k = 32 ks + 8 (l >> 4) .. + 7
+        const int l = i & 63, ks = (i >> 6) & 7, f = i >> 9;
+        const int row = 16 * f + (l & 15);
+        wl[i] = row < 69 ? *reinterpret_cast<const uint4*>(w + (size_t)row * 256 + 32 * ks + 8 * (l >> 4)) : make_uint4(0, 0, 0, 0);
+    }
+    f32x4_t bv[5];   // bias of the lane's result channels 16f + 4g + j
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = 16 * f + 4 * g + j; bv[f][j] = c < 69 ? bias[c] : 0.f; }
+    __syncthreads();
+    float* tw = tile[wave];
+    const int q = lane & 15, sub = lane >> 4;
+    const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    uint4 xq[8], xn[8];
+    auto xload = [&](int grp, uint4 (&dst)[8]) {
+        const long long m = (long long)grp * 16 + r16;
+        const bf16_t* px = x + (size_t)m * x_cs + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) dst[ks] = *reinterpret_cast<const uint4*>(px + 32 * ks);
+    };
+    if (gw < ngroups) xload(gw, xq);
+    for (int grp = gw; grp < ngroups; grp += nw) {
+        if (grp + nw < ngroups) xload(grp + nw, xn);   // the next pixel group's operand under this group's MFMAs and tail
+        f32x4_t acc[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) acc[f] = bv[f];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int f = 0; f < 5; ++f)
+                acc[f] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, wl[(f * 8 + ks) * 64 + lane]), __builtin_bit_cast(bf16x8_t, xq[ks]), acc[f]);
+        // D[i = 4g + j][col = r16] of fragment f = channel 16f + 4g + j of pixel r16 -> tile[pixel][channel]
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+            *reinterpret_cast<float4*>(tw + r16 * HCT_PITCH + 16 * f + 4 * g) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is this wave's own: its LDS operations complete in order
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {   // the tail, four pixels per pass (16 lanes each), as head_tail_fwd64_kernel
+            const int pl = 4 * s4 + sub;
+            const long long m = (long long)grp * 16 + pl;
+            const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
+            const float* h = tw + pl * HCT_PITCH;
+            float r[4], h03[4];
+            load4<float>(h + 4 + 4 * q, r);
+            load4<float>(h, h03);
+            const float h68 = h[68];
+            const float c2x = coord2d[((size_t)n * 2 + 0) * HW + pix], c2y = coord2d[((size_t)n * 2 + 1) * HW + pix];
+            const float ex[3] = {extents[n * 3 + 0], extents[n * 3 + 1], extents[n * 3 + 2]};
+            if (head != nullptr) {   // the fp32 logits, 72 floats per pixel: 16 lanes x 16 bytes + two more
+                float* ho = head + m * hs;
+                store4<float>(ho + 4 * q, *reinterpret_cast<const float(*)[4]>(h + 4 * q));
+                if (q < 2) store4<float>(ho + 64 + 4 * q, *reinterpret_cast<const float(*)[4]>(h + 64 + 4 * q));
+            }
+            const float r64 = (q == 15) ? h68 : -INFINITY;
+            float mx = fmaxf(fmaxf(q == 0 ? -INFINITY : r[0], r[1]), fmaxf(fmaxf(r[2], r[3]), r64));
+            mx = row16_max(mx);
+            float e[4], e64;
+            e[0] = (q == 0) ? 0.f : expf(r[0] - mx);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) e[j] = expf(r[j] - mx);
+            e64 = (q == 15) ? expf(r64 - mx) : 0.f;
+            const float inv = 1.f / row16_sum(e[0] + e[1] + e[2] + e[3] + e64);
+            T* o = pnp + m * pcs;
+            float v[4] = {e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv};
+            if (q == 0) v[0] = c2y;
+            store4<T>(o + 4 + 4 * q, v);
+            if (q == 15) {
+                const float wv[4] = {e64 * inv, 0.f, 0.f, 0.f};
+                store4<T>(o + 68, wv);
+            } else if (q == 14) {
+                const float wv[4] = {(h03[1] - 0.5f) * ex[0], (h03[2] - 0.5f) * ex[1], (h03[3] - 0.5f) * ex[2], c2x};
+                store4<T>(o, wv);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tail's reads are done before the next group overwrites the tile
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xq[ks] = xn[ks];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ map losses fwd
 __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restrict__ head, int hs,
                                                            const float* __restrict__ gt_xyz,
@@ -729,6 +831,24 @@ extern "C" int gdrn_head_tail_fwd(const float* head, int hs, const float* coord2
         pcs < nreg + 5 || (dt != GDRN_DT_F32 && dt != GDRN_DT_H16))
         return GDRN_ERR_ARG;
     return launch_ht_fwd<false>(head, hs, coord2d, extents, pnp_in, pcs, nullptr, nullptr, nullptr, nullptr, nullptr, N, HW, nreg, dtype, ST);
+}
+
+// eval mode, nreg = 64: the head's 1x1 output conv (256 -> 69, weight rows [>= 69][256] in the 16-bit format, fp32 bias) + gdrn_head_tail_fwd in
+// one launch; x: [N*HW][x_cs] 16-bit activations, head (nullable): fp32 logits [N*HW][hs >= 72], pnp_in: [N*HW][pcs >= 72] (pad channels the caller's)
+extern "C" int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d,
+                                       const float* extents, float* head, int hs, void* pnp_in, int pcs, int N, int HW, int nreg, int dtype,
+                                       void* stream) {
+    const int dt = dtype & 0xff;
+    if (!x || !w || !bias || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
+    if (dt != GDRN_DT_H16 || nreg != 64 || w_rows < 69 || x_cs < 256 || (x_cs & 7) || pcs < 72 || (pcs & 3) || (head && (hs < 72 || (hs & 3)))) return GDRN_ERR_SHAPE;
+    const long long M = (long long)N * HW;
+    if ((M & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    const int ngroups = (int)(M / 16);
+    const int blocks = (int)std::min<long long>((ngroups + 3) / 4, 1024);   // two 62 KB workgroups per CU, two rounds
+    GDRN_LAUNCH(head_conv_tail64_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
+                coord2d, extents, head, hs, reinterpret_cast<bf16_t*>(pnp_in), pcs, N, HW, ngroups);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
 }
 
 extern "C" int gdrn_head_tail_loss_fwd(const float* head, int hs, const float* coord2d, const float* extents, void* pnp_in, int pcs,

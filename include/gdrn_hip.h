@@ -148,6 +148,11 @@ int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, i
 /* Eval mode (module.eval(): BatchNorm on its running statistics): the stem conv, bn1 as per-channel scale / shift (gdrn_bn_eval_params), ReLU and
  * the 3x3 stride-2 max-pool of resnet_backbone.py:69-72 in one pass -- y = [N][64][64][64], bit-identical to gdrn_stem_conv followed by
  * gdrn_bn_relu_maxpool_fwd, without the 134 MB round trip of the conv output (ABI 3). */
+/* Eval mode, 64 regions: the geometric head's 1x1 output conv (nn.Conv2d(256, 69, 1), cdpn_rot_head_region.py:127-135; w = weight rows
+ * [>= 69][256] in the 16-bit format, fp32 bias) and gdrn_head_tail_fwd (GDRN.py:156-169) in one launch: the fp32 logits go to `head` only if it
+ * is non-NULL ([N*HW][hs >= 72]; callers that return the maps), pnp_in as gdrn_head_tail_fwd writes it (ABI 3). */
+int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d, const float* extents,
+                            float* head, int hs, void* pnp_in, int pcs, int N, int HW, int nreg, int dtype, void* stream);
 int gdrn_stem_conv_pool(const void* canvas, const void* w32, const float* scale, const float* shift, void* y, int N, int dtype, void* stream);
 /* Stem weight gradient (backward-weight of nn.Conv2d(3, 64, 7, 2, 3), resnet_backbone.py:23, implicit in engine.py:279) fused with
  * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel

@@ -1125,3 +1125,49 @@ def test_stem_conv_pool_eval_equals_the_two_kernel_path_bit_for_bit(H, N):
     ref = F.max_pool2d(F.relu(H.rounded(F.conv2d(H.rounded(img.cpu(), dt), H.rounded(w, dt), None, 2, 3), dt) * scale.cpu().view(1, -1, 1, 1)
                               + shift.cpu().view(1, -1, 1, 1)), 3, 2, 1)
     assert H.rel(H.nchw(got, 64), ref) < TOL[dt]
+
+
+def test_head_conv_tail_eval_equals_the_two_launch_path(H):
+    """gdrn_head_conv_tail_fwd (inference: the head's 1x1 output conv 256 -> 69 + the head tail in one kernel, r5) against the reference's
+    arithmetic (F.conv2d on the rounded operands -> slice / softmax / concat / extent scaling, cdpn_rot_head_region.py:127-135, GDRN.py:156-169)
+    and against the two-launch path gdrn_conv_gemm -> gdrn_head_tail_fwd on the same operands."""
+    from gdrnet_amd import synth
+
+    lib, dev, dt, st = cabi.load(BF16), H.DEV, BF16, H.stream()
+    B, HW, nreg, hs = 2, 4096, 64, 72
+    M = B * HW
+    b = synth.make_batch(B, seed=9)
+    x = H.rounded(torch.relu(H.randn(120, B, 256, 64, 64)), dt)
+    w = H.rounded(H.randn(121, 69, 256, 1, 1) / 16.0, dt)
+    bias = H.randn(122, 69) * 0.2
+    logits = F.conv2d(x, w, bias)
+    sm = torch.softmax(logits[:, 5:], 1)
+    pnp_ref = torch.cat([(logits[:, 1:4] - 0.5) * b["roi_extent"].view(B, 3, 1, 1), b["roi_coord_2d"], sm], 1)
+    f = lambda t: t.to(dev).float().contiguous()
+    c2d, ext = f(b["roi_coord_2d"]), f(b["roi_extent"])
+    xd = H.nhwc(x, dt)
+    wrows = torch.zeros(128, 256, dtype=HT, device=dev)
+    wrows[:69] = w.view(69, 256).to(dev).to(HT)
+    head = torch.full((M, hs), float("nan"), device=dev)
+    pnp = torch.zeros(M, 128, dtype=HT, device=dev)
+    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, B, HW, nreg, dt, st),
+          "head_conv_tail_fwd")
+    torch.cuda.synchronize()
+    got_h = head[:, :69].cpu().view(B, 64, 64, 69).permute(0, 3, 1, 2)
+    assert H.rel(got_h, logits) < 2e-5, H.rel(got_h, logits)
+    assert float(head[:, 69:].abs().max()) == 0.0   # (rows 69..71 of the weight fragments are zero)
+    got = pnp.float().cpu().view(B, 64, 64, 128)
+    assert H.rel(got[..., :69].permute(0, 3, 1, 2), pnp_ref) < TOL[dt]
+    assert float(got[..., 69:].abs().max()) == 0.0
+    # the two-launch path on the same operands
+    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=f(bias), out_f32=1, y_cs=hs)
+    pnp2 = torch.zeros(M, 128, dtype=HT, device=dev)
+    check(lib.gdrn_head_tail_fwd(ptr(y2), hs, ptr(c2d), ptr(ext), ptr(pnp2), 128, B, HW, nreg, dt | cabi.PREZEROED, st), "head_tail_fwd")
+    torch.cuda.synchronize()
+    assert H.rel(head[:, :69], y2.view(M, hs)[:, :69]) < 2e-6
+    assert float((pnp.float() - pnp2.float()).abs().max()) < 2e-3 and float((pnp != pnp2).float().mean()) < 2e-3   # rare one-ulp flips of the 16-bit rounding
+    # head = NULL: the logits are not written, pnp_in unchanged
+    pnp3 = torch.zeros(M, 128, dtype=HT, device=dev)
+    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), None, hs, ptr(pnp3), 128, B, HW, nreg, dt, st), "head_conv_tail_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(pnp3.view(torch.int16), pnp.view(torch.int16))
