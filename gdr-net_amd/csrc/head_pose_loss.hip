@@ -190,13 +190,19 @@ __global__ __launch_bounds__(256) void head_tail_fwd64_kernel(const float* __res
 // pixel, four classes per lane): the softmax and the stores are head_tail_fwd64_kernel's.  `head` (nullable) still receives the fp32 logits for
 // callers that return the maps (cfg.TEST.USE_PNP, gdrn_correspondences).
 constexpr int HCT_PITCH = 84;   // floats per pixel row of the wave's logit tile (80 + 4: consecutive pixels 16 bytes apart in the bank map)
-template <typename T>
+// LOSS (train mode, r5): the same pass also accumulates the map losses as head_tail_fwd64_kernel<T, true> does (GDRN.py:345-400; one partial row per
+// workgroup, added in a fixed order by gdrn_map_loss_finalize_rows); `head` is then mandatory -- the backward pass reads the logits.
+template <typename T, bool LOSS>
 __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __restrict__ x, int x_cs, const bf16_t* __restrict__ w,
                                                                const float* __restrict__ bias, const float* __restrict__ coord2d,
                                                                const float* __restrict__ extents, float* __restrict__ head, int hs,
-                                                               T* __restrict__ pnp, int pcs, int N, int HW, int ngroups) {
+                                                               T* __restrict__ pnp, int pcs, int N, int HW, int ngroups,
+                                                               const float* __restrict__ gt_xyz, const float* __restrict__ mvis,
+                                                               const float* __restrict__ mtr, const long long* __restrict__ gt_region, double* acc) {
     __shared__ __attribute__((aligned(16))) uint4 wl[5 * 8 * 64];            // [fragment][k-step][lane]: one ds_read_b128 per A operand, conflict-free
     __shared__ __attribute__((aligned(16))) float tile[4][16 * HCT_PITCH];
+    __shared__ float red[6][16];
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     for (int i = threadIdx.x; i < 5 * 8 * 64; i += 256) {   // A operand: row = output channel 16f + (l & 15), k = 32 ks + 8 (l >> 4) .. + 7
         const int l = i & 63, ks = (i >> 6) & 7, f = i >> 9;
@@ -248,6 +254,15 @@ __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __r
             const float h68 = h[68];
             const float c2x = coord2d[((size_t)n * 2 + 0) * HW + pix], c2y = coord2d[((size_t)n * 2 + 1) * HW + pix];
             const float ex[3] = {extents[n * 3 + 0], extents[n * 3 + 1], extents[n * 3 + 2]};
+            float mv = 0.f, mt = 0.f, gx[3] = {0.f, 0.f, 0.f};
+            long long gr = 0;
+            if constexpr (LOSS) {   // (every global load of the pass up front, by all 16 lanes of the pixel: see head_tail_fwd64_kernel)
+                mv = mvis[m];
+                mt = mtr[m];
+                gr = gt_region[m];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gx[c] = gt_xyz[((size_t)n * 3 + c) * HW + pix];
+            }
             if (head != nullptr) {   // the fp32 logits, 72 floats per pixel: 16 lanes x 16 bytes + two more
                 float* ho = head + m * hs;
                 store4<float>(ho + 4 * q, *reinterpret_cast<const float(*)[4]>(h + 4 * q));
@@ -273,11 +288,46 @@ __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __r
                 const float wv[4] = {(h03[1] - 0.5f) * ex[0], (h03[2] - 0.5f) * ex[1], (h03[3] - 0.5f) * ex[2], c2x};
                 store4<T>(o, wv);
             }
+            if constexpr (LOSS) {   // cross entropy over the 65 classes of logits * visib + the masked L1 sums (head_tail_fwd64_kernel<T, true>)
+                const int tgt = (int)(gr * (long long)mv);
+                float z[4], zt = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    z[j] = r[j] * mv;
+                    if (4 * q + j == tgt) zt = z[j];
+                }
+                const float z64 = (q == 15) ? r64 * mv : -INFINITY;
+                if (q == 15 && tgt == 64) zt = z64;
+                float mz = fmaxf(fmaxf(z[0], z[1]), fmaxf(fmaxf(z[2], z[3]), z64));
+                mz = row16_max(mz);
+                float es = expf(z[0] - mz) + expf(z[1] - mz) + expf(z[2] - mz) + expf(z[3] - mz) + (q == 15 ? expf(z64 - mz) : 0.f);
+                es = row16_sum(es);
+                zt = row16_sum(zt);
+                if (q == 0) {
+                    a[4] += (logf(es) + mz) - zt;
+                    a[5] += mv;
+                    a[3] += fabsf(h03[0] - mt);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) a[c] += fabsf(h03[1 + c] * mv - gx[c] * mv);
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tail's reads are done before the next group overwrites the tile
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xq[ks] = xn[ks];
+    }
+    if constexpr (LOSS) {   // this workgroup's partial row [8 + blockIdx.x * 8 .. + 5]
+        if (q == 0)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[k][threadIdx.x >> 4] = a[k];
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            double v = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v += (double)red[threadIdx.x][i];
+            acc[8 + (size_t)blockIdx.x * 8 + threadIdx.x] = v;
+        }
     }
 }
 
@@ -845,8 +895,34 @@ extern "C" int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, i
     if ((M & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const int ngroups = (int)(M / 16);
     const int blocks = (int)std::min<long long>((ngroups + 3) / 4, 1024);   // two 62 KB workgroups per CU, two rounds
-    GDRN_LAUNCH(head_conv_tail64_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
-                coord2d, extents, head, hs, reinterpret_cast<bf16_t*>(pnp_in), pcs, N, HW, ngroups);
+    GDRN_LAUNCH((head_conv_tail64_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
+                coord2d, extents, head, hs, reinterpret_cast<bf16_t*>(pnp_in), pcs, N, HW, ngroups, nullptr, nullptr, nullptr, nullptr, nullptr);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+// train mode: the same + the map-loss sums of gdrn_head_tail_loss_fwd as per-workgroup partial rows: acc = 8 + 8 * gdrn_head_conv_tail_loss_rows(N, HW)
+// doubles, finished by gdrn_map_loss_finalize_rows; head (the fp32 logits) is mandatory -- gdrn_head_tail_bwd reads it
+extern "C" int gdrn_head_conv_tail_loss_rows(int N, int HW) {
+    const long long M = (long long)N * HW;
+    if (N <= 0 || HW <= 0 || (M & 15)) return GDRN_ERR_ARG;
+    return (int)std::min<long long>((M / 16 + 3) / 4, 1024);
+}
+
+extern "C" int gdrn_head_conv_tail_loss_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d,
+                                            const float* extents, float* head, int hs, void* pnp_in, int pcs, const float* gt_xyz,
+                                            const float* mask_visib, const float* mask_trunc, const long long* gt_region, double* acc, int N, int HW,
+                                            int nreg, int dtype, void* stream) {
+    const int dt = dtype & 0xff;
+    if (!x || !w || !bias || !coord2d || !extents || !head || !pnp_in || !gt_xyz || !mask_visib || !mask_trunc || !gt_region || !acc || N <= 0 || HW <= 0)
+        return GDRN_ERR_ARG;
+    if (dt != GDRN_DT_H16 || nreg != 64 || w_rows < 69 || x_cs < 256 || (x_cs & 7) || pcs < 72 || (pcs & 3) || hs < 72 || (hs & 3)) return GDRN_ERR_SHAPE;
+    const long long M = (long long)N * HW;
+    if ((M & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    const int ngroups = (int)(M / 16);
+    const int blocks = gdrn_head_conv_tail_loss_rows(N, HW);
+    GDRN_LAUNCH((head_conv_tail64_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
+                coord2d, extents, head, hs, reinterpret_cast<bf16_t*>(pnp_in), pcs, N, HW, ngroups, gt_xyz, mask_visib, mask_trunc, gt_region, acc);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

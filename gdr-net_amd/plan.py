@@ -822,21 +822,35 @@ class Plan:
         self.hs = 72
         self.head_out = E(M, self.hs, dtype=F32t)
         bias_o = e.P[h + "23.bias"]
-        # inference (no batch statistics, no losses, 64 regions, 16-bit): the 1x1 output conv and the head tail as ONE kernel -- the fp32 logits still
-        # go to head_out (callers that return the maps read them), but nothing reads them back on the path
-        fused_tail = e.h16 and not S and not WL and nreg == 64
+        # 64 regions, 16-bit: the 1x1 output conv and the head tail as ONE kernel (gdrn_head_conv_tail_fwd; with losses gdrn_head_conv_tail_loss_fwd,
+        # which also accumulates the map-loss sums) -- the fp32 logits still go to head_out (the backward pass and callers that return the maps
+        # read them), but the forward pass does not read them back
+        fused_tail = e.h16 and nreg == 64
         if not fused_tail:
             op, _ = self._conv(LO, hx, 256, self.head_out, 64, 64, 64, 64, 1, 0, bias=bias_o, out_f32=1, y_cs=self.hs, cout=e.head_c)
             self.fwd.append(op)
         self.pnp_in = e._zeros(M, 128)   # channels >= 5 + nreg stay zero (PREZEROED: the kernels do not re-write the pad)
         self.keep.append(self.pnp_in)
         self.tensors.update({"head_out": self.head_out, "pnp_in": self.pnp_in})
-        if fused_tail:
+        if fused_tail and WL:
+            self.acc_rows = int(lib.gdrn_head_conv_tail_loss_rows(B, 4096))
+            assert self.acc_rows > 0
+            self.acc = E(8 + 8 * self.acc_rows, dtype=torch.float64)
+            self.losses = e._zeros(8, dtype=F32t)
+
+            def head_conv_tail(st, ctx, hx=hx):
+                check(lib.gdrn_head_conv_tail_loss_fwd(ptr(hx), 256, ptr(LO.wf), LO.rows_f, ptr(bias_o), ctx["coord2d"], ctx["extents"], ptr(self.head_out), self.hs,
+                                                       ptr(self.pnp_in), 128, ctx["gt_xyz"], ctx["mask_visib"], ctx["mask_trunc"], ctx["gt_region"], ptr(self.acc),
+                                                       B, 4096, nreg, e.dt | PREZEROED, st), "head_conv_tail_loss_fwd")
+
+            head_conv_tail.meta = dict(kernel="head_conv_tail64_kernel<bf16,true>", flops=2.0 * M * 256 * e.head_c, layer=h + "23+tail+losses")
+            self.fwd.append(head_conv_tail)
+        elif fused_tail:
             def head_conv_tail(st, ctx, hx=hx):
                 check(lib.gdrn_head_conv_tail_fwd(ptr(hx), 256, ptr(LO.wf), LO.rows_f, ptr(bias_o), ctx["coord2d"], ctx["extents"], ptr(self.head_out), self.hs,
                                                   ptr(self.pnp_in), 128, B, 4096, nreg, e.dt | PREZEROED, st), "head_conv_tail_fwd")
 
-            head_conv_tail.meta = dict(kernel="head_conv_tail64_kernel<bf16>", flops=2.0 * M * 256 * e.head_c, layer=h + "23+tail")
+            head_conv_tail.meta = dict(kernel="head_conv_tail64_kernel<bf16,false>", flops=2.0 * M * 256 * e.head_c, layer=h + "23+tail")
             self.fwd.append(head_conv_tail)
         elif WL:
             # map-loss sums: totals in acc[0..7], behind them one partial row per workgroup of the kernel (ACC_ROWS: stored, then added in a fixed

@@ -153,6 +153,13 @@ int gdrn_stem_conv(const void* canvas, const void* w32, void* y, float* stats, i
  * is non-NULL ([N*HW][hs >= 72]; callers that return the maps), pnp_in as gdrn_head_tail_fwd writes it (ABI 3). */
 int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d, const float* extents,
                             float* head, int hs, void* pnp_in, int pcs, int N, int HW, int nreg, int dtype, void* stream);
+/* ... and with do_loss=True (GDRN.py:345-400) the same pass also accumulates the map-loss sums as gdrn_head_tail_loss_fwd does, one partial row per
+ * workgroup: acc = 8 + 8 * gdrn_head_conv_tail_loss_rows(N, HW) doubles, finished by gdrn_map_loss_finalize_rows; head is mandatory (the backward
+ * pass reads the logits). */
+int gdrn_head_conv_tail_loss_rows(int N, int HW);
+int gdrn_head_conv_tail_loss_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d, const float* extents,
+                                 float* head, int hs, void* pnp_in, int pcs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                                 const long long* gt_region, double* acc, int N, int HW, int nreg, int dtype, void* stream);
 int gdrn_stem_conv_pool(const void* canvas, const void* w32, const float* scale, const float* shift, void* y, int N, int dtype, void* stream);
 /* Stem weight gradient (backward-weight of nn.Conv2d(3, 64, 7, 2, 3), resnet_backbone.py:23, implicit in engine.py:279) fused with
  * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel

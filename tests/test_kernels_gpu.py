@@ -1171,3 +1171,51 @@ def test_head_conv_tail_eval_equals_the_two_launch_path(H):
     check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), None, hs, ptr(pnp3), 128, B, HW, nreg, dt, st), "head_conv_tail_fwd")
     torch.cuda.synchronize()
     assert torch.equal(pnp3.view(torch.int16), pnp.view(torch.int16))
+
+
+def test_head_conv_tail_loss_fwd_equals_the_two_launch_path(H):
+    """gdrn_head_conv_tail_loss_fwd (do_loss=True: 1x1 output conv + head tail + the map-loss sums in one kernel, r5) against gdrn_conv_gemm ->
+    gdrn_head_tail_loss_fwd on the same operands: logits, pnp_in and the five map losses (GDRN.py:345-400)."""
+    from gdrnet_amd import synth
+
+    lib, dev, dt, st = cabi.load(BF16), H.DEV, BF16, H.stream()
+    B, HW, nreg, hs = 2, 4096, 64, 72
+    M = B * HW
+    b = synth.make_batch(B, seed=9)
+    b["roi_mask_visib"][1, :8] = 0
+    x = H.rounded(torch.relu(H.randn(130, B, 256, 64, 64)), dt)
+    w = H.rounded(H.randn(131, 69, 256, 1, 1) / 16.0, dt)
+    bias = H.randn(132, 69) * 0.2
+    f = lambda t: t.to(dev).float().contiguous()
+    c2d, ext, gxyz, mv, mt = f(b["roi_coord_2d"]), f(b["roi_extent"]), f(b["roi_xyz"]), f(b["roi_mask_visib"]), f(b["roi_mask_trunc"])
+    greg = b["roi_region"].to(dev).contiguous()
+    xd = H.nhwc(x, dt)
+    wrows = torch.zeros(128, 256, dtype=HT, device=dev)
+    wrows[:69] = w.view(69, 256).to(dev).to(HT)
+    # two launches
+    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=f(bias), out_f32=1, y_cs=hs)
+    rows2 = int(lib.gdrn_head_tail_loss_rows(B, HW, nreg, hs, 128))
+    acc2 = torch.zeros(8 + 8 * rows2, dtype=torch.float64, device=dev)
+    pnp2 = torch.zeros(M, 128, dtype=HT, device=dev)
+    l2 = torch.zeros(8, device=dev)
+    check(lib.gdrn_head_tail_loss_fwd(ptr(y2), hs, ptr(c2d), ptr(ext), ptr(pnp2), 128, ptr(gxyz), ptr(mv), ptr(mt), ptr(greg), ptr(acc2), B, HW, nreg,
+                                      dt | cabi.PREZEROED | cabi.ACC_ROWS, st), "head_tail_loss_fwd")
+    check(lib.gdrn_map_loss_finalize_rows(ptr(acc2), rows2, B, HW, ptr(l2), st), "finalize_rows")
+    # one launch
+    rows = int(lib.gdrn_head_conv_tail_loss_rows(B, HW))
+    assert rows == min(M // 64, 1024)
+    acc = torch.full((8 + 8 * rows,), float("nan"), dtype=torch.float64, device=dev)
+    head = torch.full((M, hs), float("nan"), device=dev)
+    pnp = torch.zeros(M, 128, dtype=HT, device=dev)
+    l1 = torch.zeros(8, device=dev)
+    check(lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
+                                           ptr(greg), ptr(acc), B, HW, nreg, dt | cabi.PREZEROED, st), "head_conv_tail_loss_fwd")
+    check(lib.gdrn_map_loss_finalize_rows(ptr(acc), rows, B, HW, ptr(l1), st), "finalize_rows")
+    torch.cuda.synchronize()
+    assert H.rel(head[:, :69], y2.view(M, hs)[:, :69]) < 2e-6
+    assert float((pnp.float() - pnp2.float()).abs().max()) < 2e-3 and float((pnp != pnp2).float().mean()) < 2e-3
+    assert torch.isfinite(l1).all()
+    np.testing.assert_allclose(l1[:5].cpu().numpy(), l2[:5].cpu().numpy(), rtol=2e-6)
+    # without a logits buffer the loss variant refuses (the backward pass reads it)
+    assert lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), None, hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
+                                            ptr(greg), ptr(acc), B, HW, nreg, dt | cabi.PREZEROED, st) == -1
