@@ -110,6 +110,8 @@ _SIGS = {
     "gdrn_stem_conv_pool": [P, P, P, P, P, I, I, P],
     "gdrn_head_conv_tail_fwd": [P, I, P, I, P, P, P, P, I, P, I, I, I, I, I, P],
     "gdrn_head_conv_tail_loss_rows": [I, I],
+    "gdrn_head_out_dgrad_rows": [I, I],
+    "gdrn_head_out_dgrad": [P, I, P, I, P, I, P, P, P, P, P, I, P, I, I, I, P],
     "gdrn_head_conv_tail_loss_fwd": [P, I, P, I, P, P, P, P, I, P, I, P, P, P, P, P, I, I, I, I, P],
     "gdrn_stem_wgrad_parts": [I],
     "gdrn_stem_wgrad": [P, P, P, P, P, P, I, P, P, I, P],

@@ -331,6 +331,125 @@ __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------ 1x1 output conv: data gradient + BatchNorm-backward sums
+// The data gradient of the head's nn.Conv2d(256, 69, 1) -- d_act[px][256] = d_logits[px][69] . W -- with the ReLU mask and the two BatchNorm-backward
+// sums of the BatchNorm(+ReLU) in front of the conv in its epilogue (what gdrn_conv_gemm's bnb_* epilogue does for this launch; autograd,
+// core/gdrn_modeling/engine.py:279).  On the generic 128 x 128 tile this is the step's least efficient launch (K = 69 of a 128-deep reduction, 83 TFLOP/s,
+// 111 us for 335 MB).  Here (r5): W^T in LDS in fragment order (16 fragments of 16 channels x 3 k-steps of 32 = 48 KB); a wave takes 16 pixels at a
+// time -- B fragments (pixel r16, 8 logit gradients per k-group) straight from global memory, 48 MFMAs -- and turns the 16 x 256 fp32 result through a
+// wave-private LDS tile, 64 channels at a time, into the layout in which the tensors stream: a lane owns 8 consecutive channels of one pixel = one
+// 16-byte load of the BatchNorm's raw input and one 16-byte store, eight lanes a pixel's 128-byte line.  A lane meets the same 32 channels for every
+// pixel it handles, so the BatchNorm-backward sums are 64 lane-local accumulators, reduced once at the end: one partial row [2][256] per workgroup.
+constexpr int HOD_PITCH = 68;   // floats per pixel of the wave's 64-channel result tile
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head_out_dgrad64_kernel(const bf16_t* __restrict__ dy, int dy_cs, const bf16_t* __restrict__ wd, int wd_cs,
+                                                               const bf16_t* __restrict__ raw, int raw_cs, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, bf16_t* __restrict__ dx, int dx_cs,
+                                                               float* __restrict__ rows, int ngroups) {
+    __shared__ __attribute__((aligned(16))) uint4 wl[16 * 3 * 64];          // [fragment][k-step][lane]
+    __shared__ __attribute__((aligned(16))) float tab[4][256];              // mean, 1/std, forward scale, forward shift per channel
+    __shared__ __attribute__((aligned(16))) float tile[4][16 * HOD_PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+    for (int i = threadIdx.x; i < 16 * 3 * 64; i += 256) {   // A operand: row = input channel 16f + (l & 15), k = logit 32 ks + 8 (l >> 4) .. + 7
+        const int l = i & 63, ks = (i >> 6) % 3, f = i / 192;
+        wl[i] = *reinterpret_cast<const uint4*>(wd + (size_t)(16 * f + (l & 15)) * wd_cs + 32 * ks + 8 * (l >> 4));
+    }
+    for (int c = threadIdx.x; c < 256; c += 256) { tab[0][c] = mean[c]; tab[1][c] = invstd[c]; tab[2][c] = scale[c]; tab[3][c] = shift[c]; }
+    __syncthreads();
+    float* tw = tile[wave];
+    const int oct = lane & 7, psub = lane >> 3;   // streaming layout: channel octet of the 64-channel quarter, pixel 0..7 (+ 8 in the second half)
+    float t1[4][8], t2[4][8];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1[qd][j] = 0.f; t2[qd][j] = 0.f; }
+    const int nw = gridDim.x * 4;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += nw) {
+        const long long m0 = (long long)grp * 16;
+        uint4 yq[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) yq[ks] = *reinterpret_cast<const uint4*>(dy + (size_t)(m0 + r16) * dy_cs + 32 * ks + 8 * g);
+        uint4 rq[4][2];   // the raw BatchNorm input of the lane's (pixel, octet) pairs: all eight loads of the group go out before the MFMAs
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                rq[qd][hf] = *reinterpret_cast<const uint4*>(raw + (size_t)(m0 + psub + 8 * hf) * raw_cs + 64 * qd + 8 * oct);
+        f32x4_t acc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+                acc[f] = GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, wl[(f * 3 + ks) * 64 + lane]), __builtin_bit_cast(bf16x8_t, yq[ks]), acc[f]);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {   // channels 64 qd .. 64 qd + 63
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+                const f32x4_t v = acc[4 * qd + f4];
+                *reinterpret_cast<float4*>(tw + r16 * HOD_PITCH + 16 * f4 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int c0 = 64 * qd + 8 * oct;
+            float km[8], ki[8], kc[8], kh[8];
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const float4 a0 = *reinterpret_cast<const float4*>(&tab[0][c0 + 4 * j4]), a1 = *reinterpret_cast<const float4*>(&tab[1][c0 + 4 * j4]);
+                const float4 a2 = *reinterpret_cast<const float4*>(&tab[2][c0 + 4 * j4]), a3 = *reinterpret_cast<const float4*>(&tab[3][c0 + 4 * j4]);
+                km[4 * j4] = a0.x; km[4 * j4 + 1] = a0.y; km[4 * j4 + 2] = a0.z; km[4 * j4 + 3] = a0.w;
+                ki[4 * j4] = a1.x; ki[4 * j4 + 1] = a1.y; ki[4 * j4 + 2] = a1.z; ki[4 * j4 + 3] = a1.w;
+                kc[4 * j4] = a2.x; kc[4 * j4 + 1] = a2.y; kc[4 * j4 + 2] = a2.z; kc[4 * j4 + 3] = a2.w;
+                kh[4 * j4] = a3.x; kh[4 * j4 + 1] = a3.y; kh[4 * j4 + 2] = a3.z; kh[4 * j4 + 3] = a3.w;
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pl = psub + 8 * hf;
+                float gq[8];
+                {
+                    const float4 u0 = *reinterpret_cast<const float4*>(tw + pl * HOD_PITCH + 8 * oct), u1 = *reinterpret_cast<const float4*>(tw + pl * HOD_PITCH + 8 * oct + 4);
+                    gq[0] = u0.x; gq[1] = u0.y; gq[2] = u0.z; gq[3] = u0.w; gq[4] = u1.x; gq[5] = u1.y; gq[6] = u1.z; gq[7] = u1.w;
+                }
+                float xv[8];
+                Vec16<bf16_t>::unpack(rq[qd][hf], xv);
+                float ov[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool keep = xv[j] * kc[j] + kh[j] > 0.f;
+                    const float gv = keep ? gq[j] : 0.f;
+                    ov[j] = gv;
+                    t1[qd][j] += gv;
+                    t2[qd][j] += gv * (xv[j] - km[j]) * ki[j];
+                }
+                *reinterpret_cast<uint4*>(dx + (size_t)(m0 + pl) * dx_cs + c0) = Vec16<bf16_t>::pack(ov);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's reads are done before the next quarter overwrites it
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // the lane's 32 channels (quarter qd, octet oct, j) summed over the eight lanes that share the octet (psub = lane >> 3), then over the four waves
+    // in a fixed order: one partial row [2][256] per workgroup
+    __syncthreads();   // (every wave is done with its tile; the tiles are reused as the reduction buffer: [wave][2][256] floats = 8 KB <= 4 x 4352 B)
+    float* red = &tile[0][0];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float u1 = t1[qd][j], u2 = t2[qd][j];
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
+            if (psub == 0) {
+                red[(wave * 2 + 0) * 256 + 64 * qd + 8 * oct + j] = u1;
+                red[(wave * 2 + 1) * 256 + 64 * qd + 8 * oct + j] = u2;
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+        rows[(size_t)blockIdx.x * 512 + i] = (red[i] + red[512 + i]) + (red[1024 + i] + red[1536 + i]);
+}
+
 // ------------------------------------------------------------------------------------------ map losses fwd
 __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restrict__ head, int hs,
                                                            const float* __restrict__ gt_xyz,
@@ -897,6 +1016,32 @@ extern "C" int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, i
     const int blocks = (int)std::min<long long>((ngroups + 3) / 4, 1024);   // two 62 KB workgroups per CU, two rounds
     GDRN_LAUNCH((head_conv_tail64_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
                 coord2d, extents, head, hs, reinterpret_cast<bf16_t*>(pnp_in), pcs, N, HW, ngroups, nullptr, nullptr, nullptr, nullptr, nullptr);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+// data gradient of the 1x1 output conv with the BatchNorm(+ReLU)-backward mask and sums of the layer in front of it: dy = d_logits [N*HW][dy_cs >= 96]
+// (16-bit; channels >= 69 zero), wd = the data-gradient operand rows [256][wd_cs >= 96] (row ci = W[:, ci], columns >= 69 zero), raw = that BatchNorm's raw
+// input [N*HW][raw_cs], mean / invstd / scale / shift its statistics and forward affine (mask = scale * raw + shift > 0), dx = the masked gradient
+// [N*HW][dx_cs], rows = [gdrn_head_out_dgrad_rows(N, HW)][2][256] partial sums for gdrn_bn_bwd_coef
+extern "C" int gdrn_head_out_dgrad_rows(int N, int HW) {
+    const long long M = (long long)N * HW;
+    if (N <= 0 || HW <= 0 || (M & 15)) return GDRN_ERR_ARG;
+    return (int)std::min<long long>((M / 16 + 3) / 4, 512);
+}
+
+extern "C" int gdrn_head_out_dgrad(const void* dy, int dy_cs, const void* wd, int wd_cs, const void* raw, int raw_cs, const float* mean,
+                                   const float* invstd, const float* scale, const float* shift, void* dx, int dx_cs, float* rows, int N, int HW,
+                                   int dtype, void* stream) {
+    const int dt = dtype & 0xff;
+    if (!dy || !wd || !raw || !mean || !invstd || !scale || !shift || !dx || !rows || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
+    if (dt != GDRN_DT_H16 || dy_cs < 96 || wd_cs < 96 || raw_cs < 256 || dx_cs < 256 || ((dy_cs | wd_cs | raw_cs | dx_cs) & 7)) return GDRN_ERR_SHAPE;
+    const long long M = (long long)N * HW;
+    if ((M & 15) || M * std::max(std::max(dy_cs, raw_cs), dx_cs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    const int ngroups = (int)(M / 16);
+    GDRN_LAUNCH(head_out_dgrad64_kernel<bf16_t>, dim3(gdrn_head_out_dgrad_rows(N, HW)), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(dy), dy_cs,
+                reinterpret_cast<const bf16_t*>(wd), wd_cs, reinterpret_cast<const bf16_t*>(raw), raw_cs, mean, invstd, scale, shift,
+                reinterpret_cast<bf16_t*>(dx), dx_cs, rows, ngroups);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

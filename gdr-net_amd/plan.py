@@ -884,8 +884,28 @@ class Plan:
             self.grad_group[h + "23.bias"] = len(self.bwd_groups)
             self._zero_regions.append(self._grad16(gb))
             grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(self.d_head), 128, M, e.head_c, ptr(gb), e.dt | PREZEROED, st), "bias_grad")))
-            op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256,
-                               bnb=(prev_bn, prev_raw, None, True) if e.gemm_bnb else None)
+            if e.h16 and e.gemm_bnb:
+                # the 1x1 output conv's data gradient on its own kernel (K = 69: the generic 128 x 128 tile ran it at 83 TFLOP/s), with the ReLU mask and
+                # the BatchNorm-backward sums of the head's last BatchNorm in the epilogue as the generic kernel's bnb_* epilogue has them
+                sbp = self.bn[prev_bn]
+                nrows_h = int(lib.gdrn_head_out_dgrad_rows(B, 4096))
+                assert 0 < nrows_h and nrows_h * 2 * 256 <= self.stats.numel()
+
+                def head_dgrad(st, ctx, d_hx=d_hx, prev_raw=prev_raw, sbp=sbp):
+                    check(lib.gdrn_head_out_dgrad(ptr(self.d_head), 128, ptr(LO.wd), LO.cin_d, ptr(prev_raw), 256, ptr(sbp.mean), ptr(sbp.invstd), ptr(sbp.scale),
+                                                  ptr(sbp.shift), ptr(d_hx), 256, ptr(self.stats), B, 4096, e.dt, st), "head_out_dgrad")
+
+                coef_h = self._bn_coef_op(prev_bn, self.stats, nrows_h)
+
+                def op(st, ctx):
+                    head_dgrad(st, ctx)
+                    coef_h(st, ctx)
+
+                op.parts = (head_dgrad, coef_h)
+                op.meta = dict(kernel="head_out_dgrad64_kernel<bf16>", flops=2.0 * M * 256 * e.head_c, bytes=float(M * (128 + 256 + 256) * 2), layer=h + "23:dgrad")
+            else:
+                op, _ = self._conv(LO, self.d_head, 128, d_hx, 64, 64, 64, 64, 1, 0, w=LO.wd, rows=LO.rows_d, cin=128, cout=256,
+                                   bnb=(prev_bn, prev_raw, None, True) if e.gemm_bnb else None)
             grp.append(op)
             self.bwd_groups.append(grp)
 

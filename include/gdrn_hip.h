@@ -160,6 +160,13 @@ int gdrn_head_conv_tail_loss_rows(int N, int HW);
 int gdrn_head_conv_tail_loss_fwd(const void* x, int x_cs, const void* w, int w_rows, const float* bias, const float* coord2d, const float* extents,
                                  float* head, int hs, void* pnp_in, int pcs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
                                  const long long* gt_region, double* acc, int N, int HW, int nreg, int dtype, void* stream);
+/* Data gradient of that 1x1 output conv (autograd, core/gdrn_modeling/engine.py:279) with the ReLU mask and the two BatchNorm-backward sums of the
+ * BatchNorm(+ReLU) in front of it in the epilogue (cdpn_rot_head_region.py:120-135): dy = d_logits [N*HW][dy_cs >= 96] (channels >= 69 zero), wd = operand
+ * rows [256][wd_cs >= 96] (row ci = W[:, ci]), raw / mean / invstd / scale / shift = that BatchNorm's raw input, batch statistics and forward affine
+ * (mask: scale * raw + shift > 0), dx [N*HW][dx_cs] = the masked gradient, rows = [gdrn_head_out_dgrad_rows(N, HW)][2][256] for gdrn_bn_bwd_coef (ABI 3). */
+int gdrn_head_out_dgrad_rows(int N, int HW);
+int gdrn_head_out_dgrad(const void* dy, int dy_cs, const void* wd, int wd_cs, const void* raw, int raw_cs, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, void* dx, int dx_cs, float* rows, int N, int HW, int dtype, void* stream);
 int gdrn_stem_conv_pool(const void* canvas, const void* w32, const float* scale, const float* shift, void* y, int N, int dtype, void* stream);
 /* Stem weight gradient (backward-weight of nn.Conv2d(3, 64, 7, 2, 3), resnet_backbone.py:23, implicit in engine.py:279) fused with
  * the BatchNorm-backward apply in front of it: the stem has no data gradient, so dy = a*g + (b*raw + c) per channel

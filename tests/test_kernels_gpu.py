@@ -1148,9 +1148,10 @@ def test_head_conv_tail_eval_equals_the_two_launch_path(H):
     xd = H.nhwc(x, dt)
     wrows = torch.zeros(128, 256, dtype=HT, device=dev)
     wrows[:69] = w.view(69, 256).to(dev).to(HT)
+    bias_d = f(bias)
     head = torch.full((M, hs), float("nan"), device=dev)
     pnp = torch.zeros(M, 128, dtype=HT, device=dev)
-    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, B, HW, nreg, dt, st),
+    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(bias_d), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, B, HW, nreg, dt, st),
           "head_conv_tail_fwd")
     torch.cuda.synchronize()
     got_h = head[:, :69].cpu().view(B, 64, 64, 69).permute(0, 3, 1, 2)
@@ -1160,7 +1161,7 @@ def test_head_conv_tail_eval_equals_the_two_launch_path(H):
     assert H.rel(got[..., :69].permute(0, 3, 1, 2), pnp_ref) < TOL[dt]
     assert float(got[..., 69:].abs().max()) == 0.0
     # the two-launch path on the same operands
-    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=f(bias), out_f32=1, y_cs=hs)
+    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=bias_d, out_f32=1, y_cs=hs)
     pnp2 = torch.zeros(M, 128, dtype=HT, device=dev)
     check(lib.gdrn_head_tail_fwd(ptr(y2), hs, ptr(c2d), ptr(ext), ptr(pnp2), 128, B, HW, nreg, dt | cabi.PREZEROED, st), "head_tail_fwd")
     torch.cuda.synchronize()
@@ -1168,7 +1169,7 @@ def test_head_conv_tail_eval_equals_the_two_launch_path(H):
     assert float((pnp.float() - pnp2.float()).abs().max()) < 2e-3 and float((pnp != pnp2).float().mean()) < 2e-3   # rare one-ulp flips of the 16-bit rounding
     # head = NULL: the logits are not written, pnp_in unchanged
     pnp3 = torch.zeros(M, 128, dtype=HT, device=dev)
-    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), None, hs, ptr(pnp3), 128, B, HW, nreg, dt, st), "head_conv_tail_fwd")
+    check(lib.gdrn_head_conv_tail_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(bias_d), ptr(c2d), ptr(ext), None, hs, ptr(pnp3), 128, B, HW, nreg, dt, st), "head_conv_tail_fwd")
     torch.cuda.synchronize()
     assert torch.equal(pnp3.view(torch.int16), pnp.view(torch.int16))
 
@@ -1192,8 +1193,9 @@ def test_head_conv_tail_loss_fwd_equals_the_two_launch_path(H):
     xd = H.nhwc(x, dt)
     wrows = torch.zeros(128, 256, dtype=HT, device=dev)
     wrows[:69] = w.view(69, 256).to(dev).to(HT)
+    bias_d = f(bias)
     # two launches
-    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=f(bias), out_f32=1, y_cs=hs)
+    y2, _ = H.conv_gemm(xd, wrows.view(128, 1, 256), B, 64, 64, 256, 256, 64, 64, 69, 1, 1, 1, 0, dt, bias=bias_d, out_f32=1, y_cs=hs)
     rows2 = int(lib.gdrn_head_tail_loss_rows(B, HW, nreg, hs, 128))
     acc2 = torch.zeros(8 + 8 * rows2, dtype=torch.float64, device=dev)
     pnp2 = torch.zeros(M, 128, dtype=HT, device=dev)
@@ -1208,7 +1210,7 @@ def test_head_conv_tail_loss_fwd_equals_the_two_launch_path(H):
     head = torch.full((M, hs), float("nan"), device=dev)
     pnp = torch.zeros(M, 128, dtype=HT, device=dev)
     l1 = torch.zeros(8, device=dev)
-    check(lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
+    check(lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(bias_d), ptr(c2d), ptr(ext), ptr(head), hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
                                            ptr(greg), ptr(acc), B, HW, nreg, dt | cabi.PREZEROED, st), "head_conv_tail_loss_fwd")
     check(lib.gdrn_map_loss_finalize_rows(ptr(acc), rows, B, HW, ptr(l1), st), "finalize_rows")
     torch.cuda.synchronize()
@@ -1217,5 +1219,47 @@ def test_head_conv_tail_loss_fwd_equals_the_two_launch_path(H):
     assert torch.isfinite(l1).all()
     np.testing.assert_allclose(l1[:5].cpu().numpy(), l2[:5].cpu().numpy(), rtol=2e-6)
     # without a logits buffer the loss variant refuses (the backward pass reads it)
-    assert lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(f(bias)), ptr(c2d), ptr(ext), None, hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
+    assert lib.gdrn_head_conv_tail_loss_fwd(ptr(xd), 256, ptr(wrows), 128, ptr(bias_d), ptr(c2d), ptr(ext), None, hs, ptr(pnp), 128, ptr(gxyz), ptr(mv), ptr(mt),
                                             ptr(greg), ptr(acc), B, HW, nreg, dt | cabi.PREZEROED, st) == -1
+
+
+def test_head_out_dgrad_with_bn_backward_sums(H):
+    """gdrn_head_out_dgrad (r5): the data gradient of the head's 1x1 output conv with the ReLU mask (affine: scale * raw + shift > 0) and the two
+    BatchNorm-backward sums of the BatchNorm in front of it, against torch and against gdrn_conv_gemm's bnb_* epilogue on the same operands."""
+    lib, dev, dt, st = cabi.load(BF16), H.DEV, BF16, H.stream()
+    B, HW = 2, 4096
+    M = B * HW
+    dy = H.rounded(H.randn(140, B, 69, 64, 64) * 0.02, dt)
+    w = H.rounded(H.randn(141, 69, 256, 1, 1) / 16.0, dt)
+    raw = H.rounded(H.randn(142, B, 256, 64, 64) * 1.5 + 0.3, dt)
+    mean, invstd = H.randn(143, 256) * 0.2, torch.rand(256, generator=torch.Generator().manual_seed(144)) + 0.5
+    scale, shift = torch.rand(256, generator=torch.Generator().manual_seed(145)) + 0.5, H.randn(146, 256) * 0.3
+    V = lambda t: t.view(1, -1, 1, 1)
+    g = F.conv_transpose2d(dy, w)                      # [B, 256, 64, 64]
+    m = (raw * V(scale) + V(shift)) > 0
+    gm = g * m
+    xhat = (raw - V(mean)) * V(invstd)
+    ref1, ref2 = gm.sum((0, 2, 3)), (gm * xhat).sum((0, 2, 3))
+    d = lambda t: t.to(dev).float().contiguous()
+    dyd = torch.zeros(M, 128, dtype=HT, device=dev)
+    dyd[:, :69] = dy.permute(0, 2, 3, 1).reshape(M, 69).to(dev).to(HT)
+    wd = torch.zeros(256, 128, dtype=HT, device=dev)
+    wd[:, :69] = w.view(69, 256).t().to(dev).to(HT)
+    rawd = H.nhwc(raw, dt)
+    nrows = int(lib.gdrn_head_out_dgrad_rows(B, HW))
+    assert nrows == 128
+    rows = torch.full((nrows, 2, 256), float("nan"), device=dev)
+    dx = torch.full((M, 256), float("nan"), dtype=HT, device=dev)
+    mean_d, invstd_d, scale_d, shift_d = d(mean), d(invstd), d(scale), d(shift)   # (named: a temporary's memory may be handed out again before the launch reads it)
+    check(lib.gdrn_head_out_dgrad(ptr(dyd), 128, ptr(wd), 128, ptr(rawd), 256, ptr(mean_d), ptr(invstd_d), ptr(scale_d), ptr(shift_d), ptr(dx), 256, ptr(rows),
+                                  B, HW, dt, st), "head_out_dgrad")
+    torch.cuda.synchronize()
+    got = dx.float().cpu().view(B, 64, 64, 256).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all() and H.rel(got, gm) < TOL[dt]
+    sums = rows.sum(0).cpu()
+    assert H.rel(sums[0], ref1) < 2e-3 and H.rel(sums[1], ref2) < 2e-3
+    # the generic kernel's epilogue on the same operands: the same masked gradient up to the 16-bit rounding, the same sums
+    y2, s2 = H.conv_gemm(dyd.view(B, 64, 64, 128), wd.view(256, 1, 128), B, 64, 64, 128, 128, 64, 64, 256, 1, 1, 1, 0, dt,
+                         bnb=dict(x=rawd, mean=mean_d, invstd=invstd_d, scale=scale_d, shift=shift_d))
+    assert float((dx.float() - y2.view(M, 256).float()).abs().max()) < 1e-3 * float(gm.abs().max()) + 1e-6
+    assert H.rel(rows.sum(0), s2.sum(0)) < 1e-4
