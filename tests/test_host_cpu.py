@@ -355,3 +355,26 @@ def test_build_is_stamped_with_the_source_hash(tmp_path, monkeypatch):
     assert B.needs_build()                          # a stamp of other sources, however new the file is
     stamp.write_text(B.source_hash() + "\n")
     assert not B.needs_build()
+
+
+def test_plans_route_the_stem_and_the_head_output_conv_to_their_own_kernels():
+    """r5 wiring on dry plans (launch lists only): inference runs the stem as one kernel and the 1x1 output conv + head tail as one kernel and the
+    small-map convs in the eight-wave form; the training step runs the output conv + tail + map losses as one kernel, its data gradient on
+    head_out_dgrad64_kernel, and keeps four waves for the data gradients of a two-stream backward pass; the parity (fp32) mode and a region count
+    other than 64 keep the generic launches."""
+    kernels = lambda ops: [getattr(op, "meta", {}).get("kernel") for op in ops if getattr(op, "meta", None)]
+    e = _dry_engine("bf16")
+    inf = kernels(e.plan(64, False, False).fwd)
+    assert "stem_conv_pool_kernel" in inf and "stem_conv_kernel" not in inf
+    assert "head_conv_tail64_kernel<bf16,false>" in inf
+    assert sum(k.startswith("conv_gemm_kernel<bf16,128,128>") for k in inf) == 3   # (was 4: the 1x1 output conv left the generic kernel)
+    assert sum(k.endswith(",2,1>") or k.endswith(",2>") for k in inf if k.startswith("conv3x3_halo_kernel")) == 18   # layer3 + layer4 + the 16x16 head conv: eight waves
+    tr = e.plan(64, True, True)
+    fwd, bwd = kernels(tr.fwd), kernels(tr.bwd)
+    assert "stem_conv_kernel" in fwd and "stem_conv_pool_kernel" not in fwd            # train mode: bn1 needs the batch statistics first
+    assert "head_conv_tail64_kernel<bf16,true>" in fwd and "head_out_dgrad64_kernel<bf16>" in bwd
+    assert not any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in bwd)   # four-wave data gradients (side stream on)
+    assert any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in fwd)
+    e32 = _dry_engine("fp32")
+    k32 = kernels(e32.plan(64, True, True).fwd + e32.plan(64, True, True).bwd)
+    assert not any(k.startswith(("head_conv_tail", "head_out_dgrad", "stem_conv")) for k in k32)
