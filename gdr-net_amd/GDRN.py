@@ -444,6 +444,8 @@ class GDRN(nn.Module):
         dev, B = eng.dev, x.shape[0]
 
         if not do_loss:  # test
+            # (the fused output-conv + tail kernel writes the fp32 logits only for callers that return the maps -- GDRN.py:183-190 / `_maps` below)
+            kctx["want_maps"] = bool(cfg.TEST.USE_PNP)
             with torch.no_grad():
                 plan.run_forward(kctx)
             out_dict = {"rot": plan.rot[:B].clone(), "trans": plan.trans[:B].clone()}   # (plan.B >= B: padded inference batch)

@@ -847,7 +847,9 @@ class Plan:
             self.fwd.append(head_conv_tail)
         elif fused_tail:
             def head_conv_tail(st, ctx, hx=hx):
-                check(lib.gdrn_head_conv_tail_fwd(ptr(hx), 256, ptr(LO.wf), LO.rows_f, ptr(bias_o), ctx["coord2d"], ctx["extents"], ptr(self.head_out), self.hs,
+                # ctx["want_maps"] False (GDRN.forward without cfg.TEST.USE_PNP): nobody reads the logits -- head = NULL saves their 75 MB at bs = 64
+                check(lib.gdrn_head_conv_tail_fwd(ptr(hx), 256, ptr(LO.wf), LO.rows_f, ptr(bias_o), ctx["coord2d"], ctx["extents"],
+                                                  ptr(self.head_out) if ctx.get("want_maps", True) else None, self.hs,
                                                   ptr(self.pnp_in), 128, B, 4096, nreg, e.dt | PREZEROED, st), "head_conv_tail_fwd")
 
             head_conv_tail.meta = dict(kernel="head_conv_tail64_kernel<bf16,false>", flops=2.0 * M * 256 * e.head_c, layer=h + "23+tail")
