@@ -414,6 +414,46 @@ def measure_roofline(model, plan, kctx, dtype):
                             "achieved": round(best[2]["flops"] / ((best[0].elapsed_time(best[1]) - ovh_ms) * 1e-3) / 1e12, 1)}}
 
 
+def fp32_seed_probe(m32, dev):
+    """the fp32 (parity) engine on the THREE seeded bs = 64 batches of golden G11 (tests/golden/g11_baseline_sizes.npz: the
+    reference's own GDRN.forward(do_loss=True) at this size, in fp32 and evaluated in fp64) -- worst-of-seeds pose error against the reference's fp32
+    outputs, beside the reference's own fp32-vs-fp64 distance on each batch (the floor two correct fp32 implementations cannot be told apart below:
+    1.02e-4 in R on seed 2) and the engine's distance from that fp64 value.  Fixture data only; the oracle is not involved."""
+    import numpy as np
+    import torch
+
+    from gdrnet_amd import synth
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g11_baseline_sizes.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    per, worst, floor, vs64 = {}, 0.0, {}, {}
+    for seed in (1, 2, 3):
+        tag = f"lm13_b64_s{seed}"
+        m32.load_state_dict(synth.make_state_dict(0))
+        m32.train()
+        b = synth.make_batch(64, seed=seed)
+        b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+        with torch.no_grad():
+            m32(b["roi_img"], **synth.model_kwargs(b, do_loss=True))
+        pl = m32.engine().plan(64, True, True)
+        fc = pl.fc_out.float().cpu()
+        got = {"rot6d": fc[:, :6], "t_": fc[:, 6:9], "rot": pl.rot.float().cpu(), "trans": pl.trans.float().cpu()}
+        e = {k: rel(got[k], torch.from_numpy(g[f"{tag}/{k}"])) for k in got}
+        per[str(seed)] = {k: float("%.3e" % v) for k, v in e.items()}
+        worst = max(worst, max(e.values()))
+        floor[str(seed)] = float("%.3e" % rel(torch.from_numpy(g[f"{tag}/rot"]), torch.from_numpy(g[f"{tag}/f64/rot"])))
+        vs64[str(seed)] = float("%.3e" % rel(got["rot"], torch.from_numpy(g[f"{tag}/f64/rot"])))
+    m32.load_state_dict(synth.make_state_dict(0))
+    return {"pose_rel_err_worst_of_seeds_1_2_3_vs_reference_g11": float("%.3e" % worst), "pose_rel_err_per_seed_vs_reference_g11": per,
+            "R_reference_fp32_vs_its_own_fp64_per_seed": floor, "R_engine_vs_reference_fp64_per_seed": vs64,
+            "worst_of_seeds_within_1e-4": worst < 1e-4,
+            "rule": "rot6d / t_ / trans within 1e-4 of the reference on every seed; R within 1e-4 of it, or no farther from the reference's fp64 value than "
+                    "1.5 x the reference's own fp32 path on that batch (tests/test_e2e_gpu.py::test_fp32_vs_the_reference_itself_at_baseline_sizes_g11)"}
+
+
 def roi_cropper_extras(B, dev, timed):
     """the GPU RoI cropper / target builder that feeds the path -- train-mode batch of B RoIs cut from synthetic
     640x480 / 720x540 frames resident in HBM (launches only; the per-RoI task table is prepared once, as a loader thread would)."""
@@ -594,9 +634,12 @@ def main():
             cfg32.MODEL.CDPN.HIP_DTYPE = "fp32"
             m32, o32 = GDRN.build_model_optimizer(cfg32)
             m32.load_state_dict(synth.make_state_dict(0))
+            seeds32 = None
             if want_parity:
                 probes["fp32"] = pose_probe(m32)
                 m32.load_state_dict(synth.make_state_dict(0))
+                if B == 64:
+                    seeds32 = fp32_seed_probe(m32, dev)
             m32.train()
             t32 = timed(lambda: m32.train_step(batch["roi_img"], optimizer=o32, **kw), 5)
             also["fp32_parity_mode"] = {"roi_s": round(B / t32, 1), "ms_per_step": round(t32 * 1e3, 3),
@@ -609,6 +652,8 @@ def main():
                     "roi_coord_2d", "roi_cams", "roi_centers", "roi_whs", "roi_extents", "resize_ratios")})
                 r32 = measure_roofline(m32, plan32, kctx32, "fp32")
                 also["fp32_parity_mode"]["roofline"] = {k: r32[k] for k in ("kernel", "launches_per_step", "avg_launch_us", "achieved", "peak", "frac")}
+            if seeds32 is not None:
+                also["fp32_parity_mode"].update(seeds32)
             del m32, o32
             torch.cuda.empty_cache()
 
@@ -663,8 +708,10 @@ def main():
                              "the reference's arithmetic on the same stage inputs) and the conditioned network (near-identity residual blocks, x80)")}
                 if "fp32" in probes and "fp32_parity_mode" in res:
                     e32 = errs(probes["fp32"], ref["plain"])
-                    res["fp32_parity_mode"].update({f"pose_rel_err_vs_oracle_bs{B}": e32, "pose_rel_err": max(e32.values()), "bound": 1e-4,
-                                                    "within_north_star_1e-4": max(e32.values()) < 1e-4})
+                    w3 = res["fp32_parity_mode"].get("pose_rel_err_worst_of_seeds_1_2_3_vs_reference_g11")
+                    res["fp32_parity_mode"].update({f"pose_rel_err_vs_oracle_bs{B}_seed1": e32, "pose_rel_err_seed1": max(e32.values()),
+                                                    "pose_rel_err": max(max(e32.values()), w3 or 0.0), "bound": 1e-4,
+                                                    "within_north_star_1e-4": max(max(e32.values()), w3 or 0.0) < 1e-4})
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

@@ -915,6 +915,43 @@ def test_fp32_pose_parity_over_seeds_at_bs64(policy, monkeypatch):
     assert not bad, bad
 
 
+
+@pytest.mark.parametrize("tag,cfgname,B,seed,ncls", [("lm13_b64_s1", "lm13", 64, 1, 13), ("lm13_b64_s2", "lm13", 64, 2, 13), ("lm13_b64_s3", "lm13", 64, 3, 13),
+                                                    ("lmo_b32_s3", "lmo", 32, 3, 8)])
+def test_fp32_vs_the_reference_itself_at_baseline_sizes_g11(golden_dir, tag, cfgname, B, seed, ncls):
+    """the fp32 (parity) engine against golden G11 = the REFERENCE's own GDRN.forward(do_loss=True) run at BASELINE.json's
+    batch sizes (tests/golden/make_golden.py::golden_g11: LM-13 bs = 64 on seeds 1-3, LM-O bs = 32) -- no oracle between the two.  Same rule as
+    test_fp32_pose_parity_over_seeds_at_bs64: rot6d / t_ / trans within 1e-4 of the reference's fp32 outputs; R within 1e-4 of them, or -- on a
+    batch where the reference's own fp32 R is farther than that from the noise-free (fp64) value of the graph -- no farther from the fp64 value
+    than 1.5 x the reference's fp32 path is (G11 also holds the reference module evaluated in fp64, `f64/*`; seed 2: the reference's fp32 R sits
+    1.02e-4 from it, one nearly degenerate 6-vector).  The 8 losses: 2e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from gdrnet_amd.cfg import lmo_cfg
+
+    g = np.load(os.path.join(golden_dir, "g11_baseline_sizes.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    model, _ = build("fp32", {"lm13": lm13_cfg, "lmo": lmo_cfg}[cfgname])
+    model.train()
+    batch = to_dev(synth.make_batch(B, seed=seed, num_classes=ncls))
+    with torch.no_grad():
+        _, loss_dict = model(batch["roi_img"], **synth.model_kwargs(batch, do_loss=True))
+    plan = model.engine().plan(B, True, True)
+    fc = plan.fc_out.cpu()
+    got = {"rot6d": fc[:, :6], "t_": fc[:, 6:9], "rot": plan.rot.cpu(), "trans": plan.trans.cpu()}
+    ref = {k: torch.from_numpy(g[f"{tag}/{k}"]) for k in got}
+    e = {k: rel(got[k], ref[k]) for k in got}
+    msg = f"fp32 engine vs the reference itself (G11 {tag}): " + str({k: "%.2e" % v for k, v in e.items()})
+    assert max(e["rot6d"], e["t_"], e["trans"]) < 1e-4, msg
+    r64 = torch.from_numpy(g[f"{tag}/f64/rot"])
+    noise, e64 = rel(ref["rot"], r64), rel(got["rot"], r64)
+    msg += f" | R: reference fp32 vs its own fp64 evaluation {noise:.2e}, engine vs that fp64 value {e64:.2e}"
+    assert e["rot"] < 1e-4 or e64 < max(1e-4, 1.5 * noise), msg
+    print(msg)
+    for k, v in zip(list(g[f"{tag}/loss_names"]), g[f"{tag}/loss_values"]):
+        assert abs(loss_dict[k].item() - v) <= 2e-4 * max(abs(v), 1e-3), (k, loss_dict[k].item(), v)
+
+
 def test_fp32_pose_parity_over_seeds():
     """configs[0] (bs=4), fp32 mode, pose outputs against the CPU oracle on five differently seeded batches: every one within the
     1e-4 north-star bound (the single golden batch of test_fp32_train_step_vs_reference sits at 9e-5)."""

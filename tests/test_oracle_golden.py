@@ -75,6 +75,30 @@ def test_forward_loss_backward_vs_reference(g5, B, tag):
     assert int(bufs["backbone.bn1.num_batches_tracked"]) == int(g5[f"{tag}/buf/nbt"])
 
 
+
+G11_CASES = [("lm13_b64_s1", 64, 1, 13), ("lm13_b64_s2", 64, 2, 13), ("lm13_b64_s3", 64, 3, 13), ("lmo_b32_s3", 32, 3, 8)]
+
+
+@pytest.mark.parametrize("tag,B,seed,ncls", G11_CASES)
+def test_oracle_vs_reference_at_baseline_sizes_g11(golden_dir, tag, B, seed, ncls):
+    """golden G11 = the reference's own GDRN.forward(do_loss=True) (GDRN.py:83-306), train mode, at BASELINE.json's batch sizes (LM-13 bs = 64,
+    seeds 1-3; LM-O bs = 32): the oracle reproduces its pose outputs and its 8 losses to 2e-5 there too -- the bs = 64 / 32 parity tests of the
+    HIP path (tests/test_e2e_gpu.py) that compare with the ORACLE are thereby pinned to the reference at the size they run at, not only
+    transitively through the B <= 4 fixtures (missing 4 / weak 3)."""
+    g = np.load(os.path.join(golden_dir, "g11_baseline_sizes.npz"))
+    torch.set_num_threads(8)
+    batch = synth.make_batch(B, seed=seed, num_classes=ncls)
+    with torch.no_grad():
+        out = O.gdrn_forward(synth.make_state_dict(0), batch, do_loss=True, training=True, bufs={})
+    for k in ("rot6d", "t_", "rot", "trans"):
+        assert rel(out[k], g[f"{tag}/{k}"]) < 2e-5, (tag, k, rel(out[k], g[f"{tag}/{k}"]))
+    names = list(g[f"{tag}/loss_names"])
+    vals = np.array([out["loss_dict"][k].item() for k in names])
+    np.testing.assert_allclose(vals, g[f"{tag}/loss_values"], rtol=2e-5)
+    vis = dict(zip(list(g[f"{tag}/vis_names"]), g[f"{tag}/vis_values"]))
+    re, te = O.mean_re_te(out["trans"], out["rot"], batch["trans"], batch["ego_rot"])
+    assert abs(re - vis["vis/error_R"]) < 1e-2 and abs(te * 100 - vis["vis/error_t"]) < 1e-3
+
 @pytest.mark.parametrize("B,tag", [(2, "b2"), (4, "b4")])
 def test_inference_vs_reference(g5, B, tag):
     sd = synth.make_state_dict(0)
