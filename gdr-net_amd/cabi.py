@@ -174,6 +174,10 @@ _SIGS = {
     "gdrn_pack_multi": [P, P, I, I, I, P],
     "gdrn_unpack_multi": [P, P, I, I, P],
     "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, F, P],
+    "gdrn_ranger_multi_dyn": [P, P, I, I, F, F, F, F, I, I, F, F, P, P],
+    "gdrn_loss_scale_update": [P, I, P],
+    "gdrn_unscale_or_zero": [P, LL, F, P, P],
+    "gdrn_scaled_loss_weights": [P, P, I, P, P, P],
     "gdrn_roi_affine": [P, I, I, I, P, P, P, P, P],
     "gdrn_roi_crop_inputs": [P, P, I, I, I, C.POINTER(D), C.POINTER(D), P, P, P],
     "gdrn_roi_targets": [P, P, I, I, P, I, P, P, P, P, P, P, P],

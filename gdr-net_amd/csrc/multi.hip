@@ -255,8 +255,24 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const gdrn_pack_task*
 // one workgroup per (tensor, row): gradient centralisation (row mean), RAdam moments, update, optional lookahead
 __global__ __launch_bounds__(256) void ranger_multi_kernel(const gdrn_ranger_task* __restrict__ tasks, const int* __restrict__ row_start,
                                                            int ntasks, float beta1, float beta2, float eps, float wd, float step_size,
-                                                           int adaptive, int lookahead, float alpha, float grad_scale) {
+                                                           int adaptive, int lookahead, float alpha, float grad_scale,
+                                                           const gdrn_loss_scale_state* __restrict__ dyn, int n_sma_threshold, int lookahead_k) {
     __shared__ float red[4];
+    if (dyn != nullptr) {
+        // fp16 arithmetic mode, dynamic loss scale decided ON THE DEVICE (r6): an overflowed step (gdrn_nonfinite_flag raised dyn->flag) makes
+        // the whole update a no-op -- parameters, moments, slow weights untouched, as GradScaler.step skips optimizer.step -- and the step index
+        // the RAdam rectification is evaluated at counts APPLIED steps only (ranger.py:154-186 restated on the device, in double as Python's)
+        if (dyn->flag != 0) return;
+        const int step = dyn->base_step + dyn->applied + 1;
+        const double b2t = pow((double)beta2, (double)step), b1t = pow((double)beta1, (double)step);
+        const double nmax = 2.0 / (1.0 - (double)beta2) - 1.0;
+        const double nsma = nmax - 2.0 * step * b2t / (1.0 - b2t);
+        adaptive = nsma > (double)n_sma_threshold;
+        step_size = (float)(adaptive ? sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma * nmax / (nmax - 2.0)) / (1.0 - b1t)
+                                     : 1.0 / (1.0 - b1t));
+        lookahead = (step % lookahead_k) == 0;
+        grad_scale *= dyn->inv_scale;
+    }
     const int t = find_task(row_start, ntasks, blockIdx.x);
     const gdrn_ranger_task k = tasks[t];
     const size_t base = (size_t)(blockIdx.x - row_start[t]) * k.cols;
@@ -346,7 +362,83 @@ extern "C" int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* r
                                  void* stream) {
     if (!tasks_dev || !row_start_dev || ntasks <= 0 || total_rows <= 0) return GDRN_ERR_ARG;
     GDRN_LAUNCH(ranger_multi_kernel, dim3(total_rows), dim3(256), 0, ST, tasks_dev, row_start_dev, ntasks, beta1, beta2, eps,
-                       weight_decay, step_size, adaptive, lookahead, alpha, grad_scale);
+                       weight_decay, step_size, adaptive, lookahead, alpha, grad_scale, (const gdrn_loss_scale_state*)nullptr, 0, 1);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
+                                     float beta2, float eps, float weight_decay, int n_sma_threshold, int lookahead_k, float alpha, float grad_scale,
+                                     const gdrn_loss_scale_state* dyn, void* stream) {
+    if (!tasks_dev || !row_start_dev || !dyn || ntasks <= 0 || total_rows <= 0 || lookahead_k < 1) return GDRN_ERR_ARG;
+    GDRN_LAUNCH(ranger_multi_kernel, dim3(total_rows), dim3(256), 0, ST, tasks_dev, row_start_dev, ntasks, beta1, beta2, eps,
+                       weight_decay, 0.f, 0, 0, alpha, grad_scale, dyn, n_sma_threshold, lookahead_k);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+namespace {
+// the bookkeeping of torch.cuda.amp.GradScaler.update (growth_factor 2, backoff_factor 0.5) on the device, one thread: behind the optimizer
+// launches of a step (applied_step = 1) or behind a backward pass whose gradients go to an external optimizer (applied_step = 0)
+__global__ void loss_scale_update_kernel(gdrn_loss_scale_state* __restrict__ s, int applied_step) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (s->flag != 0) {
+        s->scale = fmaxf(s->scale * 0.5f, 1.f);
+        s->good = 0;
+        s->skipped += 1;
+        s->flag = 0;
+        s->last_overflowed = 1;
+    } else {
+        s->applied += applied_step;
+        s->good += 1;
+        s->last_overflowed = 0;
+        if (s->growth > 0 && s->good >= s->growth && s->scale < 65536.f) {
+            s->scale *= 2.f;
+            s->good = 0;
+        }
+    }
+    s->inv_scale = 1.f / s->scale;
+}
+
+// gradients for an EXTERNAL optimizer (the autograd path, train_step(optimizer=None)): g *= factor / scale, or g = 0 when the step overflowed
+// (GradScaler.unscale_ + the skipped step: a zero gradient instead of inf / NaN in .grad)
+__global__ __launch_bounds__(256) void unscale_or_zero_kernel(float* __restrict__ g, long long n, float factor, const gdrn_loss_scale_state* __restrict__ s) {
+    const float f = s->flag != 0 ? 0.f : factor * s->inv_scale;
+    const bool zero = s->flag != 0;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<float4*>(g + 4 * i);
+        v = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+        *reinterpret_cast<float4*>(g + 4 * i) = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) g[(n4 << 2) + threadIdx.x] = zero ? 0.f : g[(n4 << 2) + threadIdx.x] * f;
+}
+
+// dL/dloss_k of the backward pass = w_k (* w2_k) * loss scale, the scale read from the device state
+__global__ void scaled_loss_weights_kernel(const float* __restrict__ w, const float* __restrict__ w2, int n, const gdrn_loss_scale_state* __restrict__ s, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] = w[i] * (w2 ? w2[i] : 1.f) * s->scale;
+}
+}  // namespace
+
+extern "C" int gdrn_loss_scale_update(gdrn_loss_scale_state* state, int applied_step, void* stream) {
+    if (!state || (applied_step != 0 && applied_step != 1)) return GDRN_ERR_ARG;
+    GDRN_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), 0, ST, state, applied_step);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_unscale_or_zero(float* g, long long n, float factor, const gdrn_loss_scale_state* state, void* stream) {
+    if (!g || !state || n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return GDRN_ERR_ARG;
+    const int grid = (int)std::min<long long>(((n >> 2) + 255) / 256 + 1, 2048);
+    GDRN_LAUNCH(unscale_or_zero_kernel, dim3(grid), dim3(256), 0, ST, g, n, factor, state);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_scaled_loss_weights(const float* w, const float* w2, int n, const gdrn_loss_scale_state* state, float* out, void* stream) {
+    if (!w || !state || !out || n <= 0 || n > 64) return GDRN_ERR_ARG;
+    GDRN_LAUNCH(scaled_loss_weights_kernel, dim3(1), dim3(64), 0, ST, w, w2, n, state, out);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

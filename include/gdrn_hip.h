@@ -29,7 +29,9 @@ extern "C" {
 /* 2: status / dtype enums renamed (GDRN_E_* -> GDRN_ERR_*, GDRN_F32 / GDRN_BF16 -> GDRN_DT_*; the old names stay as deprecated aliases),
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
 /* 3: gdrn_conv_params grew halo_waves (appended; zero = the behaviour of version 2). */
-#define GDRN_ABI_VERSION 3
+/* 4: entry points added (nothing changed): gdrn_loss_scale_state + gdrn_ranger_multi_dyn / gdrn_loss_scale_update / gdrn_unscale_or_zero /
+ *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device. */
+#define GDRN_ABI_VERSION 4
 /* `dtype` arguments.  The 16-bit format is a property of the library build: libgdrn_hip.so computes GDRN_DT_BF16, libgdrn_hip_f16.so (the same
  * sources compiled with -DGDRN_HALF_F16: v_mfma_f32_*_f16, IEEE-half storage -- the arithmetic of the reference's fp16 autocast,
  * core/gdrn_modeling/main_gdrn.py:53-56,141, gdrn_evaluator.py:568) computes GDRN_DT_F16; each rejects the other's code with GDRN_ERR_ARG,
@@ -481,6 +483,30 @@ int gdrn_zero_multi(const gdrn_zero_task* tasks_dev, const int* blk_start_dev, i
  * found_inf test of torch.cuda.amp.GradScaler (core/gdrn_modeling/main_gdrn.py:53-56, engine.py:276-283) for the fp16 arithmetic mode: the
  * host skips the optimizer step and backs the loss scale off when it is raised (ABI 3). */
 int gdrn_nonfinite_flag(const float* x, long long n, int* flag, void* stream);
+/* Dynamic loss scale of the fp16 arithmetic mode kept ON THE DEVICE (ABI 4, round 6): what torch.cuda.amp.GradScaler holds on the host and reads
+ * back once per step (core/gdrn_modeling/engine.py:276-283 `scaler.step(optimizer)` / `scaler.update()`).  `flag` is the target of
+ * gdrn_nonfinite_flag (first member: a gdrn_loss_scale_state* is a valid `int* flag`).  A step then is: backward pass with
+ * gdrn_scaled_loss_weights' dL/dloss -> gdrn_nonfinite_flag over the gradients -> gdrn_ranger_multi_dyn (a no-op when the flag is raised; the RAdam
+ * step index = base_step + applied + 1 counts applied steps only; the gradients are divided by `scale` inside the kernel) -> gdrn_loss_scale_update
+ * (overflow: scale x 0.5 (>= 1), skipped + 1, flag cleared; clean: applied + applied_step, good + 1, and after `growth` clean steps in a row
+ * scale x 2 (<= 65536)).  No host read anywhere; a host reads the struct when it wants to log or checkpoint. */
+typedef struct gdrn_loss_scale_state {
+    int flag;            /* raised by gdrn_nonfinite_flag, cleared by gdrn_loss_scale_update */
+    int applied;         /* optimizer steps applied since the host wrote base_step */
+    int skipped;         /* overflowed steps so far */
+    int good;            /* clean steps since the scale last changed */
+    int growth;          /* growth interval (0: the scale never grows) */
+    float scale;         /* the loss scale on dL/dloss */
+    float inv_scale;     /* 1 / scale */
+    int base_step;       /* the optimizer's step count when `applied` was last zeroed */
+    int last_overflowed; /* 1 if the step gdrn_loss_scale_update closed last had overflowed */
+    int pad_[7];
+} gdrn_loss_scale_state;
+int gdrn_loss_scale_update(gdrn_loss_scale_state* state, int applied_step, void* stream);
+/* g[i] = flag ? 0 : g[i] * factor / scale  (gradients handed to an external optimizer: unscaled, or zeroed when the step overflowed) */
+int gdrn_unscale_or_zero(float* g, long long n, float factor, const gdrn_loss_scale_state* state, void* stream);
+/* out[k] = w[k] * (w2 ? w2[k] : 1) * scale, k < n <= 64: dL/dloss of the scaled backward pass */
+int gdrn_scaled_loss_weights(const float* w, const float* w2, int n, const gdrn_loss_scale_state* state, float* out, void* stream);
 /* OR-ed into the `dtype` argument of gdrn_gn_relu_bwd / gdrn_bias_grad / gdrn_stem_wgrad: the gradient outputs they accumulate
  * into with atomics were zeroed by the caller (gdrn_zero_multi) -- skip the internal hipMemsetAsync (one launch each). */
 #define GDRN_PREZEROED 0x100
@@ -492,6 +518,12 @@ int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev,
 int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
                       float beta2, float eps, float weight_decay, float step_size, int adaptive, int lookahead, float alpha,
                       float grad_scale, void* stream);
+/* the same update under a device-resident loss-scale state (see gdrn_loss_scale_state): step size / rectification / lookahead phase are
+ * evaluated inside the kernel from state->base_step + state->applied + 1, the gradients are additionally divided by state->scale, and a raised
+ * state->flag turns the launch into a no-op */
+int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
+                          float beta2, float eps, float weight_decay, int n_sma_threshold, int lookahead_k, float alpha,
+                          float grad_scale, const gdrn_loss_scale_state* state, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Inference post-processing on the device: get_out_coor + get_out_mask

@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gdrn_hip.h but not exported"
     assert sorted(cabi.EXPORTS) == declared, set(cabi.EXPORTS) ^ set(declared)
-    assert lib.gdrn_version() == 3  # host-only call (no device needed)
+    assert lib.gdrn_version() == 4  # host-only call (no device needed)
 
 
 def test_struct_layouts_match_the_header():
