@@ -235,8 +235,13 @@ class _PathFn(torch.autograd.Function):
             # the plan keeps ONE set of activations per (batch size, mode): a second forward overwrote what this backward needs
             raise cabi.GdrnHipError("backward of a forward pass whose activations were overwritten by a later forward of the same "
                                     "batch size: call loss.backward() before the next model(...) call")
-        ls = float(getattr(e, "loss_scale", 1.0))
-        plan.gw.copy_(glosses.to(torch.float32) * ls)   # (fp16: the engine's static loss scale on the whole gradient chain)
+        dyn = e.loss_scale_dev()   # fp16 with the dynamic loss scale: the device-resident state (None otherwise)
+        ls = 1.0 if dyn is not None else float(e._ls_host)
+        if dyn is not None:
+            gl = glosses.to(torch.float32).contiguous()
+            cabi.check(e.lib.gdrn_scaled_loss_weights(gl.data_ptr(), None, 8, dyn.ptr, plan.gw.data_ptr(), e._stream()), "scaled_loss_weights")
+        else:
+            plan.gw.copy_(glosses.to(torch.float32) * ls)   # (fp16, static: the engine's loss scale on the whole gradient chain)
         plan._gw_key = None
         plan.run_backward(ctx.kctx, on_bucket=ctx.model._on_bucket)
         red = getattr(ctx.model, "_reducer", None)
@@ -244,7 +249,9 @@ class _PathFn(torch.autograd.Function):
             # autograd clones these views into .grad on the compute stream right after we return: the bucket all-reduces
             # running on the reducer's side stream must have landed (and the mean be applied) before that
             red.finish()
-        if ls != 1.0:
+        if dyn is not None:
+            ctx.model._unscale_for_external_optimizer(e, dyn, 1.0)
+        elif ls != 1.0:
             e.grad_flat.mul_(1.0 / ls)   # .grad is the unscaled gradient, as after GradScaler.unscale_()
         return (None, None, None) + tuple(e.grads[n] for n in e.param_names)
 
@@ -268,8 +275,10 @@ class GDRN(nn.Module):
         # Arithmetic of the kernels: "bf16" (default), "fp16", "fp32" (parity mode).  An explicit cfg.MODEL.CDPN.HIP_DTYPE / GDRN_HIP_DTYPE
         # applies to training and inference alike.  Without one the reference's two AMP switches select fp16, the format of its autocast:
         # cfg.SOLVER.AMP.ENABLED (autocast + GradScaler around the train step, main_gdrn.py:53-56,141, engine.py:276-283) -> fp16 training
-        # with the engine's static loss scale; cfg.TEST.AMP_TEST (autocast around the test-time forward, gdrn_evaluator.py:568) -> fp16
-        # inference (eval-mode forward) whatever the training arithmetic is.
+        # under the engine's loss scale (dynamic like GradScaler's by default, kept on the device: engine.LossScaleState; every path that hands
+        # gradients out -- train_step with or without an optimizer, loss.backward() -- runs the finite check, and an overflowed pass leaves zero
+        # gradients / a skipped fused step, never inf / NaN); cfg.TEST.AMP_TEST (autocast around the test-time forward, gdrn_evaluator.py:568)
+        # -> fp16 inference (eval-mode forward) whatever the training arithmetic is.
         explicit = cfg.MODEL.CDPN.get("HIP_DTYPE", os.environ.get("GDRN_HIP_DTYPE"))
         solver, test = cfg.get("SOLVER", None), cfg.get("TEST", None)
         amp_train = bool(solver is not None and solver.get("AMP", None) is not None and solver.AMP.get("ENABLED", False))
@@ -488,8 +497,15 @@ class GDRN(nn.Module):
         # the returned losses (weighted like forward()'s loss_dict) are formed HERE, on the main stream in front of the backward chain, which
         # ends ~0.1 ms before the side stream does: behind the final join the one small launch and its gap were the step's last 15 us
         out = plan.losses * self._loss_w
-        ls = eng.loss_scale   # fp16: static loss scale on dL/dloss, divided out where the optimizer reads the gradients
-        if loss_weights is not None:
+        dyn = eng.loss_scale_dev()   # fp16, dynamic loss scale: its state on the device (None: bf16 / fp32 / fp16 with a static scale)
+        ls = 1.0 if dyn is not None else eng._ls_host   # static loss scale on dL/dloss, divided out where the optimizer reads the gradients
+        if dyn is not None:
+            # dL/dloss_k = weight_k x the scale as the DEVICE holds it (it changes without the host knowing): one 8-thread launch per step
+            lw2 = None if loss_weights is None else torch.as_tensor(loss_weights, dtype=torch.float32, device=eng.dev).contiguous()
+            cabi.check(eng.lib.gdrn_scaled_loss_weights(self._loss_w.data_ptr(), None if lw2 is None else lw2.data_ptr(), 8, dyn.ptr, plan.gw.data_ptr(),
+                                                        eng._stream()), "scaled_loss_weights")
+            plan._gw_key = None
+        elif loss_weights is not None:
             plan.gw.copy_(self._loss_w * loss_weights * ls)
             plan._gw_key = None
         elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version, ls):
@@ -503,7 +519,7 @@ class GDRN(nn.Module):
         mine = red is not None and self._on_bucket == red.on_bucket and red.defer_scale and (red.cuda or not red.active)
         # (fp16 with the dynamic loss scale: the update waits for the finite check over ALL gradients -- a bucket applied under the backward
         #  pass could not be taken back when a later bucket overflows)
-        guard = optimizer is not None and eng.loss_scale_dynamic
+        guard = dyn is not None
         early = (optimizer is not None and (mine or (red is None and self._on_bucket is None)) and eng.wgrad_stream and not guard
                  and hasattr(optimizer, "step_buckets_begin") and os.environ.get("GDRN_EARLY_OPT", "1") != "0")
         if early:
@@ -544,8 +560,22 @@ class GDRN(nn.Module):
         if red is not None:
             red.wait()
             gs = red.grad_scale / ls  # 1/world, folded into the fused optimizer's gradient read
-        if guard and self._overflowed(eng):
-            return out   # GradScaler.step: the optimizer step is skipped, the scale halved (the next step re-writes dL/dloss with it)
+        if guard:
+            # fp16 with the dynamic loss scale, decided on the device (r6): finite check over the flat gradient buffer (behind the all-reduce: every
+            # rank decides alike) -> fused Ranger that is a no-op when the flag is up, divides by the scale and counts applied steps itself ->
+            # GradScaler.update's bookkeeping as a one-thread launch.  No host read: the host keeps launching (r5 read the flag every step).
+            eng = plan.e
+            cabi.check(eng.lib.gdrn_nonfinite_flag(eng.grad_flat.data_ptr(), eng.grad_flat.numel(), dyn.ptr, eng._stream()), "nonfinite_flag")
+            grads = {eng.P[n]: eng.grads[n] for n in eng.param_names}
+            if optimizer is not None and hasattr(optimizer, "step_dyn") and optimizer.step_dyn(grads, gs, dyn):
+                cabi.check(eng.lib.gdrn_loss_scale_update(dyn.ptr, 1, eng._stream()), "loss_scale_update")
+                return out
+            # gradients for an optimizer that is not the fused Ranger (or none): unscaled, zeroed if the step overflowed; such an optimizer's
+            # step is skipped on the host's reading of the state (GradScaler.step does the same read)
+            self._unscale_for_external_optimizer(eng, dyn, gs)
+            if optimizer is not None and not dyn.read()["last_overflowed"]:
+                optimizer.step(grads=grads) if getattr(optimizer, "takes_grad_scale", False) else self._step_foreign(optimizer, grads)
+            return out
         if optimizer is not None:
             eng = plan.e
             grads = {eng.P[n]: eng.grads[n] for n in eng.param_names}
@@ -560,26 +590,26 @@ class GDRN(nn.Module):
             plan.e.grad_flat.mul_(gs)
         return out
 
-    def _overflowed(self, eng):
-        """fp16 arithmetic mode, the dynamic half of the reference's GradScaler (main_gdrn.py:53-56; engine.py:276-283 `scaler.step` /
-        `scaler.update`): one pass over the flat gradient buffer (gdrn_nonfinite_flag; after the all-reduce, so every rank decides alike),
-        one host read of its flag -- GradScaler.step reads its found_inf the same way.  Overflow: True (the caller skips the optimizer step),
-        loss scale x 0.5 (>= 1); otherwise False, and after loss_scale_growth clean steps the scale doubles (<= 65536)."""
-        if eng._nonfinite is None:
-            eng._nonfinite = torch.zeros(1, dtype=torch.int32, device=eng.dev)
-        cabi.check(eng.lib.gdrn_nonfinite_flag(eng.grad_flat.data_ptr(), eng.grad_flat.numel(), eng._nonfinite.data_ptr(), eng._stream()), "nonfinite_flag")
-        if int(eng._nonfinite.item()):
-            eng._nonfinite.zero_()
-            eng.loss_scale_skipped += 1
-            eng.loss_scale_good = 0
-            new = max(eng.loss_scale * 0.5, 1.0)
-            logger.warning("fp16 step %d skipped: inf / NaN in the gradients; loss scale %g -> %g", eng.loss_scale_skipped, eng.loss_scale, new)
-            eng.loss_scale = new
-            return True
-        eng.loss_scale_good += 1
-        if eng.loss_scale_good >= eng.loss_scale_growth and eng.loss_scale < 65536.0:
-            eng.loss_scale, eng.loss_scale_good = eng.loss_scale * 2.0, 0
-        return False
+    @staticmethod
+    def _unscale_for_external_optimizer(eng, dyn, factor):
+        """fp16, dynamic loss scale, gradients leaving the engine (autograd's .grad, train_step(optimizer=None)): finite check, then g <- g * factor /
+        scale or 0 when the pass overflowed (no inf / NaN reaches an optimizer -- ADVICE r5), then the scale's bookkeeping (a skipped step halves it)."""
+        st = eng._stream()
+        cabi.check(eng.lib.gdrn_nonfinite_flag(eng.grad_flat.data_ptr(), eng.grad_flat.numel(), dyn.ptr, st), "nonfinite_flag")
+        cabi.check(eng.lib.gdrn_unscale_or_zero(eng.grad_flat.data_ptr(), eng.grad_flat.numel(), float(factor), dyn.ptr, st), "unscale_or_zero")
+        cabi.check(eng.lib.gdrn_loss_scale_update(dyn.ptr, 0, st), "loss_scale_update")
+
+    @staticmethod
+    def _step_foreign(optimizer, grads):
+        for p, g in grads.items():
+            p.grad = g
+        optimizer.step()
+
+    def grad_overflowed(self):
+        """did the last fp16 backward pass (dynamic loss scale) overflow?  Its gradients were zeroed / its fused optimizer step skipped.  Reads the
+        device state (a host synchronisation)."""
+        e = self._eng
+        return bool(e is not None and e.ls_state is not None and e.ls_state.read()["last_overflowed"])
 
     def _dp_divergence_check(self, eng):
         """Data-parallel safety net of the per-bucket optimizer (the update of a bucket runs on the reducer's stream right behind its all-reduce,
@@ -614,7 +644,7 @@ class GDRN(nn.Module):
         replayed from then on; the optimizer step stays outside (its scalars change every step).  Returns None when the
         eager path has to run (warm-up, symmetric objects with a changing symmetry count, ...)."""
         B = int(x.shape[0])
-        if self.engine().loss_scale != 1.0 or self.engine().loss_scale_dynamic:
+        if self.engine().loss_scale_dynamic or self.engine()._ls_host != 1.0:
             return None   # fp16: dL/dloss carries a loss scale that changes between steps and the optimizer waits for the finite check -- eager path
         st = self.__dict__.setdefault("_graph_state", {}).setdefault(B, dict(calls=0, staging={}, graph=None, plan=None, ok=True))
         if not st["ok"]:

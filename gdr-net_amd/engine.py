@@ -74,11 +74,13 @@ class Engine:
         # (2000 = GradScaler's growth_interval); ":static" keeps the scale fixed and the optimizer update overlapped with the backward pass
         import os as _os0
         ls_spec = (_os0.environ.get("GDRN_LOSS_SCALE", "1024:2000") + ":2000").split(":")
-        self.loss_scale = float(ls_spec[0]) if self.dt == F16 else 1.0
+        # (r6) the dynamic state lives ON THE DEVICE (LossScaleState = gdrn_loss_scale_state): the finite check raises its flag, the fused optimizer
+        # reads flag / scale / step index from it, a one-thread kernel does GradScaler.update's bookkeeping -- no host read in the step; the
+        # properties below (loss_scale, loss_scale_skipped, loss_scale_good) read it back when somebody asks (logging, checkpoints, tests)
+        self._ls_host = float(ls_spec[0]) if self.dt == F16 else 1.0
         self.loss_scale_dynamic = self.dt == F16 and ls_spec[1] != "static"
         self.loss_scale_growth = int(ls_spec[1]) if ls_spec[1] != "static" else 0
-        self.loss_scale_good, self.loss_scale_skipped = 0, 0   # clean steps since the last change / optimizer steps skipped so far
-        self._nonfinite = None                                  # int32 device flag (allocated by the first fp16 train step)
+        self.ls_state = None   # LossScaleState, made by the first step that needs it (loss_scale_dev)
         self.dev = next(iter(params.values())).device
         self.dry = bool(dry)
         if self.dev.type != "cuda" and not self.dry:
@@ -190,6 +192,36 @@ class Engine:
         self.grads = {n: self.grad_flat[self.grad_offsets[n]: self.grad_offsets[n] + self.P[n].numel()].view(self.P[n].shape)
                       for n in self.param_names}
         self.bucket_bounds = self._bucket_bounds()
+
+    # ------------------------------------------------------------------------------------------ fp16 loss scale
+    @property
+    def loss_scale(self):
+        """the loss scale on dL/dloss (1 for bf16 / fp32).  Dynamic mode: read back from the device state -- a host synchronisation, not for the step's hot path"""
+        if self.ls_state is not None:
+            self._ls_host = self.ls_state.read()["scale"]
+        return self._ls_host
+
+    @loss_scale.setter
+    def loss_scale(self, v):
+        self._ls_host = float(v)
+        if self.ls_state is not None:
+            self.ls_state.write(scale=float(v))
+
+    @property
+    def loss_scale_skipped(self):
+        return self.ls_state.read()["skipped"] if self.ls_state is not None else 0
+
+    @property
+    def loss_scale_good(self):
+        return self.ls_state.read()["good"] if self.ls_state is not None else 0
+
+    def loss_scale_dev(self):
+        """the device-resident loss-scale state of the dynamic fp16 mode (None otherwise)"""
+        if not self.loss_scale_dynamic or self.dry:
+            return None
+        if self.ls_state is None:
+            self.ls_state = LossScaleState(self.dev, self._ls_host, self.loss_scale_growth)
+        return self.ls_state
 
     def set_bucket_layout(self, nb):
         """switch the gradient bucket layout (4: one GPU, 5: data parallel -- the layer4 exchange starts earlier) after construction:
@@ -488,6 +520,37 @@ class Engine:
         else:
             self.plans.move_to_end(key)
         return p
+
+
+class LossScaleState:
+    """gdrn_loss_scale_state (include/gdrn_hip.h) in device memory: what torch.cuda.amp.GradScaler keeps on the host (main_gdrn.py:53-56;
+    engine.py:276-283).  Words: 0 flag | 1 applied | 2 skipped | 3 good | 4 growth | 5 scale (f32) | 6 1 / scale (f32) | 7 base_step | 8 last_overflowed."""
+
+    def __init__(self, dev, scale, growth):
+        self.t = torch.zeros(16, dtype=torch.int32, device=dev)
+        self.f = self.t.view(torch.float32)
+        self.write(scale=scale, growth=growth)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    def write(self, scale=None, growth=None, base_step=None):
+        """host -> device (asynchronous on the current stream).  base_step: the optimizer's step count; re-basing zeroes `applied`."""
+        if scale is not None:
+            self.f[5:7] = torch.tensor([float(scale), 1.0 / float(scale)], dtype=torch.float32).to(self.t.device, non_blocking=True)
+        if growth is not None:
+            self.t[4:5] = int(growth)
+        if base_step is not None:
+            self.t[7:8] = int(base_step)
+            self.t[1:2] = 0
+
+    def read(self):
+        """device -> host (synchronises the current stream)"""
+        v = self.t.cpu()
+        fv = v.view(torch.float32)
+        return dict(flag=int(v[0]), applied=int(v[1]), skipped=int(v[2]), good=int(v[3]), growth=int(v[4]), scale=float(fv[5]), inv_scale=float(fv[6]),
+                    base_step=int(v[7]), last_overflowed=int(v[8]))
 
 
 _hip_rt = None

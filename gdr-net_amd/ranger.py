@@ -78,7 +78,12 @@ class Ranger(Optimizer):
         self.use_gc = use_gc
         self.gc_gradient_threshold = 3 if gc_conv_only else 1
 
+    def state_dict(self):
+        self.sync_dyn()   # (step counters of a run under a device-resident loss-scale state: step_dyn)
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
+        self._dyn = None  # the next step_dyn re-bases the device's step index on the loaded counters
         super().load_state_dict(state_dict)
         self._buckets_poisoned = False   # (see step_buckets_abort)
         self.__dict__.pop("_multi_cache", None)   # the task tables hold the old state tensors' addresses
@@ -127,6 +132,7 @@ class Ranger(Optimizer):
         """grads: dict param -> fp32 gradient; bucket_of(param) -> bucket index.  Prepares one gdrn_ranger_multi launch per (param group,
         bucket) for the NEXT step index; the step counters themselves advance in step_buckets_end.  False: the per-bucket path does not
         apply (mixed step counts, CPU parameters, ...) and nothing was changed -- call step()."""
+        self._leave_dyn()
         plan = []
         for gi, group in enumerate(self.param_groups):
             items = [(p, grads[p].detach()) for p in group["params"] if grads.get(p) is not None]
@@ -195,12 +201,70 @@ class Ranger(Optimizer):
         for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
             hook(self, (), {})
 
+    # ---- fp16 arithmetic mode with the dynamic loss scale on the device (r6): no host read between the backward pass and the update
+    @torch.no_grad()
+    def step_dyn(self, grads, grad_scale, dyn):
+        """One fused step under a device-resident loss-scale state `dyn` (engine.LossScaleState = gdrn_loss_scale_state): gdrn_ranger_multi_dyn
+        turns into a no-op when the state's overflow flag is raised (GradScaler.step's skip, decided on the device), divides the gradients by the
+        state's scale, and evaluates RAdam's step size / rectification / lookahead phase at base_step + applied + 1 -- the count of APPLIED
+        steps, kept on the device.  The host's state["step"] counters are NOT advanced here: sync_dyn() (called by state_dict()) reads them back.
+        The caller launches gdrn_loss_scale_update behind this.  False: the per-group multi-tensor path does not apply -- nothing was launched."""
+        plan = []
+        for gi, group in enumerate(self.param_groups):
+            items = [(p, grads[p].detach()) for p in group["params"] if grads.get(p) is not None]
+            if not items:
+                continue
+            if any(p.device.type != "cuda" or p.dtype != torch.float32 or g.dtype != torch.float32 or not g.is_contiguous() for p, g in items):
+                return False
+            states = [self._init_state(p) for p, _ in items]
+            plan.append((gi, group, items, states))
+        steps = {s["step"] for _, _, _, states in plan for s in states}
+        if len(steps) != 1:
+            return False
+        if getattr(self, "_dyn", None) is not dyn:
+            dyn.write(base_step=steps.pop())   # (re)base: device step index = these counters + steps applied from here on
+            self._dyn = dyn
+        lib = cabi.load()
+        st = torch.cuda.current_stream().cuda_stream
+        for hook in list(_global_pre_hooks()) + list(getattr(self, "_optimizer_step_pre_hooks", {}).values()):
+            hook(self, (), {})
+        for gi, group, items, states in plan:
+            beta1, beta2 = group["betas"]
+            tab, stt, nt, nrows = self._multi_table(("dyn", gi), items, float(group["lr"]))
+            cabi.check(lib.gdrn_ranger_multi_dyn(tab.data_ptr(), stt.data_ptr(), nt, nrows, beta1, beta2, group["eps"], group["weight_decay"],
+                                                 int(self.N_sma_threshhold), int(group["k"]), self.alpha, float(grad_scale), dyn.ptr, st), "ranger_multi_dyn")
+            for p, _ in items:
+                _bump_version(p)   # (possibly) updated in place behind autograd's back
+        self._opt_called = True
+        for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
+            hook(self, (), {})
+        return True
+
+    def sync_dyn(self):
+        """host step counters <- the device's count of applied steps (a host synchronisation; no-op without step_dyn)"""
+        dyn = getattr(self, "_dyn", None)
+        if dyn is None:
+            return
+        r = dyn.read()
+        step = r["base_step"] + r["applied"]
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p in self.state and "step" in self.state[p]:
+                    self.state[p]["step"] = step
+
+    def _leave_dyn(self):
+        """a step outside step_dyn follows: bring the host counters up to date and forget the device's base"""
+        if getattr(self, "_dyn", None) is not None:
+            self.sync_dyn()
+            self._dyn = None
+
     @torch.no_grad()
     def step(self, closure=None, grads=None, grad_scale=1.0):
         """grads: optional dict param -> fp32 gradient tensor (used by the fused train step to read the
         engine's flat gradient buffer directly instead of ``p.grad``).  One multi-tensor launch per param group
         when every tensor of the group is at the same step count (the normal case); per-tensor launches otherwise.
         grad_scale: factor applied to every gradient inside the kernel (1/world_size after a SUM all-reduce)."""
+        self._leave_dyn()
         lib = cabi.load()
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]

@@ -215,7 +215,9 @@ def test_fp16_overflow_skips_the_optimizer_step_and_backs_the_loss_scale_off():
     """the dynamic half of the reference's GradScaler (main_gdrn.py:53-56; engine.py:276-283) in the fused fp16 train step.
     A loss scale far too large overflows the fp16 gradient chain: the step's gradients hold inf / NaN, the optimizer step must be SKIPPED
     (parameters, Ranger moments and step counters untouched), the scale halved; with a sane scale the next step updates normally; after
-    the growth interval of clean steps (GDRN_LOSS_SCALE = "1024:2" here) the scale doubles.  The per-bucket optimizer (updates under the backward pass) is off in this mode."""
+    the growth interval of clean steps (GDRN_LOSS_SCALE = "1024:2" here) the scale doubles.  The per-bucket optimizer (updates under the backward pass) is off in this mode.
+    Round 6: all of it is decided ON THE DEVICE (gdrn_nonfinite_flag -> gdrn_ranger_multi_dyn -> gdrn_loss_scale_update over a gdrn_loss_scale_state): the
+    step makes no host read; scale / skipped count / step counters are read back here because the test asks for them."""
     B = 4
     batch = E.to_dev(synth.make_batch(B, seed=5))
     kw = synth.model_kwargs(batch, do_loss=True)
@@ -231,15 +233,16 @@ def test_fp16_overflow_skips_the_optimizer_step_and_backs_the_loss_scale_off():
     assert eng.loss_scale_dynamic and eng.loss_scale == 1024.0
     model.train_step(batch["roi_img"], optimizer=opt, **kw)          # a normal step (moments exist afterwards)
     torch.cuda.synchronize()
-    assert eng.loss_scale_skipped == 0 and {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {1}
+    steps = lambda: (opt.sync_dyn(), {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]})[1]   # (the host's counters are brought up to date on request)
+    assert eng.loss_scale_skipped == 0 and steps() == {1}
     snap = {n: p.detach().clone() for n, p in model.named_parameters()}
     mom = {n: opt.state[p]["exp_avg"].clone() for n, p in model.named_parameters()}
     eng.loss_scale = 2.0 ** 60                                       # dL/dloss beyond fp16's range: the chain overflows
     out = model.train_step(batch["roi_img"], optimizer=opt, **kw)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()                                 # the losses themselves are fp32 forward results
-    assert eng.loss_scale_skipped == 1 and eng.loss_scale == 2.0 ** 59
-    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {1}
+    assert eng.loss_scale_skipped == 1 and eng.loss_scale == 2.0 ** 59 and model.grad_overflowed()
+    assert steps() == {1}
     for n, p in model.named_parameters():
         assert torch.equal(p.detach(), snap[n]), n
         assert torch.equal(opt.state[p]["exp_avg"], mom[n]), n
@@ -247,7 +250,50 @@ def test_fp16_overflow_skips_the_optimizer_step_and_backs_the_loss_scale_off():
     for _ in range(2):
         model.train_step(batch["roi_img"], optimizer=opt, **kw)
     torch.cuda.synchronize()
-    assert {opt.state[p]["step"] for g in opt.param_groups for p in g["params"]} == {3}
+    assert steps() == {3} and not model.grad_overflowed()
+    assert opt.state_dict()["state"][0]["step"] == 3                  # ... and a checkpoint carries the synchronised counters
     assert eng.loss_scale == 2048.0 and eng.loss_scale_skipped == 1   # two clean steps (growth interval 2): doubled
     assert all(torch.isfinite(p).all() for p in model.parameters())
     assert not torch.equal(dict(model.named_parameters())["backbone.conv1.weight"].detach(), snap["backbone.conv1.weight"])
+
+
+def test_fp16_overflow_on_the_autograd_and_external_optimizer_paths_leaves_zero_gradients():
+    """the paths that hand gradients to somebody else's optimizer -- loss.backward() (autograd node) and train_step(optimizer=None) --
+    run the finite check too: an overflowed pass leaves ZERO gradients (not inf / NaN), halves the scale and can be queried
+    (model.grad_overflowed()); a clean pass leaves the unscaled gradients (equal to the static-scale engine's up to the scale's exactness)."""
+    B = 4
+    batch = E.to_dev(synth.make_batch(B, seed=5))
+    kw = synth.model_kwargs(batch, do_loss=True)
+    model, opt = E.build("fp16")
+    model.load_state_dict(synth.conditioned_state_dict(0))
+    model.train()
+    eng = model.engine()
+    assert eng.loss_scale_dynamic
+    # clean autograd pass
+    _, ld = model(batch["roi_img"], **kw)
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    g_clean = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g_clean.values()) and not model.grad_overflowed()
+    assert float(g_clean["rot_head_net.features.20.weight"].abs().max()) > 0
+    # overflowing autograd pass
+    eng.loss_scale = 2.0 ** 60
+    model.zero_grad()
+    _, ld = model(batch["roi_img"], **kw)
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    assert model.grad_overflowed() and eng.loss_scale == 2.0 ** 59
+    assert all(torch.equal(p.grad, torch.zeros_like(p.grad)) for p in model.parameters())
+    # train_step(optimizer=None): same rule on the engine's flat buffer
+    eng.loss_scale = 2.0 ** 60
+    kw2 = dict(kw)
+    kw2.pop("do_loss")
+    model.train_step(batch["roi_img"], optimizer=None, **kw2)
+    torch.cuda.synchronize()
+    assert model.grad_overflowed() and float(eng.grad_flat.abs().max()) == 0.0
+    eng.loss_scale = 1024.0
+    model.train_step(batch["roi_img"], optimizer=None, **kw2)
+    torch.cuda.synchronize()
+    assert not model.grad_overflowed()
+    g2 = eng.grads["rot_head_net.features.20.weight"]
+    assert E.rel(g2, g_clean["rot_head_net.features.20.weight"]) < 2e-2   # (BatchNorm running statistics moved in between; the batch statistics did not)
