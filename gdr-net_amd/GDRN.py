@@ -235,8 +235,8 @@ class _PathFn(torch.autograd.Function):
             # the plan keeps ONE set of activations per (batch size, mode): a second forward overwrote what this backward needs
             raise cabi.GdrnHipError("backward of a forward pass whose activations were overwritten by a later forward of the same "
                                     "batch size: call loss.backward() before the next model(...) call")
-        dyn = e.loss_scale_dev()   # fp16 with the dynamic loss scale: the device-resident state (None otherwise)
-        ls = 1.0 if dyn is not None else float(e._ls_host)
+        dyn = e.loss_scale_dev() if hasattr(e, "loss_scale_dev") else None   # fp16 with the dynamic loss scale: the device-resident state (None otherwise)
+        ls = 1.0 if dyn is not None else float(getattr(e, "_ls_host", getattr(e, "loss_scale", 1.0)))
         if dyn is not None:
             gl = glosses.to(torch.float32).contiguous()
             cabi.check(e.lib.gdrn_scaled_loss_weights(gl.data_ptr(), None, 8, dyn.ptr, plan.gw.data_ptr(), e._stream()), "scaled_loss_weights")
