@@ -153,6 +153,8 @@ _SIGS = {
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_bwd": [P, P, I, I, I, I, I, P],
+    "gdrn_bn_relu_upsample2x_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "gdrn_upsample2x_bwd_bnsums": [P, P, P, P, P, P, P, I, I, I, I, P, I, P],
     "gdrn_gn_relu_fwd": [P, P, P, P, P, I, I, I, I, F, I, P],
     "gdrn_gn_relu_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_leaky_bwd": [P, P, P, LL, I, P],

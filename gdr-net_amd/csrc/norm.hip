@@ -397,8 +397,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------ upsample
 // PyTorch area_pixel_compute_source_index(align_corners=True): src = dst * (in-1)/(out-1) in fp32.
-template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+// BNR (r6): x is the RAW input of a BatchNorm + ReLU and the upsampled tensor is that of relu(scale * x + shift), each source value rounded to
+// the storage format first -- exactly what gdrn_bn_apply would have stored and this kernel then read (cdpn_rot_head_region.py:103-123:
+// BN -> ReLU -> UpsamplingBilinear2d): one launch and one tensor round trip less per upsampling
+template <typename T, bool BNR = false>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                                             const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
     constexpr int V = Vec16<T>::VEC;
     const int Ho = 2 * H, Wo = 2 * W, cvn = C / V;
     const float sh = (float)(H - 1) / (float)(Ho - 1), sw = (float)(W - 1) / (float)(Wo - 1);
@@ -419,6 +423,20 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
         Vec16<T>::load(b + (size_t)xp * C, a01);
         Vec16<T>::load(b + (size_t)yp * W * C, a10);
         Vec16<T>::load(b + ((size_t)yp * W + xp) * C, a11);
+        if constexpr (BNR) {
+            float sc[V], sh_[V], t[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { sc[j] = scale[cv * V + j]; sh_[j] = shift[cv * V + j]; }
+            float* src[4] = {a00, a01, a10, a11};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) t[j] = fmaxf(__builtin_fmaf(src[k][j], sc[j], sh_[j]), 0.f);   // bn_apply_kernel's arithmetic
+                alignas(16) T q[V];
+                Vec16<T>::store(q, t);     // round to the storage format ...
+                Vec16<T>::load(q, src[k]); // ... as the stored activation would have been
+            }
+        }
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
         Vec16<T>::store(y + (size_t)i * V, o);
@@ -436,6 +454,57 @@ __device__ __forceinline__ float up_weight(int o, int i, int In, float s) {
     return w;
 }
 
+// gradient of the 2x bilinear (align_corners) upsampling w.r.t. input pixel (n, iy, ix), channel vector cv: acc[V]
+template <typename T>
+__device__ __forceinline__ void up_bwd_pixel(const T* __restrict__ dy, int n, int iy, int ix, int cv, int H, int W, int C, float sh, float sw,
+                                             float (&acc)[Vec16<T>::VEC]) {
+    constexpr int V = Vec16<T>::VEC;
+    const int Ho = 2 * H, Wo = 2 * W;
+    // outputs whose source coordinate lies in (iy-1, iy+1): a candidate range of at most six per dimension, of which at most FOUR
+    // consecutive ones carry a weight (2x, align_corners).  The 4 x 4 block starting at the first weighted row / column is loaded from
+    // clamped addresses with zero weights where there is nothing -- all loads independent.  (Walking the candidate range with
+    // `continue` on zero weights issued the up to 16 loads of a pixel one memory round trip after the other.)
+    const int oy_lo = max(0, (int)floorf((iy - 1) / sh)), ox_lo = max(0, (int)floorf((ix - 1) / sw));
+    float wyc[6], wxc[6];
+    int fy = 5, fx = 5;
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+        wyc[k] = (oy_lo + k < Ho) ? up_weight(oy_lo + k, iy, H, sh) : 0.f;
+        wxc[k] = (ox_lo + k < Wo) ? up_weight(ox_lo + k, ix, W, sw) : 0.f;
+        if (wyc[k] != 0.f) fy = k;
+        if (wxc[k] != 0.f) fx = k;
+    }
+    float wy4[4], wx4[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        wy4[a] = 0.f;
+        wx4[a] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (fy + a == k) wy4[a] = wyc[k];
+            if (fx + a == k) wx4[a] = wxc[k];
+        }
+    }
+    const int oy0 = oy_lo + fy, ox0 = ox_lo + fx;
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const size_t row = (size_t)(n * Ho + min(oy0 + a, Ho - 1)) * Wo;
+        float d[4][V];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Vec16<T>::load(dy + (row + min(ox0 + b, Wo - 1)) * C + cv * V, d[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float w = wy4[a] * wx4[b];
+            if (w != 0.f) {   // (same order of additions as before: oy outer, ox inner, zero weights skipped)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += w * d[b][j];
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
     constexpr int V = Vec16<T>::VEC;
@@ -448,52 +517,72 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
-        // outputs whose source coordinate lies in (iy-1, iy+1): a candidate range of at most six per dimension, of which at most FOUR
-        // consecutive ones carry a weight (2x, align_corners).  The 4 x 4 block starting at the first weighted row / column is loaded from
-        // clamped addresses with zero weights where there is nothing -- all loads independent.  (Walking the candidate range with
-        // `continue` on zero weights issued the up to 16 loads of a pixel one memory round trip after the other.)
-        const int oy_lo = max(0, (int)floorf((iy - 1) / sh)), ox_lo = max(0, (int)floorf((ix - 1) / sw));
-        float wyc[6], wxc[6];
-        int fy = 5, fx = 5;
-#pragma unroll
-        for (int k = 5; k >= 0; --k) {
-            wyc[k] = (oy_lo + k < Ho) ? up_weight(oy_lo + k, iy, H, sh) : 0.f;
-            wxc[k] = (ox_lo + k < Wo) ? up_weight(ox_lo + k, ix, W, sw) : 0.f;
-            if (wyc[k] != 0.f) fy = k;
-            if (wxc[k] != 0.f) fx = k;
-        }
-        float wy4[4], wx4[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            wy4[a] = 0.f;
-            wx4[a] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (fy + a == k) wy4[a] = wyc[k];
-                if (fx + a == k) wx4[a] = wxc[k];
-            }
-        }
-        const int oy0 = oy_lo + fy, ox0 = ox_lo + fx;
         float acc[V];
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const size_t row = (size_t)(n * Ho + min(oy0 + a, Ho - 1)) * Wo;
-            float d[4][V];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) Vec16<T>::load(dy + (row + min(ox0 + b, Wo - 1)) * C + cv * V, d[b]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float w = wy4[a] * wx4[b];
-                if (w != 0.f) {   // (same order of additions as before: oy outer, ox inner, zero weights skipped)
-#pragma unroll
-                    for (int j = 0; j < V; ++j) acc[j] += w * d[b][j];
-                }
-            }
-        }
+        up_bwd_pixel<T>(dy, n, iy, ix, cv, H, W, C, sh, sw, acc);
         Vec16<T>::store(dx + (size_t)i * V, acc);
     }
+}
+
+// ... and the same with the reduction pass of the BatchNorm(+ReLU) backward that reads the result (bn_bwd_reduce_kernel, affine ReLU mask):
+// channel-stationary threads (cv, rl) walk the low-resolution pixels of the workgroup's row range, write dx UNMASKED (what the separate
+// kernel stores; the consumer's operand transform masks it) and accumulate sum g / sum g * xhat of the masked, storage-rounded value
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_bnsums_kernel(const T* __restrict__ dy, T* __restrict__ dx, const T* __restrict__ x,
+                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                    const float* __restrict__ msc, const float* __restrict__ msh, int N, int H,
+                                                                    int W, int C, float* __restrict__ rows, int rows_per_block) {
+    constexpr int V = Vec16<T>::VEC;
+    const int tpr = C / V, rpp = 256 / tpr;
+    const int cv = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    const float sh = (float)(H - 1) / (float)(2 * H - 1), sw = (float)(W - 1) / (float)(2 * W - 1);
+    __shared__ float kst[4][512];
+    __shared__ float part[4][2 * 512];
+    for (int c = threadIdx.x; c < C; c += 256) { kst[0][c] = mean[c]; kst[1][c] = invstd[c]; kst[2][c] = msc[c]; kst[3][c] = msh[c]; }
+    for (int i = threadIdx.x; i < 4 * 2 * 512; i += 256) (&part[0][0])[i] = 0.f;
+    __syncthreads();
+    float s1[V], s2[V], mu[V], is[V], ksc[V], ksh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        s1[j] = 0.f; s2[j] = 0.f;
+        mu[j] = kst[0][cv * V + j]; is[j] = kst[1][cv * V + j]; ksc[j] = kst[2][cv * V + j]; ksh[j] = kst[3][cv * V + j];
+    }
+    const long long npix = (long long)N * H * W;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(npix, r0 + rows_per_block);
+    if (rl < rpp) {
+        for (long long r = r0 + rl; r < r1; r += rpp) {
+            const int ix = (int)(r % W), iy = (int)((r / W) % H), n = (int)(r / ((long long)W * H));
+            float acc[V], g[V], xv[V];
+            up_bwd_pixel<T>(dy, n, iy, ix, cv, H, W, C, sh, sw, acc);
+            alignas(16) T q[V];
+            Vec16<T>::store(q, acc);
+            *reinterpret_cast<uint4*>(dx + r * C + cv * V) = *reinterpret_cast<const uint4*>(q);
+            Vec16<T>::load(q, g);      // the stored (rounded) value: what bn_bwd_reduce_kernel would read back
+            Vec16<T>::load(x + r * C + cv * V, xv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float gg = g[j];
+                if (!(__builtin_fmaf(xv[j], ksc[j], ksh[j]) > 0.f)) gg = 0.f;
+                s1[j] += gg;
+                s2[j] += gg * (xv[j] - mu[j]) * is[j];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = tpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (rl < rpp && (tpr >= 64 || lane < tpr)) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            part[wave][cv * V + j] = s1[j];
+            part[wave][C + cv * V + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    float* dst = rows + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm
@@ -896,6 +985,37 @@ extern "C" int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W
     DISPATCH(dtype,
              GDRN_LAUNCH(upsample2x_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)dy, (float*)dx, N, H, W, C),
              GDRN_LAUNCH(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+extern "C" int gdrn_bn_relu_upsample2x_fwd(const void* x_raw, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+    if (!x_raw || !scale || !shift || !y || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
+    if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    const long long n = (long long)N * 4 * H * W * C;
+    DISPATCH(dtype,
+             GDRN_LAUNCH((upsample2x_fwd_kernel<float, true>), dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x_raw, (float*)y, N, H, W, C, scale, shift),
+             GDRN_LAUNCH((upsample2x_fwd_kernel<bf16_t, true>), dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x_raw, (bf16_t*)y, N, H, W, C, scale, shift));
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+// upsampling backward + the reduction pass of the BatchNorm(+ReLU) backward that consumes its result (gdrn_bn_bwd_reduce with the affine ReLU
+// mask), in one launch: dx (unmasked, as gdrn_upsample2x_bwd writes it) and one partial row [2][C] per workgroup of
+// (sum g, sum g * xhat), g = dx where mask_scale * x + mask_shift > 0 -- rows = gdrn_bn_bwd_reduce_rows(N*H*W, C, dtype), for gdrn_bn_bwd_coef
+extern "C" int gdrn_upsample2x_bwd_bnsums(const void* dy, void* dx, const void* x_raw, const float* mean, const float* invstd, const float* mask_scale,
+                                          const float* mask_shift, int N, int H, int W, int C, float* rows, int dtype, void* stream) {
+    if (!dy || !dx || !x_raw || !mean || !invstd || !mask_scale || !mask_shift || !rows || N <= 0 || H < 2 || W < 2 || (C % 8) || C > 512) return GDRN_ERR_ARG;
+    if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4;
+    if (256 % (C / V)) return GDRN_ERR_SHAPE;
+    int rpb, blocks;
+    bwd_reduce_grid((long long)N * H * W, C, dtype, &rpb, &blocks);
+    DISPATCH(dtype,
+             GDRN_LAUNCH(upsample2x_bwd_bnsums_kernel<float>, dim3(blocks), dim3(256), 0, ST, (const float*)dy, (float*)dx, (const float*)x_raw, mean, invstd,
+                         mask_scale, mask_shift, N, H, W, C, rows, rpb),
+             GDRN_LAUNCH(upsample2x_bwd_bnsums_kernel<bf16_t>, dim3(blocks), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)x_raw, mean, invstd,
+                         mask_scale, mask_shift, N, H, W, C, rows, rpb));
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

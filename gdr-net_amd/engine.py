@@ -118,6 +118,9 @@ class Engine:
         # settled by the A/B measurements of rounds 1-4 (their switches are gone with round 5): the last bucket's weight
         # gradients run under the stem's backward, generic weight / bias gradients go to the side stream too, a side-stream weight-gradient
         # launch asks for 84 KiB of LDS (one workgroup per CU), the 16-bit modes use the dedicated stem kernels and the split-K fc layers
+        # the head's BatchNorm + ReLU in front of an upsampling evaluated by the upsampling launch, its backward sums by the upsampling's adjoint
+        # (r6, gdrn_bn_relu_upsample2x_fwd / gdrn_upsample2x_bwd_bnsums): "0" = separate launches (A/B, the bit-equality test)
+        self.fuse_up = self.h16 and _os.environ.get("GDRN_FUSE_UP", "1") != "0"
         self.tail_overlap = True
         self.side_small = True
         self.wgrad_side_lds = 84 * 1024

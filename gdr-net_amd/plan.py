@@ -336,7 +336,7 @@ class Plan:
         e = self.e
         return e.use_halo and e.h16 and L.kind == "conv" and L.wfF is not None
 
-    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False, apply=True):
+    def _bn_bwd(self, bnkey, dy, ymask, raw, dx, g_out=None, affine_mask=False, prereduced=False, xf=False, apply=True, sums_done=False):
         """BatchNorm(+ReLU) backward: [reduce -> coef ->] apply.  prereduced: dy arrives masked and the producing data-gradient
         launch has already turned its epilogue rows into the coefficients (see _conv, bnb).
         affine_mask: BN -> ReLU without residual: the ReLU mask is recomputed from raw*scale+shift (what bn_apply
@@ -351,6 +351,11 @@ class Plan:
         if prereduced:
             self._bn_coef_op(bnkey, self.stats, 1)  # (allocates the coefficient vectors; the launch itself sits in _conv)
             msc = msh = ym = None                    # dy is already masked
+        elif sums_done:
+            # the launch that produced dy (gdrn_upsample2x_bwd_bnsums) has written the reduction's rows already; dy itself is NOT masked
+            nrows = int(lib.gdrn_bn_bwd_reduce_rows(s.npix, s.C, e.dt))
+            assert nrows > 0 and nrows * 2 * s.C <= self.stats.numel(), (bnkey, nrows)
+            ops.append(self._bn_coef_op(bnkey, self.stats, nrows))
         else:
             nrows = int(lib.gdrn_bn_bwd_reduce_rows(s.npix, s.C, e.dt))
             assert nrows > 0 and nrows * 2 * s.C <= self.stats.numel(), (bnkey, nrows)
@@ -761,18 +766,33 @@ class Plan:
         prev_bn, prev_raw = h + "1", rawt
         # pend_h: hx = relu(bn(prev_raw)) is evaluated (and written to hx) by the next head conv while it stages its patch
         pend_h = dict(x1=rawt, xf=dict(mode=1, a=self.bn[h + "1"].scale, c=self.bn[h + "1"].shift, relu=True)) if xf_first else None
+        up_next = False
         for hi, (ci, bi, up) in enumerate(HEAD_CONVS):
             Lc = e.layers[h + str(ci)]
             grp = []
+            fused_up, pre_sums = bool(up and up_next), False
             if up:
                 assert pend_h is None
                 u = E(B, 2 * Hh, 2 * Hh, 256)
                 self.tensors[h + f"{ci}.up"] = u
-                self.fwd.append(lambda st, ctx, hx=hx, u=u, Hh=Hh: check(lib.gdrn_upsample2x_fwd(ptr(hx), ptr(u), B, Hh, Hh, 256, e.dt, st), "upsample_fwd"))
+                sp_ = self.bn.get(prev_bn)
+                if fused_up:
+                    # (r6) BatchNorm + ReLU of the previous conv evaluated by the upsampling itself (its activation tensor is never stored), and
+                    # in the backward pass the upsampling's adjoint also reduces that BatchNorm's backward sums: two launches and two tensor
+                    # round trips less per upsampling
+                    self.fwd.append(lambda st, ctx, r_=prev_raw, sp_=sp_, u=u, Hh=Hh: check(
+                        lib.gdrn_bn_relu_upsample2x_fwd(ptr(r_), ptr(sp_.scale), ptr(sp_.shift), ptr(u), B, Hh, Hh, 256, e.dt, st), "bn_relu_upsample_fwd"))
+                else:
+                    self.fwd.append(lambda st, ctx, hx=hx, u=u, Hh=Hh: check(lib.gdrn_upsample2x_fwd(ptr(hx), ptr(u), B, Hh, Hh, 256, e.dt, st), "upsample_fwd"))
                 if T:
                     d_u = E(B, 2 * Hh, 2 * Hh, 256)
                     self.tensors[h + f"{ci}.d_up"] = d_u
-                    up_bwd = (lambda st, ctx, d_u=d_u, d_hx=d_hx, Hh=Hh: check(lib.gdrn_upsample2x_bwd(ptr(d_u), ptr(d_hx), B, Hh, Hh, 256, e.dt, st), "upsample_bwd"))
+                    if fused_up:
+                        up_bwd = (lambda st, ctx, d_u=d_u, d_hx=d_hx, Hh=Hh, r_=prev_raw, sp_=sp_: check(
+                            lib.gdrn_upsample2x_bwd_bnsums(ptr(d_u), ptr(d_hx), ptr(r_), ptr(sp_.mean), ptr(sp_.invstd), ptr(sp_.scale), ptr(sp_.shift), B, Hh, Hh,
+                                                           256, ptr(self.stats), e.dt, st), "upsample_bwd_bnsums"))
+                    else:
+                        up_bwd = (lambda st, ctx, d_u=d_u, d_hx=d_hx, Hh=Hh: check(lib.gdrn_upsample2x_bwd(ptr(d_u), ptr(d_hx), B, Hh, Hh, 256, e.dt, st), "upsample_bwd"))
                     d_in = d_u
                 xin, Hh = u, 2 * Hh
             else:
@@ -780,17 +800,21 @@ class Plan:
                 d_in = d_hx
                 up_bwd = None
             raw, act = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
-            self.tensors.update({h + f"{ci}.raw": raw, h + f"{ci}.act": act})
+            self.tensors[h + f"{ci}.raw"] = raw
             nxt = HEAD_CONVS[hi + 1] if hi + 1 < len(HEAD_CONVS) else None
             # this conv's BatchNorm + ReLU is applied by the next head conv on load when no upsampling sits in between
             xf_next = (not FOLD) and nxt is not None and not nxt[2] and self._xf_ok(e.layers[h + str(nxt[0])], 1, Hh)
+            # the NEXT conv sits behind an upsampling that applies this conv's BatchNorm + ReLU itself (see `fused_up` above)
+            up_next = (not FOLD) and S and e.fuse_up and nxt is not None and nxt[2] and (T or not WL)
             if FOLD:
                 self.fwd.append(self._conv_bn_eval(Lc, h + str(bi), xin, 256, act, Hh, Hh, Hh, Hh, 1, 1, relu=True))
             else:
                 op, cp = self._conv(Lc, pend_h["x1"] if pend_h else xin, 256, raw, Hh, Hh, Hh, Hh, 1, 1, stats=self.stats if S else None,
                                     xf=dict(pend_h["xf"], out=xin) if pend_h else None)
                 self.fwd.append(op)
-                self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, None if xf_next else act)
+                self.fwd += self._bn_fwd(h + str(bi), raw, cp, 256, B * Hh * Hh, None if (xf_next or up_next) else act)
+            if not up_next:
+                self.tensors[h + f"{ci}.act"] = act   # (behind a fused upsampling the activation is never stored)
             if T:
                 d_act, d_raw = E(B, Hh, Hh, 256), E(B, Hh, Hh, 256)
                 self.tensors.update({h + f"{ci}.d_act": d_act, h + f"{ci}.d_raw": d_raw})
@@ -799,11 +823,12 @@ class Plan:
                 pre = (not nxt[2] and self._fusable(e.layers[h + str(nxt[0])])) if nxt is not None else e.gemm_bnb  # (last conv: the 1x1 output conv's data gradient)
                 xfb = self._xf_ok(Lc, 3 if pre else 4, Hh)  # this BN's backward apply inside Lc's data-gradient launch (mode 3, or 4 = with the ReLU mask)
                 xd = None
+                sd_ = bool(up_next and not pre)   # the fused upsampling's adjoint behind this conv has reduced this BatchNorm's backward sums
                 if xfb:
-                    ops, xd = self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre, xf=True)
+                    ops, xd = self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre, xf=True, sums_done=sd_)
                     grp += ops
                 else:
-                    grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre)
+                    grp += self._bn_bwd(h + str(bi), d_act, act, raw, d_raw, affine_mask=True, prereduced=pre, sums_done=sd_)
                 grp.append(self._wgrad(Lc, xin, d_raw, Hh, Hh, Hh, Hh, 1, 1, 256, 256, 256, 256))
                 grp.append(self._unpack(Lc))
                 fuse_in = (not up) and self._fusable(Lc)  # d_in is the gradient w.r.t. the previous BN+ReLU's output

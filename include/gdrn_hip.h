@@ -340,6 +340,14 @@ int gdrn_maxpool_bwd(const void* dy, const unsigned char* idx, const void* x, co
 /* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), cdpn_rot_head_region.py:102 */
 int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int gdrn_upsample2x_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, void* stream);
+/* (ABI 4) BatchNorm + ReLU + 2x bilinear upsampling in one launch: y = upsample2x(relu(scale * x_raw + shift)), every source value rounded to the
+ * storage format first (= gdrn_bn_apply followed by gdrn_upsample2x_fwd, bit for bit; cdpn_rot_head_region.py:103-123). */
+int gdrn_bn_relu_upsample2x_fwd(const void* x_raw, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int dtype, void* stream);
+/* (ABI 4) gdrn_upsample2x_bwd + the reduction pass of the BatchNorm(+ReLU) backward that reads its result (gdrn_bn_bwd_reduce with the affine mask
+ * mask_scale * x_raw + mask_shift > 0) in one launch: dx as gdrn_upsample2x_bwd writes it (unmasked), rows [gdrn_bn_bwd_reduce_rows(N*H*W, C,
+ * dtype)][2][C] for gdrn_bn_bwd_coef. */
+int gdrn_upsample2x_bwd_bnsums(const void* dy, void* dx, const void* x_raw, const float* mean, const float* invstd, const float* mask_scale,
+                               const float* mask_shift, int N, int H, int W, int C, float* rows, int dtype, void* stream);
 
 /* nn.GroupNorm(G, C) + ReLU (conv_pnp_net.py:78-80) and backward.  dgamma/dbeta: fp32 [C], accumulated
  * over samples (zeroed inside). */

@@ -602,6 +602,49 @@ def test_conv3x3_wgrad_grouped(H, variant, grid):
         assert torch.isfinite(g).all() and H.rel(g, r) < 1e-2
 
 
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bn_relu_upsample_fused_equals_the_two_launch_path_bit_for_bit(H, dt):
+    """r6: gdrn_bn_relu_upsample2x_fwd == gdrn_bn_apply (ReLU) followed by gdrn_upsample2x_fwd, bit for bit (the fused launch rounds every
+    source value to the storage format exactly where the stored activation would have been rounded); and gdrn_upsample2x_bwd_bnsums ==
+    gdrn_upsample2x_bwd followed by gdrn_bn_bwd_reduce (affine ReLU mask): dx bit for bit, the partial rows bit for bit (same workgroup
+    geometry, same order of additions) -- cdpn_rot_head_region.py:103-123 (BatchNorm -> ReLU -> UpsamplingBilinear2d) and its backward."""
+    lib = cabi.load(BF16)
+    dev = H.DEV
+    N, Hh, C_ = 3, 8, 256
+    raw = H.nhwc(H.rounded(H.randn(300, N, C_, Hh, Hh) * 1.5, dt), dt)
+    g = torch.Generator().manual_seed(7)
+    scale = (0.5 + torch.rand(C_, generator=g)).to(dev)
+    shift = (torch.rand(C_, generator=g) - 0.5).to(dev)
+    mean = (torch.rand(C_, generator=g) - 0.5).to(dev)
+    invstd = (0.5 + torch.rand(C_, generator=g)).to(dev)
+    npix = N * Hh * Hh
+    st = H.stream()
+    act = torch.empty_like(raw)
+    check(lib.gdrn_bn_apply(ptr(raw), ptr(scale), ptr(shift), None, ptr(act), npix, C_, 1, dt, st), "bn_apply")
+    u_ref = torch.empty(N, 2 * Hh, 2 * Hh, C_, dtype=raw.dtype, device=dev)
+    check(lib.gdrn_upsample2x_fwd(ptr(act), ptr(u_ref), N, Hh, Hh, C_, dt, st), "upsample_fwd")
+    u = torch.full_like(u_ref, float("nan"))
+    check(lib.gdrn_bn_relu_upsample2x_fwd(ptr(raw), ptr(scale), ptr(shift), ptr(u), N, Hh, Hh, C_, dt, st), "bn_relu_upsample_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(u, u_ref)
+    # ... against torch on the rounded operands too
+    ref = F.interpolate(H.rounded(F.relu(H.nchw(raw) * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)), dt), scale_factor=2, mode="bilinear", align_corners=True)
+    assert H.rel(H.nchw(u), ref) < TOL[dt]
+    # backward
+    d_u = H.nhwc(H.rounded(H.randn(301, N, C_, 2 * Hh, 2 * Hh), dt), dt)
+    nrows = lib.gdrn_bn_bwd_reduce_rows(npix, C_, dt)
+    dx_ref = torch.empty_like(raw)
+    rows_ref = torch.full((nrows, 2, C_), float("nan"), device=dev)
+    check(lib.gdrn_upsample2x_bwd(ptr(d_u), ptr(dx_ref), N, Hh, Hh, C_, dt, st), "upsample_bwd")
+    check(lib.gdrn_bn_bwd_reduce(ptr(dx_ref), None, ptr(raw), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), npix, C_, ptr(rows_ref), dt, st), "bn_bwd_reduce")
+    dx = torch.full_like(raw, float("nan"))
+    rows = torch.full((nrows, 2, C_), float("nan"), device=dev)
+    check(lib.gdrn_upsample2x_bwd_bnsums(ptr(d_u), ptr(dx), ptr(raw), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), N, Hh, Hh, C_, ptr(rows), dt, st), "upsample_bwd_bnsums")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    assert torch.equal(rows, rows_ref), H.rel(rows, rows_ref)
+
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])
