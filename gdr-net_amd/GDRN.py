@@ -681,6 +681,9 @@ class GDRN(nn.Module):
     def _maps(self, plan, B):
         """mask / coor_x / coor_y / coor_z / region as NCHW fp32 (GDRN.py:235-237)."""
         e, lib = plan.e, plan.e.lib
+        if not getattr(plan, "head_valid", True):
+            raise cabi.GdrnHipError("the head logits of this forward pass were not written (inference without cfg.TEST.USE_PNP hands the fused head "
+                                    "kernel head = NULL): plan.head_out holds an earlier call's values")
         st = e._stream()
         C_ = e.head_c
         full = torch.empty(B, C_, 64, 64, dtype=torch.float32, device=e.dev)

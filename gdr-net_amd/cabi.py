@@ -131,7 +131,6 @@ _SIGS = {
     "gdrn_conv3x3_wgrad_splits": [C.POINTER(WgradParams)],
     "gdrn_conv3x3_wgrad_multi": [P, P, I, I, P],
     "gdrn_conv3x3_wgrad_multi_lds": [P, P, I, I, I, P],
-    "gdrn_conv3x3_wgrad_multi_w128": [P, P, I, I, I, P],
     "gdrn_wgrad_reduce_multi": [P, P, I, I, P],
     "gdrn_pack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, I, P],
     "gdrn_unpack4": [P, P, I, I, I, I, I, I, I, LL, LL, LL, LL, I, P],
@@ -153,6 +152,8 @@ _SIGS = {
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_bwd": [P, P, I, I, I, I, I, P],
+    "gdrn_block64_eval_ok": [I, I, I, I],
+    "gdrn_block64_eval": [P, P, P, P, P, P, I, I, I, I, P],
     "gdrn_bn_relu_upsample2x_fwd": [P, P, P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_bwd_bnsums": [P, P, P, P, P, P, P, I, I, I, I, P, I, P],
     "gdrn_gn_relu_fwd": [P, P, P, P, P, I, I, I, I, F, I, P],

@@ -48,10 +48,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // hipGetLastError() says behind it -- and that call ALSO returns (and clears) an error some earlier HIP call of this host thread left behind,
 // the host framework's included (a pointer-attribute probe on a host pointer, a failed attribute query of another library, ...): r5's smoke run
 // reported "launch failure" for the first launch of a process that way.  The stale error is not this library's: drop it before the launch.
-#define GDRN_LAUNCH(...)                  \
-    do {                                  \
-        (void)hipGetLastError();          \
-        hipLaunchKernelGGL(__VA_ARGS__);  \
+// (the dropped code is kept -- gdrn_tls_stale_hip_error, reported by gdrn_last_hip_error as "stale:<name>" -- instead of vanishing, and
+//  every launch starts with a clean slot for its own status, so an old failure cannot be attached to a later, unrelated one)
+extern thread_local int gdrn_tls_stale_hip_error;
+#define GDRN_LAUNCH(...)                                             \
+    do {                                                             \
+        const hipError_t stale__ = hipGetLastError();                \
+        if (stale__ != hipSuccess) gdrn_tls_stale_hip_error = (int)stale__; \
+        gdrn_tls_hip_error = 0;                                      \
+        hipLaunchKernelGGL(__VA_ARGS__);                             \
     } while (0)
 
 // (the HIP error code behind the most recent GDRN_ERR_LAUNCH of this host thread, for the caller's error message: gdrn_last_hip_error)

@@ -692,9 +692,9 @@ int launch_v3(const gdrn_conv_params& p, int N, hipStream_t st) {
 
 template <int XF>
 int launch_v3_cfg(const gdrn_conv_params& p, int cfg, int N, hipStream_t st) {
+    // (the four-wave bring-up forms of the two tiles -- <16,256,2,2,1>, <8,128,2,2,1>: ten instantiations per library, unreachable from
+    //  gdrn_v3_config -- are gone with round 6)
     if (cfg == 1) return launch_v3<16, 256, 2, 4, 1, XF>(p, N, st);
-    if (cfg == 3) return launch_v3<16, 256, 2, 2, 1, XF>(p, N, st);   // 4 waves, one per SIMD, 128 x 128 wave tiles
-    if (cfg == 4) return launch_v3<8, 128, 2, 2, 1, XF>(p, N, st);    // 4 waves, one per SIMD, 64 x 64 wave tiles
     return launch_v3<8, 128, 2, 2, 2, XF>(p, N, st);
 }
 
@@ -707,16 +707,14 @@ int gdrn_v3_config(const gdrn_conv_params* p) {
     if (p->dtype != GDRN_DT_H16 || (p->Cin & 63) || p->Cin < 64 || (p->Cout & 127) || (p->Wo & 15) || (p->Ho & 7)) return 0;
     if (p->act > 1 || p->out_f32) return 0;
     const int N = p->M / (p->Ho * p->Wo);
-    constexpr int f_big = 1, f_small = 2;   // (configurations 3 / 4 -- four-wave forms of the two tiles -- were bring-up variants; launch_v3_cfg keeps them)
+    constexpr int f_big = 1, f_small = 2;
     // 256-channel tile when the grid still has at least one workgroup per CU: the patch (+ transform) is staged once per pixel tile
     // (p->v3_min_wg > 0 lowers the threshold: the tests exercise the 256-channel tile on small grids with it)
     const long long min_wg = p->v3_min_wg > 0 ? p->v3_min_wg : 256;
     if ((p->Cout & 255) == 0 && (p->Ho & 15) == 0 && !p->addend && !p->bnb_mask && (long long)N * (p->Ho / 16) * (p->Wo / 16) * (p->Cout / 256) >= min_wg) {
         // LDS of the 16x16x256 tile: two patches + ring + raw staging (one or two inputs) + the transform's per-channel table
         const size_t need = (p->xf_mode >= 2 ? V3<16, 256, 2, 4, 1, 2>::OFF_TAB : V3<16, 256, 2, 4, 1, 0>::OFF_TAB) + (size_t)xf_nk(p->xf_mode) * p->Cin * sizeof(float);
-        if (need > 160 * 1024) return f_small;
-        if (f_big == 1 || f_big == 3) return f_big;
-        return f_small;
+        return need > 160 * 1024 ? f_small : f_big;
     }
     return f_small;
 }
@@ -729,14 +727,14 @@ int gdrn_v3_preferred(const gdrn_conv_params* p) {
     const int cfg = gdrn_v3_config(p);
     // (the K-split tile's isolated x1.07-1.11 on the 256-channel 16x16 maps did not survive in the step: with the addend / stored-mask
     //  epilogue of the BasicBlock data gradients it ran 39 us against 32 us, +0.2 ms per step -- it is not preferred anywhere)
-    return (cfg == 1 || cfg == 3) && p->xf_mode != 0;
+    return cfg == 1 && p->xf_mode != 0;
 }
 
 int gdrn_v3_tile(const gdrn_conv_params* p, int* th, int* tw, int* bn) {
     const int cfg = gdrn_v3_config(p);
-    *th = (cfg == 1 || cfg == 3) ? 16 : (cfg ? 8 : 0);
+    *th = cfg == 1 ? 16 : (cfg ? 8 : 0);
     *tw = cfg ? 16 : 0;
-    *bn = (cfg == 1 || cfg == 3) ? 256 : (cfg ? 128 : 0);
+    *bn = cfg == 1 ? 256 : (cfg ? 128 : 0);
     return cfg;
 }
 
@@ -758,7 +756,7 @@ int gdrn_v3_launch(const gdrn_conv_params* pp, void* stream) {
     const gdrn_conv_params& p = *pp;
     const int cfg = gdrn_v3_config(pp);
     if (cfg == 0) return GDRN_ERR_SHAPE;
-    const int bn = (cfg == 1 || cfg == 3) ? 256 : 128;
+    const int bn = cfg == 1 ? 256 : 128;
     if ((p.x_cs & 7) || (p.y_cs & 7) || (p.addend && (p.add_cs & 7)) || (p.bnb_x && (p.bnb_cs & 7))) return GDRN_ERR_SHAPE;  // 16-byte accesses
     if (p.w_rows < p.Cout || (p.w_rows & 63) || (p.Cout % bn)) return GDRN_ERR_SHAPE;
     const int hw = p.Ho * p.Wo;

@@ -62,9 +62,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // one workgroup: tile `bid % ntile`, pixel-range split `bid / ntile` of the layer described by p.  NA = 16-channel output fragments per
-// wave = the workgroup tile's output channels / 16: 4 (64 x 64 tile, 144 accumulator registers, two workgroups per CU) or 8 (128 x 64 tile,
-// 288 accumulator registers: one wave per SIMD with the accumulators in the AGPR half of the register file; every transposed X fragment
-// feeds 8 MFMAs instead of 4 -- 34 instead of 2 x 52 transposed LDS reads per 144 MFMAs -- and the X patch is staged once per 128 channels)
+// wave = the workgroup tile's output channels / 16 = 4 (64 x 64 tile, 144 accumulator registers, two workgroups per CU)
 template <int S, int NA>
 __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, int npatch, int nsplit, unsigned char* smem) {
     using G_ = Geo<S>;
@@ -74,7 +72,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     constexpr int NDL = G_::ND * NA / 4;           // dY granules per thread and stage
     constexpr int DPSTEP = 256 / DSEGS;            // pixels between a thread's dY granules (a multiple of the patch width 8)
     static_assert(NPIX * XP <= XB, "X patch fits its LDS slot");
-    static_assert(NA == 4 || NA == 8, "64- or 128-channel tile");
+    static_assert(NA == 4, "64 x 64 workgroup tile (the 128 x 64 form of rounds 4-5 -- NA = 8, accumulators named in the AGPRs -- was removed in round 6)");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int g = lane >> 4, q = lane & 15;
@@ -165,20 +163,11 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     // wave tile: ALL 64 output channels (4 fragments) x 16 input channels (wave w: ci block w).  The X fragments are re-read for
     // every tap (9 x 2 k-steps), the dY fragments once per k-step: a 64 x 16 wave tile needs 16 + 36 = 52 transposed LDS reads per
     // stage where the 32 x 32 one needed 8 + 72 = 80, for the same 72 MFMAs
-    // NA = 8: 128 x 16 per wave, 8 + 8 + 18 = 34 reads for 144 MFMAs.  Its 72 accumulator tuples: taps 0..7 are the 256 AGPRs, named
-    // literally (tuple t*8 + a = a[4*(t*8+a) .. +3]) -- as C++ values hipcc gives the loop-carried accumulators VGPR homes and copies all
-    // of them into and out of the AGPRs every stage -- and tap 8's eight tuples are ordinary VGPR values.  Nothing else of this kernel
-    // may live in an AGPR: the build asserts that the compiler emitted no v_accvgpr_* of its own and spilled nothing (tools/check_isa.py)
     f32x4_t acc[9][NA];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int a = 0; a < NA; ++a) acc[t][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if constexpr (NA == 8) {
-        asm volatile("v_accvgpr_write_b32 a0, 0" ::: "a0", "a255");   // the clobbers make the kernel descriptor cover all 256 AGPRs
-#pragma unroll
-        for (int i = 1; i < 256; ++i) asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(i));
-    }
     (void)wa; (void)wb;
 
     // transpose-read lane bases.  k (pixel) map of one 32-pixel k-step (4 image rows x 8): read r of lane group g
@@ -233,16 +222,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                if constexpr (NA == 4) {
-                    acc[j % 9][a] = GDRN_MFMA16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a]);
-                } else if (j % 9 < 8) {
-                    asm volatile(GDRN_MFMA16_ASM " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]),
-                                 "i"(4 * ((j % 9) * 8 + a)), "i"(4 * ((j % 9) * 8 + a) + 3));
-                } else {
-                    asm volatile(GDRN_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc[j % 9][a]) : "v"(fa[j / 9][a]), "v"(fb[j % (RD + 1)]));
-                }
-            }
+            for (int a = 0; a < NA; ++a) acc[j % 9][a] = GDRN_MFMA16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a]);
             // next patch: one address piece + its loads per group (same scheduling region as the MFMAs above)
             if (j == 0) LDD()
             if (j == 1) LDX(0, x0)
@@ -265,22 +245,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
 #undef STX
 #undef WRITE_PATCH
 
-    // accumulator tuple (t, a) -> registers: for the 128-channel tile taps 0..7 are read out of the AGPRs one tuple at a time, right in
-    // front of their store (a block of 256 reads would need 256 VGPRs at once)
-    auto tuple = [&](auto T_, auto A_) -> f32x4_t {
-        constexpr int t = decltype(T_)::value, a = decltype(A_)::value;
-        if constexpr (NA == 8 && t < 8) {
-            float r0, r1, r2, r3;
-            asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
-                         : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)
-                         : "i"(4 * (t * 8 + a)), "i"(4 * (t * 8 + a) + 1), "i"(4 * (t * 8 + a) + 2), "i"(4 * (t * 8 + a) + 3));
-            return f32x4_t{r0, r1, r2, r3};
-        } else {
-            return acc[t][a];
-        }
-    };
-    // the last MFMAs have to leave the matrix pipe before their AGPRs are read (the compiler pads nothing around asm statements)
-    if constexpr (NA == 8) asm volatile("s_nop 15\n\ts_nop 15");
+    auto tuple = [&](auto T_, auto A_) -> f32x4_t { return acc[decltype(T_)::value][decltype(A_)::value]; };
     if (p.ws != nullptr) {
         // workspace order (read by wgrad_reduce_multi): per 64 x 64 tile [36 fragments (t, a', b')][4 tile quadrants (wa', wb')][64 lanes][4]
         // with the 16 x 16 block (co16 = wa'*2 + a', ci16 = wb'*2 + b'): this wave holds co16 = a (0..3), ci16 = wave.  A 128-channel
@@ -344,38 +309,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const gdrn_
     else wgrad_tile<1, 4>(p, bid - blk_start[lo], npatch, p.splits, smem);
 }
 
-__device__ __forceinline__ void w128_logical_block(const gdrn_wgrad_params* __restrict__ tasks, const int* __restrict__ blk_start, int ntasks,
-                                                   int bid, unsigned char* smem) {
-    int lo = 0, hi = ntasks;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (blk_start[mid] <= bid) lo = mid; else hi = mid;
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    const gdrn_wgrad_params p = tasks[lo];
-    const int npatch = wgrad_npatch(p);
-    if (p.stride == 2) wgrad_tile<2, 8>(p, bid - blk_start[lo], npatch, p.splits, smem);
-    else wgrad_tile<1, 8>(p, bid - blk_start[lo], npatch, p.splits, smem);
-}
-
-// The same grouped launch on 128(co) x 64(ci) workgroup tiles (layers with Cout % 128 == 0): one workgroup = one wave per SIMD with the
-// whole register file (288 accumulator registers per lane), blk_start counts (Cout/128)*(Cin/64)*splits workgroups per task.
-// The grid may be SMALLER than the table's blk_start[ntasks] logical workgroups: a resident workgroup then walks the logical ids blockIdx.x,
-// blockIdx.x + gridDim.x, ... -- a launch of G workgroups keeps G compute units and leaves the others to another stream's kernels (this
-// kernel shares a CU with nothing: its four waves own the register file).
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_w128_multi_kernel(const gdrn_wgrad_params* __restrict__ tasks,
-                                                                         const int* __restrict__ blk_start, int ntasks) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nlog = blk_start[ntasks];
-    for (int lb = blockIdx.x; lb < nlog; lb += gridDim.x) w128_logical_block(tasks, blk_start, ntasks, xcd_remap(lb, nlog), smem);
-}
-
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_w128_kernel(const gdrn_wgrad_params p, int npatch, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (p.stride == 2) wgrad_tile<2, 8>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
-    else wgrad_tile<1, 8>(p, xcd_remap(blockIdx.x, gridDim.x), npatch, nsplit, smem);
-}
-
 // Sum the workspace partials of one 16(co) x 16(ci) x 9(tap) unit per workgroup and write it in the parameter's layout
 // (for OIHW gradients 16 runs of 144 contiguous floats); LDS turns fragment order into that layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const gdrn_wreduce_task* __restrict__ tasks,
@@ -431,14 +364,14 @@ extern "C" int gdrn_conv3x3_wgrad_ok(const gdrn_wgrad_params* p) {
     if (!(p->dtype == GDRN_DT_H16 && p->KH == 3 && p->KW == 3 && p->pad == 1 && (p->Cin % 64) == 0 && (p->Cout % 64) == 0 &&
           (p->x_cs % 8) == 0 && (p->dy_cs % 8) == 0 && (p->Wo % 8) == 0))
         return 0;
-    if (p->variant != 0 && !(p->variant == GDRN_WGRAD_W128 && (p->Cout % 128) == 0)) return 0;
+    if (p->variant != 0) return 0;   // (GDRN_WGRAD_W128, the 128 x 64 tile of rounds 4-5, is gone: r6)
     if (p->stride == 1) return p->Hi == p->Ho && p->Wi == p->Wo && (p->Ho % 8) == 0;
     if (p->stride == 2) return p->Hi == 2 * p->Ho && p->Wi == 2 * p->Wo && (p->Ho % 4) == 0;
     return 0;
 }
 
-// workgroup tiles of a layer: 64 x 64, or 128(co) x 64(ci) for variant GDRN_WGRAD_W128
-static inline int wgrad_tiles(const gdrn_wgrad_params& p) { return (p.Cout / (p.variant == GDRN_WGRAD_W128 ? 128 : 64)) * (p.Cin / 64); }
+// workgroup tiles of a layer (64 x 64)
+static inline int wgrad_tiles(const gdrn_wgrad_params& p) { return (p.Cout / 64) * (p.Cin / 64); }
 
 // number of pixel-range splits the launcher uses for these params (p->splits <= 0: automatic); the workspace of the
 // p->ws path holds splits * Cout * Cin * 9 floats
@@ -451,7 +384,7 @@ extern "C" int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* pp) {
     const int tiles = wgrad_tiles(p);
     int splits = p.splits;
     // one partial tile per workgroup either way: target one workgroup per CU (two when the partials are plain stores and two fit a CU)
-    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(p.ws && p.variant == 0 ? 512 : 256, tiles)));
+    if (splits <= 0) splits = std::max(1, std::min(npatch / 4 > 0 ? npatch / 4 : 1, cdiv(p.ws ? 512 : 256, tiles)));
     splits = std::min(splits, npatch);
     const int per = cdiv(npatch, splits);
     return cdiv(npatch, per);  // no empty split: every workspace slab gets written
@@ -467,18 +400,6 @@ extern "C" int gdrn_conv3x3_wgrad(const gdrn_wgrad_params* pp, void* stream) {
     const int tiles = wgrad_tiles(p);
     const int splits = gdrn_conv3x3_wgrad_splits(pp);
     if (splits <= 0) return GDRN_ERR_SHAPE;
-    if (p.variant == GDRN_WGRAD_W128) {
-        constexpr size_t smem = 2 * (size_t)stage_bytes<8>();
-        static std::once_flag once;
-        static hipError_t attr_err = hipSuccess;
-        std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_w128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        });
-        if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
-        GDRN_LAUNCH(conv3x3_wgrad_w128_kernel, dim3(tiles * splits), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), p, npatch, splits);
-        GDRN_CHECK_LAUNCH();
-        return GDRN_OK;
-    }
     constexpr size_t smem = 2 * (size_t)stage_bytes<4>();
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -520,26 +441,6 @@ extern "C" int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, 
 
 extern "C" int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {
     return gdrn_conv3x3_wgrad_multi_lds(tasks_dev, blk_start_dev, ntasks, nblocks, 0, stream);
-}
-
-// Grouped launch on the 128 x 64 tiles (every task variant GDRN_WGRAD_W128): nblocks = blk_start[ntasks] logical workgroups walked by
-// `grid` resident ones (grid <= 0 or > nblocks: nblocks; rounded down to a multiple of 8 so that a resident workgroup stays on its XCD's ids)
-extern "C" int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int grid,
-                                             void* stream) {
-    if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;
-    constexpr size_t smem = 2 * (size_t)stage_bytes<8>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_w128_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    });
-    if (attr_err != hipSuccess) return GDRN_ERR_LAUNCH;
-    if (grid <= 0 || grid > nblocks) grid = nblocks;
-    if (grid < nblocks && grid >= 8) grid &= ~7;
-    GDRN_LAUNCH(conv3x3_wgrad_w128_multi_kernel, dim3(grid), dim3(256), smem, reinterpret_cast<hipStream_t>(stream), tasks_dev, blk_start_dev,
-                       ntasks);
-    GDRN_CHECK_LAUNCH();
-    return GDRN_OK;
 }
 
 extern "C" int gdrn_wgrad_reduce_multi(const gdrn_wreduce_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream) {

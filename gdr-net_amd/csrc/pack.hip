@@ -154,12 +154,22 @@ inline int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<lo
 extern "C" int gdrn_version(void) { return GDRN_ABI_VERSION; }
 
 thread_local int gdrn_tls_hip_error = 0;
+thread_local int gdrn_tls_stale_hip_error = 0;
+// returns AND clears the calling thread's launch-error slot (a code is reported once, with the failure it belongs to).  Without a launch error:
+// 0, and `name` says "hipSuccess" -- or "stale:<name>" when a launch of this thread found (and dropped) an error some earlier HIP call had left
+// behind (GDRN_LAUNCH): not this library's failure, but worth a line in a debug log; that slot is cleared too.
 extern "C" int gdrn_last_hip_error(char* name, int cap) {
-    const int e = gdrn_tls_hip_error;
+    const int e = gdrn_tls_hip_error, stale = gdrn_tls_stale_hip_error;
+    gdrn_tls_hip_error = 0;
+    gdrn_tls_stale_hip_error = 0;
     if (name && cap > 0) {
-        const char* s = hipGetErrorName((hipError_t)e);
         int i = 0;
-        for (; s && s[i] && i < cap - 1; ++i) name[i] = s[i];
+        if (e == 0 && stale != 0) {
+            const char* pre = "stale:";
+            for (; pre[i] && i < cap - 1; ++i) name[i] = pre[i];
+        }
+        const char* s = hipGetErrorName((hipError_t)(e ? e : stale));
+        for (int k = 0; s && s[k] && i < cap - 1; ++k, ++i) name[i] = s[k];
         name[i] = 0;
     }
     return e;

@@ -121,6 +121,8 @@ class Engine:
         # the head's BatchNorm + ReLU in front of an upsampling evaluated by the upsampling launch, its backward sums by the upsampling's adjoint
         # (r6, gdrn_bn_relu_upsample2x_fwd / gdrn_upsample2x_bwd_bnsums): "0" = separate launches (A/B, the bit-equality test)
         self.fuse_up = self.h16 and _os.environ.get("GDRN_FUSE_UP", "1") != "0"
+        # eval mode: a 64-channel BasicBlock (layer1) as one launch, its intermediate in LDS (r6, gdrn_block64_eval); "0" = two halo launches
+        self.block64 = self.h16 and _os.environ.get("GDRN_BLOCK64", "1") != "0"
         self.tail_overlap = True
         self.side_small = True
         self.wgrad_side_lds = 84 * 1024

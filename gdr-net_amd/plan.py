@@ -51,6 +51,7 @@ class Plan:
         self.tensors = {}          # name -> activation / gradient buffer (inspection by the tests)
         self._zero_regions = []    # fp32 tensors the backward accumulates into with atomics: cleared by ONE gdrn_zero_multi launch
         self.generation = 0        # bumped by every run_forward: a backward checks its activations are still the plan's
+        self.head_valid = True     # plan.head_out holds the logits of the last forward (False: inference without cfg.TEST.USE_PNP skipped them)
         self.grad_group = {}       # parameter name -> forward index of the backward group that completes its gradient
         self._build()
         if self.has_backward:
@@ -630,6 +631,23 @@ class Plan:
                 npo = B * Ho * Ho
                 raw1, a1, raw2, out = E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl), E(B, Ho, Ho, pl)
                 self.tensors.update({pfx + ".raw1": raw1, pfx + ".a1": a1, pfx + ".raw2": raw2, pfx + ".out": out})
+                if FOLD and e.block64 and Ld is None and inpl == 64 and pl == 64 and e.use_halo and B >= e.halo_min_b and L1.wfF is not None \
+                        and L1.wfmt.get("e", 1) == 1 and L2.wfmt.get("e", 1) == 1 and int(lib.gdrn_block64_eval_ok(B, Hc, Hc, e.dt)):
+                    # eval, 64 channels (layer1): the whole BasicBlock as ONE launch, the intermediate in LDS (r6, csrc/block64.hip)
+                    f1, f2 = e.fold(pfx + ".bn1", L1), e.fold(pfx + ".bn2", L2)
+                    L1.wfmt["e"] = L2.wfmt["e"] = 1   # (fragment-major layout of the first halo kernel: what gdrn_block64_eval reads)
+                    if not self._fold_hooked:
+                        self.eval_prep.append(lambda st, ctx: self.e.eval_refresh())
+                        self._fold_hooked = True
+
+                    def blk(st, ctx, x=x, out=out, L1=L1, L2=L2, f1=f1, f2=f2, Hc=Hc):
+                        check(lib.gdrn_block64_eval(ptr(x), ptr(L1.wfF_e), ptr(f1.shift), ptr(L2.wfF_e), ptr(f2.shift), ptr(out), B, Hc, Hc, e.dt, st), "block64_eval")
+
+                    blk.meta = dict(kernel="block64_eval_kernel", flops=2.0 * 2 * B * Hc * Hc * 64 * 64 * 9, layer=pfx + ".conv1+conv2")
+                    self.fwd.append(blk)
+                    del self.tensors[pfx + ".raw1"], self.tensors[pfx + ".a1"], self.tensors[pfx + ".raw2"]
+                    x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
+                    continue
                 if FOLD:  # eval: three (four) launches per block, no BatchNorm passes
                     self.fwd.append(self._conv_bn_eval(L1, pfx + ".bn1", x, inpl, a1, Hc, Hc, Ho, Ho, stride, 1, relu=True))
                     res = x
@@ -873,6 +891,8 @@ class Plan:
         elif fused_tail:
             def head_conv_tail(st, ctx, hx=hx):
                 # ctx["want_maps"] False (GDRN.forward without cfg.TEST.USE_PNP): nobody reads the logits -- head = NULL saves their 75 MB at bs = 64
+                # (head_valid: does plan.head_out hold THIS forward's logits?  readers -- GDRN._maps, tools -- assert it: ADVICE r5)
+                self.head_valid = bool(ctx.get("want_maps", True))
                 check(lib.gdrn_head_conv_tail_fwd(ptr(hx), 256, ptr(LO.wf), LO.rows_f, ptr(bias_o), ctx["coord2d"], ctx["extents"],
                                                   ptr(self.head_out) if ctx.get("want_maps", True) else None, self.hs,
                                                   ptr(self.pnp_in), 128, B, 4096, nreg, e.dt | PREZEROED, st), "head_conv_tail_fwd")

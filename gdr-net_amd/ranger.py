@@ -85,7 +85,8 @@ class Ranger(Optimizer):
     def load_state_dict(self, state_dict):
         self._dyn = None  # the next step_dyn re-bases the device's step index on the loaded counters
         super().load_state_dict(state_dict)
-        self._buckets_poisoned = False   # (see step_buckets_abort)
+        # (an aborted per-bucket step -- step_buckets_abort -- left some buckets' PARAMETERS one step ahead too: reloading the optimizer alone does
+        #  not make the pair consistent, so the flag stays until the caller says both were restored: reset_after_abort())
         self.__dict__.pop("_multi_cache", None)   # the task tables hold the old state tensors' addresses
 
     def _init_state(self, p):
@@ -145,9 +146,7 @@ class Ranger(Optimizer):
                 return False
             plan.append((gi, group, items, states))
         lib = cabi.load()
-        if getattr(self, "_buckets_poisoned", False):
-            raise cabi.GdrnHipError("a per-bucket optimizer step was aborted after some buckets had been updated: parameters and moments of those "
-                                    "buckets are one step ahead of the rest -- reload the optimizer / model state before training on")
+        self._check_not_poisoned()
         self._bucket_launches = [[] for _ in range(nbuckets)]
         self._bucket_done = 0
         self._bucket_params = []
@@ -190,6 +189,16 @@ class Ranger(Optimizer):
         for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
             hook(self, (), {})
 
+    def reset_after_abort(self):
+        """the caller has restored BOTH the model's parameters and this optimizer's state (load_state_dict on each) after an aborted per-bucket
+        step: stepping is allowed again"""
+        self._buckets_poisoned = False
+
+    def _check_not_poisoned(self):
+        if getattr(self, "_buckets_poisoned", False):
+            raise cabi.GdrnHipError("a per-bucket optimizer step was aborted after some buckets had been updated: parameters and moments of those "
+                                    "buckets are one step ahead of the rest -- reload the model AND the optimizer state, then optimizer.reset_after_abort()")
+
     def step_buckets_abort(self):
         """the backward pass raised before every bucket went out: forget the prepared launches; the step counters never moved.  If no bucket
         had been updated yet the optimizer is exactly where it was (a retry is a clean step).  Otherwise some buckets' parameters and moments
@@ -199,7 +208,7 @@ class Ranger(Optimizer):
             self._buckets_poisoned = True
         self._bucket_launches, self._bucket_params, self._bucket_states = [], [], []
         for hook in list(getattr(self, "_optimizer_step_post_hooks", {}).values()) + list(_global_post_hooks()):
-            hook(self, (), {})
+            hook(self, (), {"aborted": True})   # (the partner of the pre-hook; the marker tells a step-counting hook that no step completed)
 
     # ---- fp16 arithmetic mode with the dynamic loss scale on the device (r6): no host read between the backward pass and the update
     @torch.no_grad()
@@ -264,6 +273,7 @@ class Ranger(Optimizer):
         engine's flat gradient buffer directly instead of ``p.grad``).  One multi-tensor launch per param group
         when every tensor of the group is at the same step count (the normal case); per-tensor launches otherwise.
         grad_scale: factor applied to every gradient inside the kernel (1/world_size after a SUM all-reduce)."""
+        self._check_not_poisoned()   # (a plain step on top of a half-applied per-bucket step would train on inconsistent buckets: ADVICE r5)
         self._leave_dyn()
         lib = cabi.load()
         for gi, group in enumerate(self.param_groups):

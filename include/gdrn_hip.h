@@ -30,7 +30,9 @@ extern "C" {
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
 /* 3: gdrn_conv_params grew halo_waves (appended; zero = the behaviour of version 2). */
 /* 4: entry points added (nothing changed): gdrn_loss_scale_state + gdrn_ranger_multi_dyn / gdrn_loss_scale_update / gdrn_unscale_or_zero /
- *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device. */
+ *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval.
+ *    Removed: gdrn_conv3x3_wgrad_multi_w128 and gdrn_wgrad_params.variant = GDRN_WGRAD_W128 (the 128 x 64 weight-gradient tile of rounds 4-5:
+ *    never faster inside the step). */
 #define GDRN_ABI_VERSION 4
 /* `dtype` arguments.  The 16-bit format is a property of the library build: libgdrn_hip.so computes GDRN_DT_BF16, libgdrn_hip_f16.so (the same
  * sources compiled with -DGDRN_HALF_F16: v_mfma_f32_*_f16, IEEE-half storage -- the arithmetic of the reference's fp16 autocast,
@@ -42,11 +44,13 @@ enum { GDRN_OK = 0, GDRN_ERR_ARG = -1, GDRN_ERR_SHAPE = -2, GDRN_ERR_LAUNCH = -3
 /* deprecated aliases of ABI version 1 */
 enum { GDRN_F32 = GDRN_DT_F32, GDRN_BF16 = GDRN_DT_BF16, GDRN_E_ARG = GDRN_ERR_ARG, GDRN_E_SHAPE = GDRN_ERR_SHAPE, GDRN_E_LAUNCH = GDRN_ERR_LAUNCH };
 /* gdrn_wgrad_params.variant */
-enum { GDRN_WGRAD_T64 = 0, GDRN_WGRAD_W128 = 1 };
+enum { GDRN_WGRAD_T64 = 0, GDRN_WGRAD_W128 = 1 /* removed in ABI 4: rejected by gdrn_conv3x3_wgrad_ok */ };
 
 int gdrn_version(void);
 /* Diagnostics: the HIP error code (hipError_t) behind the calling thread's most recent GDRN_ERR_LAUNCH, its name copied into `name` (cap bytes,
- * may be NULL); 0 if no launch of this thread has failed.  (ABI 3) */
+ * may be NULL); 0 if no launch of this thread has failed.  (ABI 3)  The call CLEARS the slot (ABI 4: a code is reported once, with the failure it
+ * belongs to; every launch starts with a clean slot).  Without a launch error `name` reads "hipSuccess", or "stale:<name>" when a launch of this
+ * thread found and dropped an error an earlier HIP call of the process had left behind. */
 int gdrn_last_hip_error(char* name, int cap);
 int gdrn_half_format(void);   /* GDRN_DT_BF16 or GDRN_DT_F16: the 16-bit dtype code this library build accepts */
 /* Bytes of caller-owned scratch an entry point needs for the given call (every workspace of the ABI is caller-allocated device
@@ -254,14 +258,6 @@ int gdrn_conv3x3_wgrad_splits(const gdrn_wgrad_params* p);
 int gdrn_conv3x3_wgrad_multi(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
 /* the same with an LDS request of lds_bytes (> 64 KiB: one workgroup per CU, the rest of the CU stays free for another stream's kernels) */
 int gdrn_conv3x3_wgrad_multi_lds(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int lds_bytes, void* stream);
-/* p->variant = GDRN_WGRAD_W128 (Cout a multiple of 128): 128(co) x 64(ci) workgroup tiles -- one wave per SIMD, 288 accumulator registers
- * per lane of which 256 are the AGPRs; a third of the LDS fragment reads per MFMA of the 64 x 64 tile and the X patch staged once per 128
- * output channels.  gdrn_conv3x3_wgrad / _ok / _splits honour the field; the workspace layout is the 64 x 64 tile's (a 128-channel tile is
- * stored as its two halves), so gdrn_wgrad_reduce_multi reads both kinds.  Grouped launch: every task of the table has the variant set,
- * blk_start[i] = sum_{j<i} (Cout_j/128)*(Cin_j/64)*splits_j, nblocks = blk_start[ntasks] (the kernel reads it from blk_start_dev[ntasks]);
- * grid = resident workgroups walking the nblocks logical ones (<= 0: nblocks).  A resident workgroup shares its CU with nothing, so a grid
- * below the CU count leaves the other CUs to kernels of other streams. */
-int gdrn_conv3x3_wgrad_multi_w128(const gdrn_wgrad_params* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int grid, void* stream);
 /* cin_valid: input channels the parameter really has (0 = Cin): padded operand channels are skipped */
 typedef struct gdrn_wreduce_task {
     const float* ws;
@@ -532,6 +528,15 @@ int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_de
 int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
                           float beta2, float eps, float weight_decay, int n_sma_threshold, int lookahead_k, float alpha,
                           float grad_scale, const gdrn_loss_scale_state* state, void* stream);
+
+/* (ABI 4) One 64-channel ResNet BasicBlock in EVAL mode as one launch: y = relu(conv2(relu(conv1(x) + b1)) + b2 + x), both convs 3x3 stride 1
+ * pad 1 with the BatchNorms folded into weights / biases (resnet_backbone.py:69-80 under model.eval(): ResNet-34's layer1 at inference).  x, y:
+ * [N][H][W][64] NHWC 16-bit, y != x; w1, w2: the fragment-major operands gdrn_pack_wfrag makes of the row-major [64][9][64] weights; b1, b2: fp32
+ * [64].  Bit-identical to the two gdrn_conv3x3_halo launches it replaces; the 64-channel intermediate stays in LDS.  gdrn_block64_eval_ok: 1 if
+ * the shape is covered (H % 8 == 0, W % 16 == 0). */
+int gdrn_block64_eval_ok(int N, int H, int W, int dtype);
+int gdrn_block64_eval(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int N, int H, int W, int dtype,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Inference post-processing on the device: get_out_coor + get_out_mask

@@ -616,6 +616,7 @@ def test_per_bucket_optimizer_counts_hooks_and_survives_a_failed_backward():
     from gdrnet_amd.cabi import GdrnHipError
 
     saved = opt.state_dict()
+    saved_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
     def half(ctx, on_bucket=None):
         on_bucket(0)
@@ -630,7 +631,13 @@ def test_per_bucket_optimizer_counts_hooks_and_survives_a_failed_backward():
     torch.cuda.synchronize()
     with pytest.raises(GdrnHipError, match="aborted"):
         model.train_step(batch["roi_img"], optimizer=opt, **kw)
-    opt.load_state_dict(saved)                                                              # a consistent state again
+    with pytest.raises(GdrnHipError, match="aborted"):
+        opt.step(grads={})                                                                  # (the plain step refuses too)
+    opt.load_state_dict(saved)
+    with pytest.raises(GdrnHipError, match="aborted"):                                      # the optimizer alone is not a consistent pair
+        model.train_step(batch["roi_img"], optimizer=opt, **kw)
+    model.load_state_dict(saved_model)
+    opt.reset_after_abort()                                                                 # both restored: a consistent state again
     model.train_step(batch["roi_img"], optimizer=opt, **kw)
     torch.cuda.synchronize()
 

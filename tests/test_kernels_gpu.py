@@ -229,22 +229,20 @@ def test_conv_wgrad(H, dt, case, variant):
     assert H.rel(got, w.grad) < (5e-5 if dt == F32 else 1e-2)
 
 
-W128 = 1  # GDRN_WGRAD_W128: 128 x 64 workgroup tile, accumulators in the AGPRs
+W128 = 1  # GDRN_WGRAD_W128: the 128 x 64 workgroup tile of rounds 4-5 -- removed in round 6, the library must reject it
 
 
-@pytest.mark.parametrize("variant", [0, W128])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (2, 64, 128, 24), (5, 512, 512, 8)])
 def test_conv3x3_wgrad_halo(H, case, splits, variant):
     """halo-tiled weight gradient (nine taps from one staged pixel patch) against autograd; both workgroup tiles."""
     B, I, O, Hh = case
     dt = BF16
-    if variant == W128 and O % 128:
-        wp = cabi.WgradParams()
-        wp.Hi = wp.Wi = wp.Ho = wp.Wo = Hh
-        wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype, wp.variant = I, O, I, O, 3, 3, 1, 1, B * Hh * Hh, dt, W128
-        assert cabi.load(BF16).gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0   # the wide tile needs Cout % 128 == 0
-        return
+    wpq = cabi.WgradParams()
+    wpq.Hi = wpq.Wi = wpq.Ho = wpq.Wo = Hh
+    wpq.Cin, wpq.Cout, wpq.x_cs, wpq.dy_cs, wpq.KH, wpq.KW, wpq.stride, wpq.pad, wpq.M, wpq.dtype, wpq.variant = I, O, I, O, 3, 3, 1, 1, B * Hh * Hh, dt, W128
+    assert cabi.load(BF16).gdrn_conv3x3_wgrad_ok(C.byref(wpq)) == 0   # (the wide-tile variant is gone)
     x = H.rounded(H.randn(43, B, I, Hh, Hh), dt)
     w = H.randn(44, O, I, 3, 3).requires_grad_(True)
     dy = H.rounded(H.randn(45, B, O, Hh, Hh), dt)
@@ -253,7 +251,7 @@ def test_conv3x3_wgrad_halo(H, case, splits, variant):
     assert H.rel(dw.view(O, 3, 3, I).permute(0, 3, 1, 2), w.grad) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [0, W128])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("splits", [0, 1, 5])
 @pytest.mark.parametrize("case", [(2, 64, 64, 16), (1, 128, 256, 32), (3, 256, 128, 8), (5, 512, 512, 8), (8, 64, 64, 64)])
 def test_conv3x3_wgrad_halo_workspace(H, case, splits, variant):
@@ -263,15 +261,13 @@ def test_conv3x3_wgrad_halo_workspace(H, case, splits, variant):
     x = H.rounded(H.randn(46, B, I, Hh, Hh), dt)
     w = H.randn(47, O, I, 3, 3).requires_grad_(True)
     dy = H.rounded(H.randn(48, B, O, Hh, Hh), dt)
-    if variant == W128 and O % 128:
-        pytest.skip("wide tile: Cout % 128 == 0")
     F.conv2d(x, w, None, 1, 1).backward(dy)
     grad = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hh, Hh, I, I, Hh, Hh, O, O, 3, 3, 1, 1, dt, splits=splits, halo=True, ws=True, variant=variant)
     assert torch.isfinite(grad).all()
     assert H.rel(grad, w.grad) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [0, W128])
+@pytest.mark.parametrize("variant", [0])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 @pytest.mark.parametrize("ws", [False, True])
 @pytest.mark.parametrize("case", [(2, 64, 128, 16), (3, 128, 256, 8), (2, 256, 512, 4), (1, 128, 128, 32), (5, 64, 64, 12)])
@@ -292,8 +288,6 @@ def test_conv3x3_wgrad_halo_stride2(H, case, splits, ws, variant):
         wp.Cin, wp.Cout, wp.x_cs, wp.dy_cs, wp.KH, wp.KW, wp.stride, wp.pad, wp.M, wp.dtype = I, O, I, O, 3, 3, 2, 1, B * Ho * Ho, dt
         assert cabi.load(BF16).gdrn_conv3x3_wgrad_ok(C.byref(wp)) == 0
         return
-    if variant == W128 and O % 128:
-        pytest.skip("wide tile: Cout % 128 == 0")
     got = H.conv_wgrad(H.nhwc(x, dt), H.nhwc(dy, dt), B, Hi, Hi, I, I, Ho, Ho, O, O, 3, 3, 2, 1, dt, splits=splits, halo=True, ws=ws, variant=variant)
     if not ws:
         got = got.view(O, 3, 3, I).permute(0, 3, 1, 2)
@@ -553,17 +547,15 @@ def test_bn_bwd_coef(H, nrows, C_):
     assert H.rel(o[3], s[1]) < 1e-6 and H.rel(o[4], s[0]) < 1e-6
 
 
-@pytest.mark.parametrize("variant,grid", [(0, 0), (W128, 0), (W128, 8), (W128, 21)])
+@pytest.mark.parametrize("variant,grid", [(0, 0), (0, "one-per-cu")])
 def test_conv3x3_wgrad_grouped(H, variant, grid):
-    """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer.  Wide tile: also with
-    fewer resident workgroups than logical ones (a resident workgroup walks several tiles; 21 is rounded down to 16)."""
+    """three layers of different geometry in ONE grouped launch + one reduce launch == autograd, layer by layer; "one-per-cu": the launch the
+    training step makes on its side stream (84 KiB LDS request = one workgroup per CU)."""
     from gdrnet_amd.cabi import WgradParams, WreduceTask, to_device_table
 
     lib = cabi.load(BF16)
     dt, dev = BF16, H.DEV
     cases = [(2, 64, 64, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1)]  # B, I, O, H, requested splits
-    if variant == W128:
-        cases = [(2, 64, 128, 32, 5), (3, 128, 256, 16, 2), (4, 512, 128, 8, 1), (2, 256, 512, 8, 3)]
     keep, wps, tasks, refs, grads = [], [], [], [], []
     for i, (B, I, O, Hh, sp) in enumerate(cases):
         x = H.rounded(H.randn(60 + i, B, I, Hh, Hh), dt)
@@ -588,12 +580,12 @@ def test_conv3x3_wgrad_grouped(H, variant, grid):
         tasks.append(WreduceTask(ws=ptr(ws), dst=ptr(g), nsplit=wp.splits, Cout=O, Cin=I, cin_valid=0, s_co=I * 9, s_ci=9, s_t=1))
     st1, st2 = [0], [0]
     for wp in wps:
-        st1.append(st1[-1] + (wp.Cout // (128 if variant == W128 else 64)) * (wp.Cin // 64) * wp.splits)
+        st1.append(st1[-1] + (wp.Cout // 64) * (wp.Cin // 64) * wp.splits)
         st2.append(st2[-1] + wp.Cout * wp.Cin // 256)
     tab1, tab2 = to_device_table(wps, dev), to_device_table(tasks, dev)
     s1, s2 = torch.tensor(st1, dtype=torch.int32, device=dev), torch.tensor(st2, dtype=torch.int32, device=dev)
-    if variant == W128:
-        check(lib.gdrn_conv3x3_wgrad_multi_w128(ptr(tab1), ptr(s1), len(wps), st1[-1], grid, H.stream()), "conv3x3_wgrad_multi_w128")
+    if grid == "one-per-cu":
+        check(lib.gdrn_conv3x3_wgrad_multi_lds(ptr(tab1), ptr(s1), len(wps), st1[-1], 84 * 1024, H.stream()), "conv3x3_wgrad_multi_lds")
     else:
         check(lib.gdrn_conv3x3_wgrad_multi(ptr(tab1), ptr(s1), len(wps), st1[-1], H.stream()), "conv3x3_wgrad_multi")
     check(lib.gdrn_wgrad_reduce_multi(ptr(tab2), ptr(s2), len(tasks), st2[-1], H.stream()), "wgrad_reduce_multi")
@@ -644,6 +636,43 @@ def test_bn_relu_upsample_fused_equals_the_two_launch_path_bit_for_bit(H, dt):
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref)
     assert torch.equal(rows, rows_ref), H.rel(rows, rows_ref)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64), (3, 16, 32), (1, 8, 16), (2, 24, 48)])
+def test_block64_eval_equals_two_halo_launches_bit_for_bit(H, case):
+    """r6: one 64-channel BasicBlock in eval mode as ONE launch (gdrn_block64_eval: conv1 on the 10 x 18 halo'd region, the intermediate in
+    LDS, conv2, + identity) == conv1 (bias, ReLU) -> conv2 (bias, + identity, ReLU) on the halo kernel, BIT FOR BIT (same accumulation order,
+    same roundings) -- incl. tiles on the image border (the intermediate is zero outside the image), a one-tile image and a non-square tiling;
+    and against torch on the rounded operands (resnet_backbone.py:69-80 under model.eval(): torchvision BasicBlock with folded BatchNorms)."""
+    lib = cabi.load(BF16)
+    dt = BF16
+    B, Hh, Ww = case
+    x = H.rounded(H.randn(400, B, 64, Hh, Ww), dt)
+    w1 = H.rounded(H.randn(401, 64, 64, 3, 3) / 24, dt)
+    w2 = H.rounded(H.randn(402, 64, 64, 3, 3) / 24, dt)
+    b1, b2 = H.randn(403, 64) * 0.3, H.randn(404, 64) * 0.3
+    xd = H.nhwc(x, dt)
+    wp1, wp2 = H.pack_fwd(w1, dt), H.pack_fwd(w2, dt)
+    b1d, b2d = b1.to(H.DEV), b2.to(H.DEV)
+    # two launches: first halo kernel, four waves (the 64-channel tile has no other form)
+    def halo(xin, wp, bias, addend):
+        cp_y, _ = H.conv_gemm(xin, wp, B, Hh, Ww, 64, 64, Hh, Ww, 64, 3, 3, 1, 1, dt, bias=bias, addend=addend, act=1, halo=True)
+        return cp_y
+    if Ww == Hh:   # (the helper takes square maps' geometry as Hi, Wi separately: fine for all cases)
+        pass
+    a1 = halo(xd, wp1, b1d, None)
+    y_ref = halo(a1, wp2, b2d, xd)
+    wf1, wf2 = torch.empty_like(wp1), torch.empty_like(wp2)
+    check(lib.gdrn_pack_wfrag(ptr(wp1), ptr(wf1), 64, 64, dt, H.stream()), "pack_wfrag")
+    check(lib.gdrn_pack_wfrag(ptr(wp2), ptr(wf2), 64, 64, dt, H.stream()), "pack_wfrag")
+    y = torch.full_like(xd, float("nan"))
+    assert lib.gdrn_block64_eval_ok(B, Hh, Ww, dt) == 1
+    check(lib.gdrn_block64_eval(ptr(xd), ptr(wf1), ptr(b1d), ptr(wf2), ptr(b2d), ptr(y), B, Hh, Ww, dt, H.stream()), "block64_eval")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), H.rel(y, y_ref)
+    ref = F.relu(F.conv2d(H.rounded(F.relu(F.conv2d(x, w1, b1, 1, 1)), dt), w2, b2, 1, 1) + x)
+    assert H.rel(H.nchw(y, 64), ref) < TOL[dt]
+    assert lib.gdrn_block64_eval_ok(B, 12, 16, dt) == 0 and lib.gdrn_block64_eval(ptr(xd), ptr(wf1), ptr(b1d), ptr(wf2), ptr(b2d), ptr(xd), B, Hh, Ww, dt, H.stream()) == -1
 
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
