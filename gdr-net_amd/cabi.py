@@ -51,6 +51,16 @@ class WgradParams(C.Structure):
     ]
 
 
+class S2Params(C.Structure):
+    """gdrn_s2_params: the stride-2 3x3 conv (+ fused 1x1 shortcut) of csrc/conv3x3s2.hip"""
+    _fields_ = [
+        ("x", P), ("w", P), ("y", P), ("bias", P), ("stats", P), ("wd", P), ("yd", P), ("bias_d", P), ("stats_d", P),
+        ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
+        ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("yd_cs", I),
+        ("N", I), ("w_rows", I), ("wd_rows", I), ("act", I), ("dtype", I),
+    ]
+
+
 class PoseParams(C.Structure):
     _fields_ = [
         ("fc", P), ("fs", I), ("cams", P), ("centers", P), ("whs", P), ("ratios", P), ("extents", P),
@@ -152,6 +162,9 @@ _SIGS = {
     "gdrn_maxpool_bwd": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
     "gdrn_upsample2x_fwd": [P, P, I, I, I, I, I, P],
     "gdrn_upsample2x_bwd": [P, P, I, I, I, I, I, P],
+    "gdrn_conv3x3s2_ok": [C.POINTER(S2Params)],
+    "gdrn_conv3x3s2_stats_rows": [C.POINTER(S2Params)],
+    "gdrn_conv3x3s2": [C.POINTER(S2Params), P],
     "gdrn_block64_eval_ok": [I, I, I, I],
     "gdrn_block64_eval": [P, P, P, P, P, P, I, I, I, I, P],
     "gdrn_bn_relu_upsample2x_fwd": [P, P, P, P, I, I, I, I, I, P],

@@ -123,6 +123,9 @@ class Engine:
         self.fuse_up = self.h16 and _os.environ.get("GDRN_FUSE_UP", "1") != "0"
         # eval mode: a 64-channel BasicBlock (layer1) as one launch, its intermediate in LDS (r6, gdrn_block64_eval); "0" = two halo launches
         self.block64 = self.h16 and _os.environ.get("GDRN_BLOCK64", "1") != "0"
+        # the stride-2 3x3 convs' forward pass (stage-entry conv1 + its 1x1 shortcut in one launch, Patch-PnP's convs) on the parity-plane halo
+        # kernel (r6, gdrn_conv3x3s2) where it covers the shape; "0" = the generic gather kernel
+        self.s2_halo = self.h16 and _os.environ.get("GDRN_S2_HALO", "1") != "0"
         self.tail_overlap = True
         self.side_small = True
         self.wgrad_side_lds = 84 * 1024
@@ -311,6 +314,11 @@ class Engine:
         L.wfmt = {"f": 0, "d": 0}
         if kind == "conv" and KK == 9 and not s2 and self.use_halo:  # halo-kernel operands (fragment-major)
             L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
+        elif kind == "conv" and KK == 9 and s2 and self.s2_halo:
+            # stride-2 3x3 layers (r6, csrc/conv3x3s2.hip): the FORWARD operand also in the fragment-major layout (gdrn_pack_wfrag); the data
+            # gradient stays on the generic kernel and keeps the generic-layout copies
+            L.wfF = torch.zeros_like(L.wf)
+            L.wfmt["f"] = 1
         self.layers[key] = L
         return L
 
@@ -396,7 +404,7 @@ class Engine:
             for bnkey, f in self.bn_fold.items():
                 L = f.layer
                 src = self.P[L.src[0]]
-                halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None
+                halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2
                 for dst, frag in ((L.wf_e, 0), (L.wfF_e, L.wfmt.get("e", 0) or 1)):
                     if dst is None or (halo_only and not frag):
                         continue
@@ -425,7 +433,7 @@ class Engine:
             if L.kind == "stem":
                 continue
             src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
-            halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None  # both conv passes read the fragment-major copies
+            halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2  # both conv passes read the fragment-major copies
             for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, L.wfmt["f"] or 1), ("d", L.wdF, L.wfmt["d"] or 1)):
                 if dst is None or (halo_only and not frag):
                     continue

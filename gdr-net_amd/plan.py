@@ -9,7 +9,7 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import cabi
-from .cabi import ACC_ROWS, PREZEROED, ConvParams, PoseParams, WgradParams, check, ptr
+from .cabi import ACC_ROWS, PREZEROED, ConvParams, PoseParams, S2Params, WgradParams, check, ptr
 from .engine import HEAD_CONVS, RESNET34_LAYERS, RESNET34_PLANES, _ru
 
 
@@ -94,7 +94,7 @@ class Plan:
         self.keep.append(cp)
         ref = C.byref(cp)
         halo_on = e.use_halo and self.B >= e.halo_min_b   # (fp32 parity mode: only plans of the BASELINE sizes, see Engine.__init__)
-        if halo_on and L.kind == "conv" and L.wfF is not None:
+        if halo_on and L.kind == "conv" and L.wfF is not None and not L.s2:
             which = "e" if evalw else ("f" if w is None else "d")
             # the operand's layout is a property of the LAYER, not of whichever plan happens to be built first (a bs = 4 smoke
             # plan used to pin the first halo kernel's layout for the bs = 64 training plan): the library is asked at the canonical batch
@@ -111,8 +111,8 @@ class Plan:
         # 3x3 stride-1 layers (forward and data-gradient) run on the halo-tiled kernel
         th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
         e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
-        use_halo = halo_on and th.value > 0 and L.kind == "conv" and L.wfF is not None
-        if halo_on and L.wfF is not None and not use_halo:
+        use_halo = halo_on and th.value > 0 and L.kind == "conv" and L.wfF is not None and not L.s2
+        if halo_on and L.wfF is not None and not L.s2 and not use_halo:
             raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
         if evalw:      # eval-mode operand with the BatchNorm scale folded in (Engine.fold)
             assert w is None
@@ -185,6 +185,45 @@ class Plan:
         nbytes = (self.B * Hi * Wi * cp.Cin + self.B * Ho * Wo * cp.Cout) * esz + cp.Cout * cp.Cin * cp.KH * cp.KW * esz
         run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(nbytes), layer=L.key + (":dgrad" if w is not None else ""))
         return run, cp
+
+    def _s2(self, L, x, x_cs, y, Hi, Ho, Ld=None, yd=None, stats=None, stats_d=None, bias=None, bias_d=None, act=0, evalw=False):
+        """forward launch of a 3x3 stride-2 conv on the parity-plane halo kernel (gdrn_conv3x3s2), with the block's 1x1 shortcut conv Ld in the
+        same launch when given.  Returns (op, NS(_stats_rows) of the main conv, the same for the shortcut) or None when the library does not
+        cover the shape (maps narrower than 16 pixels: the generic kernel keeps them)."""
+        e = self.e
+        if not (e.s2_halo and L.wfF is not None and L.s2):
+            return None
+        sp = S2Params()
+        sp.x, sp.y = ptr(x), ptr(y)
+        sp.w = ptr(L.wfF_e if evalw else L.wfF)
+        sp.bias, sp.stats = ptr(bias), ptr(stats)
+        if Ld is not None:
+            sp.wd, sp.yd, sp.bias_d, sp.stats_d = ptr(Ld.wf_e if evalw else Ld.wf), ptr(yd), ptr(bias_d), ptr(stats_d)
+            sp.yd_cs, sp.wd_rows = yd.shape[-1], Ld.rows_f
+            assert Ld.cin_f == L.cin_f, (L.key, Ld.key)
+        sp.Hi = sp.Wi = Hi
+        sp.Ho = sp.Wo = Ho
+        sp.Cin, sp.x_cs, sp.Cout, sp.y_cs = L.cin_f, x_cs, L.O, y.shape[-1]
+        sp.N, sp.w_rows, sp.act, sp.dtype = self.B, L.rows_f, act, e.dt
+        ref = C.byref(sp)
+        if not int(e.lib.gdrn_conv3x3s2_ok(ref)):
+            return None
+        self.keep.append(sp)
+        rows = int(e.lib.gdrn_conv3x3s2_stats_rows(ref))
+        for st_, c_ in ((stats, L.O), (stats_d, L.O)):
+            assert st_ is None or rows * 2 * c_ <= st_.numel(), (L.key, rows)
+
+        def run(st, ctx):
+            s_ = e.lib.gdrn_conv3x3s2(ref, st)
+            if s_:
+                check(s_, f"conv3x3s2 {L.key}")
+
+        macs = self.B * Ho * Ho * L.O * L.I * 9 + (self.B * Ho * Ho * Ld.O * Ld.I if Ld is not None else 0)
+        esz = 2
+        run.meta = dict(kernel=f"conv3x3s2_kernel<{'true' if Ld is not None else 'false'}>", flops=2.0 * macs,
+                        bytes=float((self.B * Hi * Hi * L.cin_f + (2 if Ld is not None else 1) * self.B * Ho * Ho * L.O) * esz + L.O * L.cin_f * 9 * esz),
+                        layer=L.key + ("+downsample" if Ld is not None else ""))
+        return run, NS(_stats_rows=rows), NS(_stats_rows=rows)
 
     def _stats_rows(self, cp):
         return cp._stats_rows
@@ -278,9 +317,10 @@ class Plan:
         self._unpack_pending.append((len(self.bwd_groups), L))
         return None  # marker, dropped when the groups are flattened
 
-    def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1):
-        """finalize (train) or eval params, then apply.  Returns list of fwd ops."""
+    def _bn_fwd(self, bnkey, raw, cp, C_, npix, y, residual=None, relu=1, stats=None):
+        """finalize (train) or eval params, then apply.  Returns list of fwd ops.  stats: the producer's partial-row scratch (default self.stats)."""
         e, lib = self.e, self.e.lib
+        stats = self.stats if stats is None else stats
         s = NS(mean=e._empty(C_, dtype=torch.float32), invstd=e._empty(C_, dtype=torch.float32),
                scale=e._empty(C_, dtype=torch.float32), shift=e._empty(C_, dtype=torch.float32), C=C_, npix=npix)
         self.bn[bnkey] = s
@@ -289,8 +329,8 @@ class Plan:
         ops = []
         if self.bn_train:
             rows = self._stats_rows(cp)
-            assert rows * 2 * C_ <= self.stats.numel(), (bnkey, rows, C_)  # the producer's partial rows fit the scratch
-            ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(self.stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
+            assert rows * 2 * C_ <= stats.numel(), (bnkey, rows, C_)  # the producer's partial rows fit the scratch
+            ops.append(lambda st, ctx: check(lib.gdrn_bn_finalize(ptr(stats), rows, C_, float(npix), ptr(g), ptr(b), ptr(rm),
                                                                   ptr(rv), ptr(nbt), 0.1, 1e-5, ptr(s.mean), ptr(s.invstd),
                                                                   ptr(s.scale), ptr(s.shift), ptr(e.bn_ws), st), "bn_finalize"))
         else:
@@ -539,6 +579,7 @@ class Plan:
         if e.stem_direct:
             n_stats = max(n_stats, int(lib.gdrn_stem_stats_rows(B)) * 128)
         self.stats = E(n_stats, dtype=F32t)
+        self.stats_b = E(B * 4096 + 4096, dtype=F32t)   # rows of a fused 1x1 shortcut conv (gdrn_conv3x3s2: <= B * 16 tiles x 2 x 128 channels)
         nreg = e.nreg
 
         # ---------------- stem
@@ -649,17 +690,38 @@ class Plan:
                     x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
                     continue
                 if FOLD:  # eval: three (four) launches per block, no BatchNorm passes
-                    self.fwd.append(self._conv_bn_eval(L1, pfx + ".bn1", x, inpl, a1, Hc, Hc, Ho, Ho, stride, 1, relu=True))
-                    res = x
-                    if Ld is not None:
+                    s2op = None
+                    if Ld is not None and e.s2_halo and L1.wfF is not None:
+                        # stage entry: conv1 (3x3 stride 2) and the 1x1 shortcut in ONE launch of the parity-plane kernel (r6), BatchNorms folded
+                        f1, fd = e.fold(pfx + ".bn1", L1), e.fold(pfx + ".downsample.1", Ld)
+                        if not self._fold_hooked:
+                            self.eval_prep.append(lambda st, ctx: self.e.eval_refresh())
+                            self._fold_hooked = True
+                        res = E(B, Ho, Ho, pl)
+                        s2op = self._s2(L1, x, inpl, a1, Hc, Ho, Ld=Ld, yd=res, bias=f1.shift, bias_d=fd.shift, act=1, evalw=True)
+                    if s2op is not None:
+                        self.fwd.append(s2op[0])
+                    else:
+                        self.fwd.append(self._conv_bn_eval(L1, pfx + ".bn1", x, inpl, a1, Hc, Hc, Ho, Ho, stride, 1, relu=True))
+                    res = x if Ld is None else (res if s2op is not None else None)
+                    if Ld is not None and s2op is None:
                         res = E(B, Ho, Ho, pl)
                         self.fwd.append(self._conv_bn_eval(Ld, pfx + ".downsample.1", x, inpl, res, Hc, Hc, Ho, Ho, stride, 0, relu=False))
                     self.fwd.append(self._conv_bn_eval(L2, pfx + ".bn2", a1, pl, out, Ho, Ho, Ho, Ho, 1, 1, relu=True, residual=res, add_cs=pl))
                     x, Hc, inpl, prev_raw2 = out, Ho, pl, raw2
                     continue
                 assert pend is None or self._xf_ok(L1)
-                op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
-                                    xf=dict(pend["xf"], out=x) if pend else None)
+                s2op = None
+                if Ld is not None and pend is None:
+                    # stage entry (r6): conv1 (3x3 stride 2) and the 1x1 shortcut conv in ONE launch of the parity-plane kernel, each with its
+                    # own BatchNorm-statistics rows
+                    rawd_ = E(B, Ho, Ho, pl)
+                    s2op = self._s2(L1, x, inpl, raw1, Hc, Ho, Ld=Ld, yd=rawd_, stats=self.stats if S else None, stats_d=self.stats_b if S else None)
+                if s2op is not None:
+                    op, cp, cpd_s2 = s2op
+                else:
+                    op, cp = self._conv(L1, pend["x1"] if pend else x, inpl, raw1, Hc, Hc, Ho, Ho, stride, 1, stats=self.stats if S else None,
+                                        xf=dict(pend["xf"], out=x) if pend else None)
                 self.fwd.append(op)
                 xf1 = self._xf_ok(L2, 1, Ho)  # bn1 + ReLU applied by conv2 on load (which also writes a1 for the weight gradient)
                 self.fwd += self._bn_fwd(pfx + ".bn1", raw1, cp, pl, npo, None if xf1 else a1)
@@ -671,14 +733,17 @@ class Plan:
                 nxt1 = e.layers.get(f"backbone.layer{li}.{b + 1}.conv1")
                 xf_out = nxt1 is not None and self._xf_ok(nxt1, 2, Ho)
                 if Ld is not None:
-                    rawd, idn = E(B, Ho, Ho, pl), (None if xf_out else E(B, Ho, Ho, pl))
+                    rawd, idn = (rawd_ if s2op is not None else E(B, Ho, Ho, pl)), (None if xf_out else E(B, Ho, Ho, pl))
                     self.tensors[pfx + ".rawd"] = rawd
                     if idn is not None:
                         self.tensors[pfx + ".idn"] = idn
                     self.fwd += self._bn_fwd(pfx + ".bn2", raw2, cp, pl, npo, None)
-                    op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
-                    self.fwd.append(op)
-                    self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd, pl, npo, idn, relu=0)
+                    if s2op is not None:   # (the shortcut conv ran with conv1: only its BatchNorm's finalize is left, from its own rows)
+                        self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd_s2, pl, npo, idn, relu=0, stats=self.stats_b)
+                    else:
+                        op, cpd = self._conv(Ld, x, inpl, rawd, Hc, Hc, Ho, Ho, stride, 0, stats=self.stats if S else None)
+                        self.fwd.append(op)
+                        self.fwd += self._bn_fwd(pfx + ".downsample.1", rawd, cpd, pl, npo, idn, relu=0)
                     s2, sd = self.bn[pfx + ".bn2"], self.bn[pfx + ".downsample.1"]
                     if xf_out:   # relu(scale2*raw2 + scale_d*rawd + shift2 + shift_d)
                         nxt_pend = dict(x1=raw2, xf=dict(mode=2, x2=rawd, a=s2.scale, b=sd.scale, c=s2.shift, c2=sd.shift, relu=True))
@@ -965,7 +1030,11 @@ class Plan:
             r, gact = E(B, Ho, Ho, 128), E(B, Ho, Ho, 128)
             mr = E(B, 32, 2, dtype=F32t)
             self.tensors.update({q + f"{ci}.raw": r, q + f"{ci}.act": gact})
-            op, _ = self._conv(Lc, px, cin, r, Hp, Hp, Ho, Ho, 2, 1, cin=cin, cout=128)
+            s2op = self._s2(Lc, px, cin, r, Hp, Ho) if cin == Lc.cin_f else None   # (r6: the parity-plane kernel on the 64 -> 32 and 32 -> 16 convs)
+            if s2op is not None:
+                op = s2op[0]
+            else:
+                op, _ = self._conv(Lc, px, cin, r, Hp, Hp, Ho, Ho, 2, 1, cin=cin, cout=128)
             self.fwd.append(op)
             gam, bet = e.P[q + f"{gi}.weight"], e.P[q + f"{gi}.bias"]
             self.fwd.append(lambda st, ctx, r=r, gam=gam, bet=bet, gact=gact, mr=mr, Ho=Ho: check(

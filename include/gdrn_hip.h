@@ -30,7 +30,7 @@ extern "C" {
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
 /* 3: gdrn_conv_params grew halo_waves (appended; zero = the behaviour of version 2). */
 /* 4: entry points added (nothing changed): gdrn_loss_scale_state + gdrn_ranger_multi_dyn / gdrn_loss_scale_update / gdrn_unscale_or_zero /
- *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval.
+ *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval; gdrn_conv3x3s2 (+ gdrn_s2_params).
  *    Removed: gdrn_conv3x3_wgrad_multi_w128 and gdrn_wgrad_params.variant = GDRN_WGRAD_W128 (the 128 x 64 weight-gradient tile of rounds 4-5:
  *    never faster inside the step). */
 #define GDRN_ABI_VERSION 4
@@ -528,6 +528,31 @@ int gdrn_ranger_multi(const gdrn_ranger_task* tasks_dev, const int* row_start_de
 int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_start_dev, int ntasks, int total_rows, float beta1,
                           float beta2, float eps, float weight_decay, int n_sma_threshold, int lookahead_k, float alpha,
                           float grad_scale, const gdrn_loss_scale_state* state, void* stream);
+
+/* (ABI 4) 3x3 STRIDE-2 pad-1 conv, forward, on a halo-tiled MFMA kernel (csrc/conv3x3s2.hip): ResNet-34's three stage-entry convs
+ * (resnet_backbone.py:69-80, torchvision BasicBlock stride 2) and Patch-PnP's stride-2 convs (conv_pnp_net.py:76-92) -- optionally with the block's
+ * 1x1 stride-2 shortcut conv (`downsample.0`) evaluated in the same launch from the same staged input (wd / yd / stats_d / bias_d).
+ *   x [N][Hi][Wi][x_cs], y [N][Ho][Wo][y_cs], yd [N][Ho][Wo][yd_cs]: NHWC 16-bit; Hi = 2 Ho, Wi = 2 Wo, Ho % 4 == 0, Wo % 16 == 0, Cin % 64 == 0,
+ *   Cout % 128 == 0.  w: the FRAGMENT-MAJOR operand gdrn_pack_wfrag makes of the row-major [w_rows][9][Cin] weights; wd: ROW-MAJOR [wd_rows][Cin].
+ *   stats / stats_d (nullable): [gdrn_conv3x3s2_stats_rows][2][Cout] partial sums for gdrn_bn_finalize; bias / bias_d (nullable) fp32 [Cout];
+ *   act: 0 none, 1 ReLU (main conv only; the shortcut branch has none). */
+typedef struct gdrn_s2_params {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    float* stats;
+    const void* wd;
+    void* yd;
+    const float* bias_d;
+    float* stats_d;
+    int Hi, Wi, Cin, x_cs;
+    int Ho, Wo, Cout, y_cs, yd_cs;
+    int N, w_rows, wd_rows, act, dtype;
+} gdrn_s2_params;
+int gdrn_conv3x3s2_ok(const gdrn_s2_params* p);
+int gdrn_conv3x3s2_stats_rows(const gdrn_s2_params* p);
+int gdrn_conv3x3s2(const gdrn_s2_params* p, void* stream);
 
 /* (ABI 4) One 64-channel ResNet BasicBlock in EVAL mode as one launch: y = relu(conv2(relu(conv1(x) + b1)) + b2 + x), both convs 3x3 stride 1
  * pad 1 with the BatchNorms folded into weights / biases (resnet_backbone.py:69-80 under model.eval(): ResNet-34's layer1 at inference).  x, y:

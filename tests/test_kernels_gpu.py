@@ -674,6 +674,70 @@ def test_block64_eval_equals_two_halo_launches_bit_for_bit(H, case):
     assert H.rel(H.nchw(y, 64), ref) < TOL[dt]
     assert lib.gdrn_block64_eval_ok(B, 12, 16, dt) == 0 and lib.gdrn_block64_eval(ptr(xd), ptr(wf1), ptr(b1d), ptr(wf2), ptr(b2d), ptr(xd), B, Hh, Ww, dt, H.stream()) == -1
 
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 32, True), (3, 128, 256, 16, True), (2, 128, 128, 32, False), (1, 128, 128, 16, False), (2, 256, 512, 16, True)])
+def test_conv3x3_stride2_parity_plane_kernel(H, case):
+    """r6: gdrn_conv3x3s2 -- 3x3 stride-2 pad-1 forward conv on the parity-plane halo kernel, with the block's 1x1 stride-2 shortcut conv in the
+    same launch (ds), per-tile BatchNorm-statistics rows for both, and the eval-mode epilogue (bias, ReLU on the main conv only) -- against
+    torch on the rounded operands (resnet_backbone.py:69-80 stage-entry blocks; conv_pnp_net.py:76-92).  case = (B, Cin, Cout, Hout, ds)."""
+    from gdrnet_amd.cabi import S2Params
+
+    lib = cabi.load(BF16)
+    dt, dev = BF16, H.DEV
+    B, I, O, Ho, ds = case
+    Hi = 2 * Ho
+    x = H.rounded(H.randn(500, B, I, Hi, Hi), dt)
+    w = H.rounded(H.randn(501, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    wd = H.rounded(H.randn(502, O, I, 1, 1) / math.sqrt(I), dt)
+    xd = H.nhwc(x, dt)
+    wp = H.pack_fwd(w, dt)
+    wf = torch.empty_like(wp)
+    check(lib.gdrn_pack_wfrag(ptr(wp), ptr(wf), wp.shape[0], I, dt, H.stream()), "pack_wfrag")
+    wdp = H.pack_fwd(wd, dt)          # [rows][1][Cin] row-major
+    ref, refd = F.conv2d(x, w, None, 2, 1), F.conv2d(x, wd, None, 2, 0)
+    for mode in ("train", "eval"):
+        sp = S2Params()
+        y = torch.full((B, Ho, Ho, O), float("nan"), dtype=xd.dtype, device=dev)
+        yd = torch.full((B, Ho, Ho, O), float("nan"), dtype=xd.dtype, device=dev)
+        sp.x, sp.w, sp.y = ptr(xd), ptr(wf), ptr(y)
+        sp.Hi = sp.Wi = Hi
+        sp.Ho = sp.Wo = Ho
+        sp.Cin, sp.x_cs, sp.Cout, sp.y_cs, sp.yd_cs = I, I, O, O, O
+        sp.N, sp.w_rows, sp.wd_rows, sp.dtype = B, wp.shape[0], wdp.shape[0], dt
+        if ds:
+            sp.wd, sp.yd = ptr(wdp), ptr(yd)
+        assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 1
+        rows = lib.gdrn_conv3x3s2_stats_rows(C.byref(sp))
+        assert rows == B * (Ho // 4) * (Ho // 16)
+        st1 = torch.full((rows, 2, O), float("nan"), device=dev)
+        st2 = torch.full((rows, 2, O), float("nan"), device=dev)
+        bias, bias_d = H.randn(503, O).to(dev), H.randn(504, O).to(dev)
+        if mode == "train":
+            sp.stats = ptr(st1)
+            if ds:
+                sp.stats_d = ptr(st2)
+        else:
+            sp.bias, sp.act = ptr(bias), 1
+            if ds:
+                sp.bias_d = ptr(bias_d)
+        check(lib.gdrn_conv3x3s2(C.byref(sp), H.stream()), "conv3x3s2")
+        torch.cuda.synchronize()
+        if mode == "train":
+            assert H.rel(H.nchw(y, O), ref) < TOL[dt]
+            s_ = st1.sum(0).cpu()
+            assert H.rel(s_[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dt] and H.rel(s_[1], (ref ** 2).sum((0, 2, 3))) < 1e-3
+            if ds:
+                assert H.rel(H.nchw(yd, O), refd) < TOL[dt]
+                s_ = st2.sum(0).cpu()
+                assert H.rel(s_[0], refd.sum((0, 2, 3))) < 1e-3 + TOL[dt] and H.rel(s_[1], (refd ** 2).sum((0, 2, 3))) < 1e-3
+        else:
+            assert H.rel(H.nchw(y, O), F.relu(ref + bias.cpu().view(1, -1, 1, 1))) < TOL[dt]
+            if ds:
+                assert H.rel(H.nchw(yd, O), refd + bias_d.cpu().view(1, -1, 1, 1)) < TOL[dt]
+    sp.Wo = sp.Ho = 8
+    sp.Hi = sp.Wi = 16
+    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # maps narrower than 16 pixels stay on the generic kernel
+
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])
