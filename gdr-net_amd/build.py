@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "lib", "libgdrn_hip.so")
 LIB_F16 = os.path.join(HERE, "lib", "libgdrn_hip_f16.so")   # the same sources with -DGDRN_HALF_F16 (csrc/common.h)
-SOURCES = ["conv_gemm.hip", "conv3x3_halo.hip", "block64.hip", "conv3x3s2.hip", "conv3x3_v3.hip", "conv_wgrad.hip", "conv3x3_wgrad.hip", "norm.hip", "head_pose_loss.hip", "pack.hip", "multi.hip", "fc.hip", "postproc.hip", "stem.hip", "roi.hip", "workspace.hip"]
+SOURCES = ["conv_gemm.hip", "conv3x3_halo.hip", "block64.hip", "conv3x3s2.hip", "conv3x3s2_dgrad.hip", "conv3x3_v3.hip", "conv_wgrad.hip", "conv3x3_wgrad.hip", "norm.hip", "head_pose_loss.hip", "pack.hip", "multi.hip", "fc.hip", "postproc.hip", "stem.hip", "roi.hip", "workspace.hip"]
 
 
 def _hipcc():

@@ -61,6 +61,17 @@ class S2Params(C.Structure):
     ]
 
 
+class S2dParams(C.Structure):
+    """gdrn_s2d_params: data gradient of the stride-2 3x3 conv (+ the shortcut's, + BatchNorm-backward epilogue) of csrc/conv3x3s2_dgrad.hip"""
+    _fields_ = [
+        ("dy", P), ("w", P), ("dx", P), ("dyd", P), ("wdd", P), ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_rows", P),
+        ("bnb_cs", I),
+        ("Hi", I), ("Wi", I), ("Cin", I), ("dx_cs", I),
+        ("Ho", I), ("Wo", I), ("Cout", I), ("dy_cs", I), ("dyd_cs", I),
+        ("N", I), ("w_rows", I), ("wdd_rows", I), ("dtype", I),
+    ]
+
+
 class PoseParams(C.Structure):
     _fields_ = [
         ("fc", P), ("fs", I), ("cams", P), ("centers", P), ("whs", P), ("ratios", P), ("extents", P),
@@ -165,6 +176,9 @@ _SIGS = {
     "gdrn_conv3x3s2_ok": [C.POINTER(S2Params)],
     "gdrn_conv3x3s2_stats_rows": [C.POINTER(S2Params)],
     "gdrn_conv3x3s2": [C.POINTER(S2Params), P],
+    "gdrn_conv3x3s2_dgrad_ok": [C.POINTER(S2dParams)],
+    "gdrn_conv3x3s2_dgrad_rows": [C.POINTER(S2dParams)],
+    "gdrn_conv3x3s2_dgrad": [C.POINTER(S2dParams), P],
     "gdrn_block64_eval_ok": [I, I, I, I],
     "gdrn_block64_eval": [P, P, P, P, P, P, I, I, I, I, P],
     "gdrn_bn_relu_upsample2x_fwd": [P, P, P, P, I, I, I, I, I, P],

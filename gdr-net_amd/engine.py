@@ -315,10 +315,11 @@ class Engine:
         if kind == "conv" and KK == 9 and not s2 and self.use_halo:  # halo-kernel operands (fragment-major)
             L.wfF, L.wdF = torch.zeros_like(L.wf), torch.zeros_like(L.wd)
         elif kind == "conv" and KK == 9 and s2 and self.s2_halo:
-            # stride-2 3x3 layers (r6, csrc/conv3x3s2.hip): the FORWARD operand also in the fragment-major layout (gdrn_pack_wfrag); the data
-            # gradient stays on the generic kernel and keeps the generic-layout copies
+            # stride-2 3x3 layers (r6, csrc/conv3x3s2.hip, conv3x3s2_dgrad.hip): both operands also in the fragment-major layout (gdrn_pack_wfrag);
+            # the generic-layout copies stay (maps narrower than 16 pixels keep the generic kernel)
             L.wfF = torch.zeros_like(L.wf)
-            L.wfmt["f"] = 1
+            L.wdF = torch.zeros_like(L.wd)   # ... and the data-gradient operand (taps not flipped) for gdrn_conv3x3s2_dgrad
+            L.wfmt["f"] = L.wfmt["d"] = 1
         self.layers[key] = L
         return L
 

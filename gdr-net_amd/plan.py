@@ -9,7 +9,7 @@ from types import SimpleNamespace as NS
 import torch
 
 from . import cabi
-from .cabi import ACC_ROWS, PREZEROED, ConvParams, PoseParams, S2Params, WgradParams, check, ptr
+from .cabi import ACC_ROWS, PREZEROED, ConvParams, PoseParams, S2Params, S2dParams, WgradParams, check, ptr
 from .engine import HEAD_CONVS, RESNET34_LAYERS, RESNET34_PLANES, _ru
 
 
@@ -224,6 +224,54 @@ class Plan:
                         bytes=float((self.B * Hi * Hi * L.cin_f + (2 if Ld is not None else 1) * self.B * Ho * Ho * L.O) * esz + L.O * L.cin_f * 9 * esz),
                         layer=L.key + ("+downsample" if Ld is not None else ""))
         return run, NS(_stats_rows=rows), NS(_stats_rows=rows)
+
+    def _s2d(self, L, dy, dx, Ho, Hi, cin, Ld=None, dyd=None, bnb=None):
+        """data-gradient launch of a 3x3 stride-2 conv on gdrn_conv3x3s2_dgrad: dx [B, Hi, Hi, cin] from dy [B, Ho, Ho, L.O]; Ld / dyd: the block's
+        1x1 shortcut conv and ITS output gradient, added in the same launch; bnb = (bn key, raw input of that BatchNorm, stored activation): dx is
+        the gradient w.r.t. that BatchNorm(+ReLU)'s output -- masked, its backward sums reduced in the epilogue, and the coefficient launch
+        appended (as _conv does for its bnb).  None when the library does not cover the shape."""
+        e = self.e
+        if not (e.s2_halo and getattr(L, "wdF", None) is not None and L.s2):
+            return None
+        sp = S2dParams()
+        sp.dy, sp.w, sp.dx = ptr(dy), ptr(L.wdF), ptr(dx)
+        if Ld is not None:
+            sp.dyd, sp.wdd, sp.dyd_cs, sp.wdd_rows = ptr(dyd), ptr(Ld.wd), dyd.shape[-1], Ld.rows_d
+            assert Ld.cin_d == L.cin_d, (L.key, Ld.key)
+        if bnb is not None:
+            bkey, braw, bmask = bnb
+            sb = self.bn[bkey]
+            sp.bnb_x, sp.bnb_mask, sp.bnb_mean, sp.bnb_invstd, sp.bnb_rows, sp.bnb_cs = ptr(braw), ptr(bmask), ptr(sb.mean), ptr(sb.invstd), ptr(self.stats), braw.shape[-1]
+        sp.Hi = sp.Wi = Hi
+        sp.Ho = sp.Wo = Ho
+        sp.Cin, sp.dx_cs, sp.Cout, sp.dy_cs = cin, dx.shape[-1], L.cin_d, dy.shape[-1]
+        sp.N, sp.w_rows, sp.dtype = self.B, L.rows_d, e.dt
+        ref = C.byref(sp)
+        if not int(e.lib.gdrn_conv3x3s2_dgrad_ok(ref)):
+            return None
+        self.keep.append(sp)
+
+        def conv_only(st, ctx):
+            s_ = e.lib.gdrn_conv3x3s2_dgrad(ref, st)
+            if s_:
+                check(s_, f"conv3x3s2_dgrad {L.key}")
+
+        run = conv_only
+        if bnb is not None:
+            nrows = int(e.lib.gdrn_conv3x3s2_dgrad_rows(ref))
+            assert nrows * 2 * cin <= self.stats.numel(), (L.key, nrows)
+            coef = self._bn_coef_op(bnb[0], self.stats, nrows)
+
+            def run(st, ctx):
+                conv_only(st, ctx)
+                coef(st, ctx)
+
+            run.parts = (conv_only, coef)
+        macs = self.B * Ho * Ho * L.O * L.I * 9 + (self.B * Ho * Ho * Ld.O * Ld.I if Ld is not None else 0)
+        run.meta = dict(kernel=f"conv3x3s2_dgrad_kernel<{'true' if Ld is not None else 'false'},{'true' if bnb is not None else 'false'}>", flops=2.0 * macs,
+                        bytes=float((self.B * Hi * Hi * cin + (2 if Ld is not None else 1) * self.B * Ho * Ho * L.cin_d) * 2 + L.cin_d * cin * 9 * 2),
+                        layer=L.key + ":dgrad" + ("+downsample:dgrad" if Ld is not None else ""))
+        return run
 
     def _stats_rows(self, cp):
         return cp._stats_rows
@@ -800,13 +848,20 @@ class Plan:
                         grp += self._bn_bwd(pfx + ".downsample.1", g2, None, rawd, d_rawd)
                         grp.append(self._wgrad(Ld, x, d_rawd, Hc, Hc, Ho, Ho, stride, 0, inpl, pl, inpl, pl))
                         grp.append(self._unpack(Ld))
-                        op, _ = self._conv(Ld, d_rawd, pl, d_xd, Ho, Ho, Hc, Hc, 2, 0, mode=1, w=Ld.wd, rows=Ld.rows_d, cin=Ld.cin_d, cout=inpl)
-                        grp.append(op)
-                        # d_x = gradient w.r.t. the previous layer's last block output (mask = x): its bn2 backward is reduced here
-                        op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 2, 1, mode=1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d,
-                                           cout=inpl, addend=d_xd, add_cs=inpl,
-                                           bnb=(f"backbone.layer{li - 1}.{RESNET34_LAYERS[li - 2] - 1}.bn2", prev_raw2, x, False) if e.gemm_bnb else None)
-                        grp.append(op)
+                        pbn = f"backbone.layer{li - 1}.{RESNET34_LAYERS[li - 2] - 1}.bn2"
+                        # (r6) conv1's data gradient, the shortcut conv's data gradient and the previous block's ReLU mask + bn2-backward sums as
+                        # ONE launch of the parity-class kernel: no d_xd tensor (three quarters zeros), no addend pass
+                        s2d = self._s2d(L1, d_raw1, d_x, Ho, Hc, inpl, Ld=Ld, dyd=d_rawd, bnb=(pbn, prev_raw2, x)) if e.gemm_bnb else None
+                        if s2d is not None:
+                            grp.append(s2d)
+                            del self.tensors[pfx + ".d_xd"]
+                        else:
+                            op, _ = self._conv(Ld, d_rawd, pl, d_xd, Ho, Ho, Hc, Hc, 2, 0, mode=1, w=Ld.wd, rows=Ld.rows_d, cin=Ld.cin_d, cout=inpl)
+                            grp.append(op)
+                            # d_x = gradient w.r.t. the previous layer's last block output (mask = x): its bn2 backward is reduced here
+                            op, _ = self._conv(L1, d_raw1, pl, d_x, Ho, Ho, Hc, Hc, 2, 1, mode=1, w=L1.wd, rows=L1.rows_d, cin=L1.cin_d,
+                                               cout=inpl, addend=d_xd, add_cs=inpl, bnb=(pbn, prev_raw2, x, False) if e.gemm_bnb else None)
+                            grp.append(op)
                     elif need_dx:
                         # previous block of the same layer: d_x is the gradient w.r.t. its output (mask = x, stored) and
                         # feeds its bn2 backward (raw input prev_raw2)
@@ -1050,7 +1105,9 @@ class Plan:
                 self._zero_regions += [self._grad16(dgam), self._grad16(dbet)]
                 grp.append(self._wgrad(Lc, px, d_r, Hp, Hp, Ho, Ho, 2, 1, cin, 128, cin, 128))
                 grp.append(self._unpack(Lc))
-                op, _ = self._conv(Lc, d_r, 128, d_px, Ho, Ho, Hp, Hp, 2, 1, mode=1, w=Lc.wd, rows=Lc.rows_d, cin=128, cout=cin)
+                op = self._s2d(Lc, d_r, d_px, Ho, Hp, cin) if cin == Lc.cin_f else None   # (r6: the parity-class kernel where it covers the map)
+                if op is None:
+                    op, _ = self._conv(Lc, d_r, 128, d_px, Ho, Ho, Hp, Hp, 2, 1, mode=1, w=Lc.wd, rows=Lc.rows_d, cin=128, cout=cin)
                 grp.append(op)
                 self.bwd_groups.append(grp)
                 d_px = d_g

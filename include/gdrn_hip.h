@@ -30,7 +30,7 @@ extern "C" {
  *    gdrn_conv_params.pad0_ became w_frag (values outside 0..2 are rejected), gdrn_wgrad_params.variant is honoured (GDRN_WGRAD_W128). */
 /* 3: gdrn_conv_params grew halo_waves (appended; zero = the behaviour of version 2). */
 /* 4: entry points added (nothing changed): gdrn_loss_scale_state + gdrn_ranger_multi_dyn / gdrn_loss_scale_update / gdrn_unscale_or_zero /
- *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval; gdrn_conv3x3s2 (+ gdrn_s2_params).
+ *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval; gdrn_conv3x3s2 / gdrn_conv3x3s2_dgrad (+ gdrn_s2_params, gdrn_s2d_params).
  *    Removed: gdrn_conv3x3_wgrad_multi_w128 and gdrn_wgrad_params.variant = GDRN_WGRAD_W128 (the 128 x 64 weight-gradient tile of rounds 4-5:
  *    never faster inside the step). */
 #define GDRN_ABI_VERSION 4
@@ -553,6 +553,32 @@ typedef struct gdrn_s2_params {
 int gdrn_conv3x3s2_ok(const gdrn_s2_params* p);
 int gdrn_conv3x3s2_stats_rows(const gdrn_s2_params* p);
 int gdrn_conv3x3s2(const gdrn_s2_params* p, void* stream);
+
+/* (ABI 4) ... and its DATA GRADIENT (csrc/conv3x3s2_dgrad.hip; autograd backward of those convs, engine.py:279): dx [N][Hi][Wi][dx_cs] (Cin
+ * channels) from dy [N][Ho][Wo][dy_cs] (Cout channels); w = the fragment-major operand gdrn_pack_wfrag makes of the row-major data-gradient
+ * operand [w_rows >= Cin][9 taps, NOT flipped][Cout].  Optional: dyd / wdd -- the output gradient of the block's 1x1 stride-2 shortcut and its
+ * ROW-MAJOR operand [wdd_rows >= Cin][Cout], whose data gradient is added in the same launch (even / even input pixels); bnb_* -- dx is the gradient
+ * w.r.t. a BatchNorm(+ReLU)'s output: masked where the stored activation bnb_mask <= 0, and rows [gdrn_conv3x3s2_dgrad_rows][2][Cin] of
+ * (sum g, sum g * (bnb_x - mean) * invstd) for gdrn_bn_bwd_coef.  Ho % 4 == 0, Wo % 16 == 0, Cin % 64 == 0, Cout % 64 == 0. */
+typedef struct gdrn_s2d_params {
+    const void* dy;
+    const void* w;
+    void* dx;
+    const void* dyd;
+    const void* wdd;
+    const void* bnb_x;
+    const void* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    float* bnb_rows;
+    int bnb_cs;
+    int Hi, Wi, Cin, dx_cs;
+    int Ho, Wo, Cout, dy_cs, dyd_cs;
+    int N, w_rows, wdd_rows, dtype;
+} gdrn_s2d_params;
+int gdrn_conv3x3s2_dgrad_ok(const gdrn_s2d_params* p);
+int gdrn_conv3x3s2_dgrad_rows(const gdrn_s2d_params* p);
+int gdrn_conv3x3s2_dgrad(const gdrn_s2d_params* p, void* stream);
 
 /* (ABI 4) One 64-channel ResNet BasicBlock in EVAL mode as one launch: y = relu(conv2(relu(conv1(x) + b1)) + b2 + x), both convs 3x3 stride 1
  * pad 1 with the BatchNorms folded into weights / biases (resnet_backbone.py:69-80 under model.eval(): ResNet-34's layer1 at inference).  x, y:

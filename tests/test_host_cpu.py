@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
     txt = open(os.path.join(ROOT, "include", "gdrn_hip.h")).read()
     for cname, cls in (("gdrn_conv_params", cabi.ConvParams), ("gdrn_wgrad_params", cabi.WgradParams), ("gdrn_pose_params", cabi.PoseParams),
                        ("gdrn_pack_task", cabi.PackTask), ("gdrn_ranger_task", cabi.RangerTask), ("gdrn_wreduce_task", cabi.WreduceTask),
-                       ("gdrn_roi_task", cabi.RoiTask), ("gdrn_s2_params", cabi.S2Params)):
+                       ("gdrn_roi_task", cabi.RoiTask), ("gdrn_s2_params", cabi.S2Params), ("gdrn_s2d_params", cabi.S2dParams)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):

@@ -738,6 +738,65 @@ def test_conv3x3_stride2_parity_plane_kernel(H, case):
     sp.Hi = sp.Wi = 16
     assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # maps narrower than 16 pixels stay on the generic kernel
 
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 32, True, True), (3, 128, 256, 16, True, True), (2, 128, 128, 32, False, False), (1, 128, 128, 16, False, False),
+                                  (2, 64, 128, 16, False, True), (2, 128, 256, 32, True, False)])
+def test_conv3x3_stride2_dgrad_parity_class_kernel(H, case):
+    """r6: gdrn_conv3x3s2_dgrad -- data gradient of the 3x3 stride-2 conv (four parity classes of input pixels, 1 / 2 / 2 / 4 taps), with the 1x1
+    stride-2 shortcut's data gradient added in the same launch (ds) and the ReLU mask + BatchNorm-backward sums of the BatchNorm whose output
+    the gradient belongs to in the epilogue (bnb) -- against autograd on the rounded operands.  case = (B, Cin, Cout, Hout, ds, bnb)."""
+    from gdrnet_amd.cabi import S2dParams
+
+    lib = cabi.load(BF16)
+    dt, dev = BF16, H.DEV
+    B, I, O, Ho, ds, bnb = case
+    Hi = 2 * Ho
+    x = H.rounded(H.randn(600, B, I, Hi, Hi), dt).requires_grad_(True)
+    w = H.rounded(H.randn(601, O, I, 3, 3) / math.sqrt(O * 9), dt)
+    wd = H.rounded(H.randn(602, O, I, 1, 1) / math.sqrt(O), dt)
+    dy = H.rounded(H.randn(603, B, O, Ho, Ho), dt)
+    dyd = H.rounded(H.randn(604, B, O, Ho, Ho), dt)
+    tot = (F.conv2d(x, w, None, 2, 1) * dy).sum() + ((F.conv2d(x, wd, None, 2, 0) * dyd).sum() if ds else 0.0)
+    tot.backward()
+    ref = x.grad
+    wdp = H.pack_dgrad(w, dt, flip=0)            # [rows >= I][9][O]
+    wdf = torch.empty_like(wdp)
+    check(lib.gdrn_pack_wfrag(ptr(wdp), ptr(wdf), wdp.shape[0], O, dt, H.stream()), "pack_wfrag")
+    wddp = H.pack_dgrad(wd, dt, flip=0)          # [rows >= I][1][O] row-major
+    sp = S2dParams()
+    dyn, dydn = H.nhwc(dy, dt), H.nhwc(dyd, dt)
+    dx = torch.full((B, Hi, Hi, I), float("nan"), dtype=dyn.dtype, device=dev)
+    sp.dy, sp.w, sp.dx = ptr(dyn), ptr(wdf), ptr(dx)
+    sp.Hi = sp.Wi = Hi
+    sp.Ho = sp.Wo = Ho
+    sp.Cin, sp.dx_cs, sp.Cout, sp.dy_cs, sp.dyd_cs = I, I, O, O, O
+    sp.N, sp.w_rows, sp.wdd_rows, sp.dtype = B, wdp.shape[0], wddp.shape[0], dt
+    if ds:
+        sp.dyd, sp.wdd = ptr(dydn), ptr(wddp)
+    if bnb:
+        raw = H.rounded(H.randn(605, B, I, Hi, Hi), dt)
+        act = H.rounded(H.randn(606, B, I, Hi, Hi), dt)      # the stored activation whose sign is the ReLU mask
+        mean, invstd = H.randn(607, I) * 0.2, 0.5 + torch.rand(I, generator=torch.Generator().manual_seed(9))
+        rawn, actn, mean_d, invstd_d = H.nhwc(raw, dt), H.nhwc(act, dt), mean.to(dev), invstd.to(dev)
+        assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 1
+        nrows = lib.gdrn_conv3x3s2_dgrad_rows(C.byref(sp))
+        rows = torch.full((nrows, 2, I), float("nan"), device=dev)
+        sp.bnb_x, sp.bnb_mask, sp.bnb_mean, sp.bnb_invstd, sp.bnb_rows, sp.bnb_cs = ptr(rawn), ptr(actn), ptr(mean_d), ptr(invstd_d), ptr(rows), I
+    assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 1
+    check(lib.gdrn_conv3x3s2_dgrad(C.byref(sp), H.stream()), "conv3x3s2_dgrad")
+    torch.cuda.synchronize()
+    got = H.nchw(dx, I)
+    if bnb:
+        gm = ref * (act > 0)
+        assert H.rel(got, gm) < TOL[dt]
+        gq = H.rounded(gm, dt) if False else gm
+        s_ = rows.sum(0).cpu()
+        assert H.rel(s_[0], gm.sum((0, 2, 3))) < 2e-3 + TOL[dt]
+        xh = (raw - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+        assert H.rel(s_[1], (gm * xh).sum((0, 2, 3))) < 2e-3 + TOL[dt]
+    else:
+        assert H.rel(got, ref) < TOL[dt]
+
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C_", [64, 256, 512])
