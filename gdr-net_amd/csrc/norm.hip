@@ -397,6 +397,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------ upsample
 // PyTorch area_pixel_compute_source_index(align_corners=True): src = dst * (in-1)/(out-1) in fp32.
+// the bilinear combination with its roundings spelled out (two instantiations of `ly0 * (lx0 * a + lx1 * b) + ly1 * (...)` were contracted into
+// different fma patterns by hipcc: fused and unfused launches must give the same bits)
+__device__ __forceinline__ float up_lerp(float ly0, float ly1, float lx0, float lx1, float a00, float a01, float a10, float a11) {
+#pragma clang fp contract(off)
+    // (explicit fma calls are not enough under -ffp-contract=fast: the `contract` flag they carry lets the back end re-pair the products --
+    //  measured: rows<false> and rows<true> disagreed on 0.06 % of the elements, every one a bf16 rounding tie.  The products are made opaque.)
+    float p0 = lx0 * a00, p1 = lx0 * a10;
+    asm volatile("" : "+v"(p0), "+v"(p1));
+    float r0 = __builtin_fmaf(lx1, a01, p0), r1 = __builtin_fmaf(lx1, a11, p1);
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    float q0 = ly0 * r0;
+    asm volatile("" : "+v"(q0));
+    return __builtin_fmaf(ly1, r1, q0);
+}
+
 // BNR (r6): x is the RAW input of a BatchNorm + ReLU and the upsampled tensor is that of relu(scale * x + shift), each source value rounded to
 // the storage format first -- exactly what gdrn_bn_apply would have stored and this kernel then read (cdpn_rot_head_region.py:103-123:
 // BN -> ReLU -> UpsamplingBilinear2d): one launch and one tensor round trip less per upsampling
@@ -413,7 +428,8 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
         const int ox = (int)(t % Wo); t /= Wo;
         const int oy = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        const float fy = sh * oy, fx = sw * ox;
+        float fy = sh * oy, fx = sw * ox;
+        asm volatile("" : "+v"(fy), "+v"(fx));   // (rounded products: see upsample2x_rows_kernel)
         const int y0 = (int)fy, x0 = (int)fx;
         const int yp = (y0 < H - 1) ? 1 : 0, xp = (x0 < W - 1) ? 1 : 0;
         const float ly1 = fy - y0, ly0 = 1.f - ly1, lx1 = fx - x0, lx0 = 1.f - lx1;
@@ -438,13 +454,87 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
             }
         }
 #pragma unroll
-        for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+        for (int j = 0; j < V; ++j) o[j] = up_lerp(ly0, ly1, lx0, lx1, a00[j], a01[j], a10[j], a11[j]);
         Vec16<T>::store(y + (size_t)i * V, o);
     }
 }
 
+// Row form (r6): a workgroup = one output row (n, oy).  The element-wise kernel above spends ~60 of its ~150 VALU instructions per 16-byte output
+// on three integer divisions, and its BNR variant transforms every source value four times (once per output pixel that reads it) -- both kernels
+// are VALU-bound, not HBM-bound (upsample2x_fwd 27 / 45 us per launch against 17 / 22 us of traffic).  Here the row's source geometry is
+// uniform, a thread keeps its channel vector (C / V a power of two that divides 256: shift / mask), and the BNR variant transforms the two source rows
+// ONCE into LDS ([2][W][C] in the storage format: exactly the activation gdrn_bn_apply would have stored) before the interpolation reads them.
+// Same arithmetic per element as the element-wise kernels: results are bit-identical to theirs.
+template <typename T, bool BNR>
+__global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int lg_cvn,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, float sh, float sw) {
+    constexpr int V = Vec16<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char up_smem[];
+    const int Ho = 2 * H, Wo = 2 * W, cvn = 1 << lg_cvn;
+    const int oy = (int)(blockIdx.x % (unsigned)Ho), n = (int)(blockIdx.x / (unsigned)Ho);
+    // (sh, sw = (in - 1) / (out - 1) come from the host: two instantiations of this kernel evaluated the division differently -- one correctly
+    //  rounded, one through v_rcp_f32 -- and their outputs disagreed on 0.06 % of the elements, every one a rounding tie of the storage format)
+    // (the source coordinate is ROUNDED before its integer part is taken off: hipcc contracted `sh * oy - y0` into one fma in one instantiation of
+    //  this kernel and not in the other -- weights one ulp apart, outputs apart on every rounding tie of the storage format.  Opaque products.)
+    float fy = sh * oy;
+    asm volatile("" : "+v"(fy));
+    const int y0 = (int)fy, yp = (y0 < H - 1) ? 1 : 0;
+    const float ly1 = fy - y0, ly0 = 1.f - ly1;
+    const T* g0 = x + (size_t)(n * H + y0) * W * C;
+    const T* g1 = g0 + (size_t)yp * W * C;
+    const int cv = threadIdx.x & (cvn - 1);   // (256 % cvn == 0: fixed per thread)
+    T* s0 = reinterpret_cast<T*>(up_smem);
+    T* s1 = s0 + (size_t)W * C;
+    if constexpr (BNR) {
+        float sc[V], sf[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { sc[j] = scale[cv * V + j]; sf[j] = shift[cv * V + j]; }
+        const int per_row = W << lg_cvn;
+        for (int i = threadIdx.x; i < 2 * per_row; i += 256) {
+            const int row = i >= per_row ? 1 : 0, j = i - row * per_row;
+            float v[V];
+            Vec16<T>::load((row ? g1 : g0) + (size_t)j * V, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = fmaxf(__builtin_fmaf(v[k], sc[k], sf[k]), 0.f);   // bn_apply_kernel's arithmetic, one rounding
+            Vec16<T>::store((row ? s1 : s0) + (size_t)j * V, v);
+        }
+        __syncthreads();
+    }
+    T* yr = y + (size_t)(n * Ho + oy) * Wo * C;
+    for (int i = threadIdx.x; i < (Wo << lg_cvn); i += 256) {
+        const int ox = i >> lg_cvn;
+        float fx = sw * ox;
+        asm volatile("" : "+v"(fx));
+        const int x0 = (int)fx, xp = (x0 < W - 1) ? 1 : 0;
+        const float lx1 = fx - x0, lx0 = 1.f - lx1;
+        const int e0 = ((x0 << lg_cvn) + cv) * V, e1 = (((x0 + xp) << lg_cvn) + cv) * V;
+        float a00[V], a01[V], a10[V], a11[V], o[V];
+        if constexpr (BNR) {
+            Vec16<T>::load(s0 + e0, a00); Vec16<T>::load(s0 + e1, a01); Vec16<T>::load(s1 + e0, a10); Vec16<T>::load(s1 + e1, a11);
+        } else {
+            Vec16<T>::load(g0 + e0, a00); Vec16<T>::load(g0 + e1, a01); Vec16<T>::load(g1 + e0, a10); Vec16<T>::load(g1 + e1, a11);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = up_lerp(ly0, ly1, lx0, lx1, a00[j], a01[j], a10[j], a11[j]);
+        Vec16<T>::store(yr + (size_t)i * V, o);
+    }
+}
+
+// the row form covers the shape: C / V a power of two that divides 256, the two source rows fit 64 KiB of LDS, one workgroup per output row
+static bool upsample_rows_ok(int N, int H, int W, int C, int dtype, int* lg) {
+    const int V = dtype == GDRN_DT_H16 ? 8 : 4, cvn = C / V;
+    if (C % V || cvn <= 0 || (cvn & (cvn - 1)) || cvn > 256) return false;
+    if ((size_t)2 * W * C * (dtype == GDRN_DT_H16 ? 2 : 4) > 64 * 1024) return false;
+    if ((long long)N * 2 * H > 0x7fffffffll) return false;
+    int l = 0;
+    while ((1 << l) < cvn) ++l;
+    *lg = l;
+    return true;
+}
+
 __device__ __forceinline__ float up_weight(int o, int i, int In, float s) {
-    const float f = s * o;
+    float f = s * o;
+    asm volatile("" : "+v"(f));   // (rounded product, as the forward kernels take it)
     const int i0 = (int)f;
     const int ip = (i0 < In - 1) ? 1 : 0;
     const float l1 = f - i0;
@@ -546,19 +636,20 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_bnsums_kernel(const T* __r
         s1[j] = 0.f; s2[j] = 0.f;
         mu[j] = kst[0][cv * V + j]; is[j] = kst[1][cv * V + j]; ksc[j] = kst[2][cv * V + j]; ksh[j] = kst[3][cv * V + j];
     }
-    const long long npix = (long long)N * H * W;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    const long long r1 = min(npix, r0 + rows_per_block);
+    const unsigned npix = (unsigned)N * (unsigned)H * (unsigned)W;   // < 2^31 (host wrapper): 32-bit index arithmetic
+    const unsigned r0 = blockIdx.x * (unsigned)rows_per_block;
+    const unsigned r1 = min(npix, r0 + (unsigned)rows_per_block);
     if (rl < rpp) {
-        for (long long r = r0 + rl; r < r1; r += rpp) {
-            const int ix = (int)(r % W), iy = (int)((r / W) % H), n = (int)(r / ((long long)W * H));
+        for (unsigned r = r0 + rl; r < r1; r += rpp) {
+            const unsigned q_ = r / (unsigned)W;
+            const int ix = (int)(r - q_ * (unsigned)W), n = (int)(q_ / (unsigned)H), iy = (int)(q_ - (unsigned)n * (unsigned)H);
             float acc[V], g[V], xv[V];
             up_bwd_pixel<T>(dy, n, iy, ix, cv, H, W, C, sh, sw, acc);
             alignas(16) T q[V];
             Vec16<T>::store(q, acc);
-            *reinterpret_cast<uint4*>(dx + r * C + cv * V) = *reinterpret_cast<const uint4*>(q);
+            *reinterpret_cast<uint4*>(dx + (size_t)r * C + cv * V) = *reinterpret_cast<const uint4*>(q);
             Vec16<T>::load(q, g);      // the stored (rounded) value: what bn_bwd_reduce_kernel would read back
-            Vec16<T>::load(x + r * C + cv * V, xv);
+            Vec16<T>::load(x + (size_t)r * C + cv * V, xv);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float gg = g[j];
@@ -971,6 +1062,15 @@ extern "C" int gdrn_upsample2x_fwd(const void* x, void* y, int N, int H, int W, 
     if (!x || !y || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
     if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;  // 4x upsampled element count / 4 per thread, 32-bit index math
     const long long n = (long long)N * 4 * H * W * C;
+    int lg = 0;
+    const float up_sh = (float)(H - 1) / (float)(2 * H - 1), up_sw = (float)(W - 1) / (float)(2 * W - 1);
+    if (upsample_rows_ok(N, H, W, C, dtype, &lg)) {   // one workgroup per output row (see upsample2x_rows_kernel)
+        DISPATCH(dtype,
+                 GDRN_LAUNCH((upsample2x_rows_kernel<float, false>), dim3(N * 2 * H), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C, lg, (const float*)nullptr, (const float*)nullptr, up_sh, up_sw),
+                 GDRN_LAUNCH((upsample2x_rows_kernel<bf16_t, false>), dim3(N * 2 * H), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, lg, (const float*)nullptr, (const float*)nullptr, up_sh, up_sw));
+        GDRN_CHECK_LAUNCH();
+        return GDRN_OK;
+    }
     DISPATCH(dtype,
              GDRN_LAUNCH(upsample2x_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x, (float*)y, N, H, W, C),
              GDRN_LAUNCH(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, N, H, W, C));
@@ -993,6 +1093,16 @@ extern "C" int gdrn_bn_relu_upsample2x_fwd(const void* x_raw, const float* scale
     if (!x_raw || !scale || !shift || !y || N <= 0 || H < 2 || W < 2 || (C % 8)) return GDRN_ERR_ARG;
     if ((long long)N * H * W * C >= (1ll << 31)) return GDRN_ERR_SHAPE;
     const long long n = (long long)N * 4 * H * W * C;
+    int lg = 0;
+    const float up_sh = (float)(H - 1) / (float)(2 * H - 1), up_sw = (float)(W - 1) / (float)(2 * W - 1);
+    if (upsample_rows_ok(N, H, W, C, dtype, &lg)) {
+        const size_t lds = (size_t)2 * W * C * (dtype == GDRN_DT_H16 ? 2 : 4);
+        DISPATCH(dtype,
+                 GDRN_LAUNCH((upsample2x_rows_kernel<float, true>), dim3(N * 2 * H), dim3(256), lds, ST, (const float*)x_raw, (float*)y, N, H, W, C, lg, scale, shift, up_sh, up_sw),
+                 GDRN_LAUNCH((upsample2x_rows_kernel<bf16_t, true>), dim3(N * 2 * H), dim3(256), lds, ST, (const bf16_t*)x_raw, (bf16_t*)y, N, H, W, C, lg, scale, shift, up_sh, up_sw));
+        GDRN_CHECK_LAUNCH();
+        return GDRN_OK;
+    }
     DISPATCH(dtype,
              GDRN_LAUNCH((upsample2x_fwd_kernel<float, true>), dim3(ew_grid(n / 4)), dim3(256), 0, ST, (const float*)x_raw, (float*)y, N, H, W, C, scale, shift),
              GDRN_LAUNCH((upsample2x_fwd_kernel<bf16_t, true>), dim3(ew_grid(n / 8)), dim3(256), 0, ST, (const bf16_t*)x_raw, (bf16_t*)y, N, H, W, C, scale, shift));

@@ -595,15 +595,16 @@ def test_conv3x3_wgrad_grouped(H, variant, grid):
 
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 256), (4, 16, 256), (2, 32, 256), (2, 8, 64)])
 @pytest.mark.parametrize("dt", DTS)
-def test_bn_relu_upsample_fused_equals_the_two_launch_path_bit_for_bit(H, dt):
+def test_bn_relu_upsample_fused_equals_the_two_launch_path_bit_for_bit(H, dt, shape):
     """r6: gdrn_bn_relu_upsample2x_fwd == gdrn_bn_apply (ReLU) followed by gdrn_upsample2x_fwd, bit for bit (the fused launch rounds every
     source value to the storage format exactly where the stored activation would have been rounded); and gdrn_upsample2x_bwd_bnsums ==
     gdrn_upsample2x_bwd followed by gdrn_bn_bwd_reduce (affine ReLU mask): dx bit for bit, the partial rows bit for bit (same workgroup
     geometry, same order of additions) -- cdpn_rot_head_region.py:103-123 (BatchNorm -> ReLU -> UpsamplingBilinear2d) and its backward."""
     lib = cabi.load(BF16)
     dev = H.DEV
-    N, Hh, C_ = 3, 8, 256
+    N, Hh, C_ = shape
     raw = H.nhwc(H.rounded(H.randn(300, N, C_, Hh, Hh) * 1.5, dt), dt)
     g = torch.Generator().manual_seed(7)
     scale = (0.5 + torch.rand(C_, generator=g)).to(dev)
