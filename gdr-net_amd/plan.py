@@ -522,7 +522,15 @@ class Plan:
                 s2 = wp.stride == 2
                 npatch = (wp.M // (wp.Ho * wp.Wo)) * (wp.Ho // (4 if s2 else 8)) * (wp.Wo // 8)
                 geo.append((npatch, npatch * (1 if s2 else 2), (wp.Cout // cot) * (wp.Cin // 64)))
-            per = max(16, sum(u * t for _, u, t in geo) // nblocks_target)   # k-steps per workgroup
+            # k-steps per workgroup: the grid's target, but no more than the layers of a shape class that carries >= 20 % of the bucket's work
+            # have -- a layer with fewer k-steps than `per` runs as ONE split of short workgroups beside the others' long ones (r6: layer4's 128
+            # against 171-256 for layer3 in their common launch: 434 us stand-alone against 322 with 128 everywhere, -0.06 ms per step;
+            # profiles/r06_wgrad_bucket_balance.txt).  Small classes (the head's ConvTranspose: 1 % of its bucket) do not set the length.
+            total = sum(u * t for _, u, t in geo)
+            share = {}
+            for _, u, t in geo:
+                share[u] = share.get(u, 0) + u * t
+            per = max(16, min([total // nblocks_target] + [u for u, w in share.items() if 5 * w >= total]))
             tasks = []
             for (L, wp, flops), (npatch, units, tiles) in zip(items, geo):
                 wp.variant = kind
