@@ -69,6 +69,7 @@ class S2dParams(C.Structure):
         ("Hi", I), ("Wi", I), ("Cin", I), ("dx_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("dy_cs", I), ("dyd_cs", I),
         ("N", I), ("w_rows", I), ("wdd_rows", I), ("dtype", I),
+        ("stats", P), ("bias", P), ("act", I),   # (ABI 5) forward-conv epilogue: the launch as the ConvTranspose2d forward
     ]
 
 

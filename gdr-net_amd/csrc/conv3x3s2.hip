@@ -1,6 +1,6 @@
 // Halo-tiled 3x3 STRIDE-2 pad-1 convolution (forward) on MFMA for gfx950, optionally with the block's 1x1 stride-2 shortcut conv in the same
 // launch (round 6): the three stage-entry convs of ResNet-34 (`layerN.0.conv1` + `layerN.0.downsample.0`, resnet_backbone.py:69-80 / torchvision
-// BasicBlock with stride 2) and Patch-PnP's three stride-2 convs (conv_pnp_net.py:76-92) on maps >= 16 pixels wide.  Until now these ran on
+// BasicBlock with stride 2) and Patch-PnP's three stride-2 convs (conv_pnp_net.py:76-92); 8-wide maps two images to a pixel tile (Geo).  Until now these ran on
 // the generic gather kernel (conv_gemm.hip) at 240-430 TFLOP/s, the shortcut as a launch of its own (7-9 us for 1 GFLOP).
 //
 // conv3x3_halo.hip's scheme with one change of geometry.  A workgroup (4 waves) owns 4 x 16 output pixels x 128 output channels (wave w:
@@ -29,28 +29,40 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 constexpr int PITCH = 80;
 __host__ __device__ constexpr int half_bytes(int ppix) { return (ppix * PITCH + 255) / 256 * 256; }
-constexpr int TH = 4, TW = 16, BN = 128;
-constexpr int PE = TW + 1, PO = TW;                         // plane widths: even / odd input columns
-constexpr int B_EE = 0, B_EO = (TH + 1) * PE, B_OE = B_EO + (TH + 1) * PO, B_OO = B_OE + TH * PE, PPIX = B_OO + TH * PO;   // 0, 85, 165, 233, 297
-constexpr int HB = half_bytes(PPIX), PBYTES = 2 * HB;       // 47616 B
-constexpr int NSLOT = (PPIX * 8 + 255) / 256;               // patch granules per thread and chunk (10)
+constexpr int TH = 4, BN = 128;
 constexpr int FM = TH, FN = 2;
+// Geometry of a pixel tile.  TW_ = 16: 4 x 16 output pixels of one image.  TW_ = 8 (maps 8 pixels wide: layer4.0, Patch-PnP's third conv): 4 x 8
+// output pixels of TWO images side by side -- a fragment's lanes 0-7 are a row of image 2 m, lanes 8-15 the same row of image 2 m + 1, whose
+// planes start IMG_OFF pixels further on.  IMG_OFF = 8 mod 16 pixels keeps the ds_read_b128 pattern conflict-free: the second half-row then
+// lands on the bank slots pixels 8-15 of a 16-pixel row would have (PITCH 80 B: 16 consecutive pixels cover the 64 banks once).
+template <int TW_>
+struct Geo {
+    static constexpr int TW = TW_, NI = 16 / TW_;                  // images per tile
+    static constexpr int PE = TW + 1, PO = TW;                     // plane widths: even / odd input columns
+    static constexpr int B_EE = 0, B_EO = (TH + 1) * PE, B_OE = B_EO + (TH + 1) * PO, B_OO = B_OE + TH * PE, IPIX = B_OO + TH * PO;   // 16: 0, 85, 165, 233, 297
+    static constexpr int IMG_OFF = NI == 1 ? 0 : (IPIX + 7) / 16 * 16 + 8;                                                            //  8: 0, 45, 85, 121, 153 -> 168
+    static constexpr int PPIX = IMG_OFF * (NI - 1) + IPIX;
+    static constexpr int HB = half_bytes(PPIX), PBYTES = 2 * HB;   // 47616 B / 51456 B
+    static constexpr int NSLOT = (NI * IPIX * 8 + 255) / 256;      // patch granules per thread and chunk (10)
+    // LDS pixel index of tap TAP for output row b, lane column 0: plane base + (b + (ky >> 1)) * plane width + (kx >> 1)
+    template <int TAP>
+    static __host__ __device__ constexpr int tap_pix(int b) {
+        constexpr int ky = TAP / 3, kx = TAP % 3;
+        constexpr int base = (ky & 1) ? ((kx & 1) ? B_OO : B_OE) : ((kx & 1) ? B_EO : B_EE);
+        constexpr int pw = (kx & 1) ? PO : PE;
+        return base + (b + (ky >> 1)) * pw + (kx >> 1);
+    }
+};
+static_assert(Geo<8>::IMG_OFF % 16 == 8 && Geo<8>::IMG_OFF >= Geo<8>::IPIX, "second image's planes: 8 mod 16 pixels behind the first's");
 
 __device__ __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
     return GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c);
 }
 
-// LDS pixel index of tap TAP for output row b, lane column 0: plane base + (b + (ky >> 1)) * plane width + (kx >> 1)
-template <int TAP>
-__host__ __device__ constexpr int tap_pix(int b) {
-    constexpr int ky = TAP / 3, kx = TAP % 3;
-    constexpr int base = (ky & 1) ? ((kx & 1) ? B_OO : B_OE) : ((kx & 1) ? B_EO : B_EE);
-    constexpr int pw = (kx & 1) ? PO : PE;
-    return base + (b + (ky >> 1)) * pw + (kx >> 1);
-}
-
-template <bool DS>
+template <bool DS, int TW_>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params p) {
+    using G = Geo<TW_>;
+    constexpr int TW = G::TW, NI = G::NI, PE = G::PE, PO = G::PO, B_EO = G::B_EO, B_OE = G::B_OE, B_OO = G::B_OO, IPIX = G::IPIX, HB = G::HB, NSLOT = G::NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
@@ -64,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
     }
     const int nt = bid % NTn, mt = bid / NTn;
     const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
-    const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = mt / (tiles_x * tiles_y);
+    const int tx = mt % tiles_x, ty = (mt / tiles_x) % tiles_y, n = (mt / (tiles_x * tiles_y)) * NI;   // first image of the tile
     const int co0 = nt * BN, y0 = ty * TH, x0 = tx * TW;
     const int kch = p.Cin / 64;
 
@@ -85,18 +97,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
     unsigned pokm = 0;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
-        const int id = i * 256 + tid, q = id >> 3, sg = id & 7;
+        const int id = i * 256 + tid, qq = id >> 3, sg = id & 7;
+        const int img = NI == 1 ? 0 : qq / IPIX, q = qq - img * IPIX;   // image of the tile, pixel of its planes
         int r, c;
         if (q < B_EO) { r = 2 * (q / PE); c = 2 * (q % PE); }
         else if (q < B_OE) { const int t = q - B_EO; r = 2 * (t / PO); c = 2 * (t % PO) + 1; }
         else if (q < B_OO) { const int t = q - B_OE; r = 2 * (t / PE) + 1; c = 2 * (t % PE); }
         else { const int t = q - B_OO; r = 2 * (t / PO) + 1; c = 2 * (t % PO) + 1; }
         const int iy = 2 * y0 - 1 + r, ix = 2 * x0 - 1 + c;
-        const bool in = q < PPIX;
+        const bool in = qq < NI * IPIX;
         const bool ok = in && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
-        poff[i] = (unsigned)((n * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * 2u + sg * 16;
-        pdst[i] = in ? (q * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
+        poff[i] = (unsigned)(((n + min(img, NI - 1)) * p.Hi + iyc) * p.Wi + ixc) * (unsigned)p.x_cs * 2u + sg * 16;
+        pdst[i] = in ? ((img * G::IMG_OFF + q) * PITCH + (sg & 1) * HB + (sg >> 1) * 16) : -1;
         pokm |= ok ? (1u << i) : 0u;
     }
     const char* xg = reinterpret_cast<const char*>(p.x);
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
     const char* wdl = nullptr;
     if constexpr (DS) wdl = reinterpret_cast<const char*>(p.wd) + ((size_t)(co0 + wave * 32 + (r16 >> 2) * 8 + (r16 & 3)) * p.Cin + g * 8) * 2;
 
-    const int lb = r16 * PITCH + (g & 1) * HB + (g >> 1) * 16;
+    const int lb = ((r16 / TW) * G::IMG_OFF + (r16 % TW)) * PITCH + (g & 1) * HB + (g >> 1) * 16;
     f32x4_t acc[FN][FM], accd[DS ? FN : 1][DS ? FM : 1];
 #pragma unroll
     for (int a = 0; a < FN; ++a)
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
     auto rd = [&](uint4 (&dst)[FM], auto S_) {
         constexpr int s_ = decltype(S_)::value, tap = s_ / 2, ks = s_ % 2;
 #pragma unroll
-        for (int b = 0; b < FM; ++b) dst[b] = *reinterpret_cast<const uint4*>(smem + lb + tap_pix<tap>(b) * PITCH + ks * 32);
+        for (int b = 0; b < FM; ++b) dst[b] = *reinterpret_cast<const uint4*>(smem + lb + G::template tap_pix<tap>(b) * PITCH + ks * 32);
     };
     for (int kc = 0; kc < kch; ++kc) {
         const bool more = kc + 1 < kch;
@@ -182,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
 #undef LOADP
 #undef WRITEP
 
-    // ---- epilogue: lane holds channels cl .. cl + 7 (cl = co0 + 32 wave + 8 g; fragment a = channels + 4 a) of pixel (y0 + b, x0 + r16)
+    // ---- epilogue: lane holds channels cl .. cl + 7 (cl = co0 + 32 wave + 8 g; fragment a = channels + 4 a) of pixel (y0 + b, x0 + r16 % TW) of image n + r16 / TW
     const int cl = co0 + wave * 32 + g * 8;
-    const int prow0 = (n * p.Ho + y0) * p.Wo + x0 + r16;
+    const int prow0 = ((n + r16 / TW) * p.Ho + y0) * p.Wo + x0 + (r16 % TW);
     auto finish = [&](f32x4_t (&A)[FN][FM], float* stats, const float* bias, char* yb, int y_cs, bool relu) {
         if (stats != nullptr) {
             float* srow = stats + (size_t)mt * 2 * p.Cout + cl;
@@ -231,10 +244,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
 
 }  // namespace
 
+// pixel-tile width for a shape: 16 (maps a multiple of 16 wide), 8 (8-wide maps, two images per tile: an even image count), 0: not covered
+static int s2_tw(const gdrn_s2_params* p) {
+    if (!p || p->Wo <= 0) return 0;
+    if (p->Wo % 16 == 0) return 16;
+    if (p->Wo % 8 == 0 && (p->N % 2) == 0) return 8;
+    return 0;
+}
+
 // 1 if gdrn_conv3x3s2 covers the shape
 extern "C" int gdrn_conv3x3s2_ok(const gdrn_s2_params* p) {
     if (!p) return 0;
-    if (p->dtype != GDRN_DT_H16 || p->N <= 0 || p->Hi != 2 * p->Ho || p->Wi != 2 * p->Wo || (p->Ho % TH) || (p->Wo % TW)) return 0;
+    const int tw = s2_tw(p);
+    if (p->dtype != GDRN_DT_H16 || p->N <= 0 || p->Hi != 2 * p->Ho || p->Wi != 2 * p->Wo || (p->Ho % TH) || tw == 0) return 0;
     if (p->Cin <= 0 || (p->Cin % 64) || p->Cout <= 0 || (p->Cout % BN) || p->w_rows < p->Cout || (p->x_cs & 7) || p->x_cs < p->Cin) return 0;
     if ((p->y_cs & 7) || p->y_cs < p->Cout || p->act < 0 || p->act > 1) return 0;
     if (p->wd && ((p->yd_cs & 7) || p->yd_cs < p->Cout || p->wd_rows < p->Cout)) return 0;
@@ -244,8 +266,26 @@ extern "C" int gdrn_conv3x3s2_ok(const gdrn_s2_params* p) {
 
 extern "C" int gdrn_conv3x3s2_stats_rows(const gdrn_s2_params* p) {
     if (!gdrn_conv3x3s2_ok(p)) return GDRN_ERR_SHAPE;
-    return p->N * (p->Ho / TH) * (p->Wo / TW);
+    const int tw = s2_tw(p);
+    return (p->N / (16 / tw)) * (p->Ho / TH) * (p->Wo / tw);
 }
+
+namespace {
+template <bool DS, int TW_>
+int launch_s2(const gdrn_s2_params& p, hipStream_t st) {
+    constexpr size_t smem = Geo<TW_>::PBYTES;
+    static std::once_flag once;
+    static bool attr_ok = false;
+    std::call_once(once, [] {
+        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_kernel<DS, TW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+    });
+    if (!attr_ok) return GDRN_ERR_LAUNCH;
+    const int grid = (p.N / Geo<TW_>::NI) * (p.Ho / TH) * (p.Wo / TW_) * (p.Cout / BN);
+    GDRN_LAUNCH((conv3x3s2_kernel<DS, TW_>), dim3(grid), dim3(256), smem, st, p);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+}  // namespace
 
 // w: the FRAGMENT-MAJOR operand gdrn_pack_wfrag makes of the row-major [w_rows][9][Cin] forward weights; wd (optional): the ROW-MAJOR
 // [wd_rows][Cin] operand of the block's 1x1 stride-2 shortcut, evaluated in the same launch into yd (+ stats_d / bias_d).
@@ -256,18 +296,7 @@ extern "C" int gdrn_conv3x3s2(const gdrn_s2_params* pp, void* stream) {
     if (!pp->wd && (pp->stats_d || pp->bias_d)) return GDRN_ERR_ARG;
     if (!gdrn_conv3x3s2_ok(pp)) return GDRN_ERR_SHAPE;
     const gdrn_s2_params& p = *pp;
-    constexpr size_t smem = PBYTES;
-    static std::once_flag once;
-    static bool attr_ok = false;
-    std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess &&
-                  hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-    });
-    if (!attr_ok) return GDRN_ERR_LAUNCH;
-    const int grid = p.N * (p.Ho / TH) * (p.Wo / TW) * (p.Cout / BN);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.wd) GDRN_LAUNCH(conv3x3s2_kernel<true>, dim3(grid), dim3(256), smem, st, p);
-    else GDRN_LAUNCH(conv3x3s2_kernel<false>, dim3(grid), dim3(256), smem, st, p);
-    GDRN_CHECK_LAUNCH();
-    return GDRN_OK;
+    if (s2_tw(pp) == 16) return p.wd ? launch_s2<true, 16>(p, st) : launch_s2<false, 16>(p, st);
+    return p.wd ? launch_s2<true, 8>(p, st) : launch_s2<false, 8>(p, st);
 }

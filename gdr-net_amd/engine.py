@@ -126,6 +126,7 @@ class Engine:
         # the stride-2 3x3 convs' forward pass (stage-entry conv1 + its 1x1 shortcut in one launch, Patch-PnP's convs) on the parity-plane halo
         # kernel (r6, gdrn_conv3x3s2) where it covers the shape; "0" = the generic gather kernel
         self.s2_halo = self.h16 and _os.environ.get("GDRN_S2_HALO", "1") != "0"
+        self.s2_tw8 = _os.environ.get("GDRN_S2_TW8", "1") != "0"   # (A/B, r6) 8-wide maps on the stride-2 kernels (two images per tile)
         self.tail_overlap = True
         self.side_small = True
         self.wgrad_side_lds = 84 * 1024
@@ -156,6 +157,8 @@ class Engine:
         #  launches inside a bucket, a third stream for the HBM-bound bucket tails, the 128 x 64 weight-gradient tile (the kernel stays in the
         #  library behind gdrn_wgrad_params.variant, with its kernel tests)
         self.wgrad_blocks = 768 if (self.wgrad_stream or self.wgrad_force_lds) else 1536
+        self.wgrad_cuts = ()   # extra launch groups of the grouped weight gradient (backward-group indices): measured again in r6, no gain
+        self.merge_forks = True   # small side-stream ops wait for their bucket's end: 6 instead of 11 stream switches per backward pass (r6: no measurable effect on the step)
         nb = _os.environ.get("GDRN_BUCKETS")
         self.buckets_from_env = nb is not None
         if nb is None:
@@ -320,6 +323,11 @@ class Engine:
             L.wfF = torch.zeros_like(L.wf)
             L.wdF = torch.zeros_like(L.wd)   # ... and the data-gradient operand (taps not flipped) for gdrn_conv3x3s2_dgrad
             L.wfmt["f"] = L.wfmt["d"] = 1
+        elif kind == "convT" and KK == 9 and self.s2_halo:
+            # the head's ConvTranspose2d(3, stride 2, pad 1, output_padding 1): its FORWARD pass is the sum gdrn_conv3x3s2_dgrad evaluates
+            # (dy = its input, rows = its output channels, taps not flipped = `wf`): the fragment-major copy of the forward operand
+            L.wfF = torch.zeros_like(L.wf)
+            L.wfmt["f"] = 1
         self.layers[key] = L
         return L
 
@@ -405,7 +413,7 @@ class Engine:
             for bnkey, f in self.bn_fold.items():
                 L = f.layer
                 src = self.P[L.src[0]]
-                halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2
+                halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2 and L.kind == "conv"
                 for dst, frag in ((L.wf_e, 0), (L.wfF_e, L.wfmt.get("e", 0) or 1)):
                     if dst is None or (halo_only and not frag):
                         continue
@@ -434,7 +442,7 @@ class Engine:
             if L.kind == "stem":
                 continue
             src = self.rt_w if key == "pnp_net.fc_rt" else self.P[L.src[0]]
-            halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2  # both conv passes read the fragment-major copies
+            halo_only = self.use_halo and self.halo_min_b <= 1 and L.wfF is not None and not L.s2 and L.kind == "conv"  # both conv passes read the fragment-major copies
             for which, dst, frag in (("f", L.wf, 0), ("d", L.wd, 0), ("f", L.wfF, L.wfmt["f"] or 1), ("d", L.wdF, L.wfmt["d"] or 1)):
                 if dst is None or (halo_only and not frag):
                     continue

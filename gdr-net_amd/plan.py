@@ -58,6 +58,8 @@ class Plan:
             self._finish_unpack()
             self._build_zero_table()
         self.bwd_groups = [[op for op in g if op is not None] for g in self.bwd_groups]
+        if self.has_backward:
+            self._merge_forks()
         self.bwd = [op for g in reversed(self.bwd_groups) for op in g]
 
     # ---- op builders -------------------------------------------------------------------------
@@ -112,7 +114,7 @@ class Plan:
         th, tw, hbn = C.c_int(0), C.c_int(0), C.c_int(0)
         e.lib.gdrn_conv3x3_tile(ref, C.byref(th), C.byref(tw), C.byref(hbn))
         use_halo = halo_on and th.value > 0 and L.kind == "conv" and L.wfF is not None and not L.s2
-        if halo_on and L.wfF is not None and not L.s2 and not use_halo:
+        if halo_on and L.kind == "conv" and L.wfF is not None and not L.s2 and not use_halo:
             raise RuntimeError(f"{L.key}: no halo tiling for {Hi}x{Wi} (the generic-layout operand copy is not maintained)")
         if evalw:      # eval-mode operand with the BatchNorm scale folded in (Engine.fold)
             assert w is None
@@ -191,7 +193,7 @@ class Plan:
         same launch when given.  Returns (op, NS(_stats_rows) of the main conv, the same for the shortcut) or None when the library does not
         cover the shape (maps narrower than 16 pixels: the generic kernel keeps them)."""
         e = self.e
-        if not (e.s2_halo and L.wfF is not None and L.s2):
+        if not (e.s2_halo and L.wfF is not None and L.s2) or (Ho < 16 and not e.s2_tw8):
             return None
         sp = S2Params()
         sp.x, sp.y = ptr(x), ptr(y)
@@ -231,7 +233,7 @@ class Plan:
         the gradient w.r.t. that BatchNorm(+ReLU)'s output -- masked, its backward sums reduced in the epilogue, and the coefficient launch
         appended (as _conv does for its bnb).  None when the library does not cover the shape."""
         e = self.e
-        if not (e.s2_halo and getattr(L, "wdF", None) is not None and L.s2):
+        if not (e.s2_halo and getattr(L, "wdF", None) is not None and L.s2) or (Ho < 16 and not e.s2_tw8):
             return None
         sp = S2dParams()
         sp.dy, sp.w, sp.dx = ptr(dy), ptr(L.wdF), ptr(dx)
@@ -273,10 +275,48 @@ class Plan:
                         layer=L.key + ":dgrad" + ("+downsample:dgrad" if Ld is not None else ""))
         return run
 
+    def _convT_fwd(self, LT, bnkey, x, y, Hi, Ho, stats=None, evalmode=False):
+        """forward launch of the head's ConvTranspose2d(3, stride 2, pad 1, output_padding 1) on gdrn_conv3x3s2_dgrad (the same sum as a stride-2
+        conv's data gradient: x [B, Hi, Hi, LT.cin_f] -> y [B, Ho = 2 Hi, Ho, LT.O]) with a forward epilogue: statistics rows (train mode) or the
+        folded BatchNorm's shift + ReLU (evalmode).  Returns (op, NS(_stats_rows)) or None when the library does not cover the shape."""
+        e = self.e
+        if not (e.s2_halo and LT.kind == "convT" and getattr(LT, "wfF", None) is not None) or (Hi < 16 and not e.s2_tw8):
+            return None
+        sp = S2dParams()
+        sp.dy, sp.dx = ptr(x), ptr(y)
+        sp.Hi = sp.Wi = Ho
+        sp.Ho = sp.Wo = Hi
+        sp.Cin, sp.dx_cs, sp.Cout, sp.dy_cs = LT.O, y.shape[-1], LT.cin_f, x.shape[-1]
+        sp.N, sp.w_rows, sp.dtype = self.B, LT.rows_f, e.dt
+        sp.w = ptr(LT.wfF)
+        ref = C.byref(sp)
+        if not int(e.lib.gdrn_conv3x3s2_dgrad_ok(ref)):
+            return None
+        if evalmode:
+            f = e.fold(bnkey, LT)
+            if not self._fold_hooked:
+                self.eval_prep.append(lambda st, ctx: self.e.eval_refresh())
+                self._fold_hooked = True
+            sp.w, sp.bias, sp.act = ptr(LT.wfF_e), ptr(f.shift), 1
+        else:
+            sp.stats = ptr(stats)
+        self.keep.append(sp)
+        rows = int(e.lib.gdrn_conv3x3s2_dgrad_rows(ref))
+        assert stats is None or rows * 2 * LT.O <= stats.numel(), (LT.key, rows)
+
+        def run(st, ctx):
+            s_ = e.lib.gdrn_conv3x3s2_dgrad(ref, st)
+            if s_:
+                check(s_, f"conv3x3s2_dgrad (forward) {LT.key}")
+
+        run.meta = dict(kernel="conv3x3s2_dgrad_kernel<false,false> (forward)", flops=2.0 * self.B * Hi * Hi * LT.O * LT.I * 9,
+                        bytes=float((self.B * Ho * Ho * LT.O + self.B * Hi * Hi * LT.cin_f) * 2 + LT.O * LT.cin_f * 9 * 2), layer=LT.key)
+        return run, NS(_stats_rows=rows)
+
     def _stats_rows(self, cp):
         return cp._stats_rows
 
-    def _wgrad(self, L, x, dy, Hi, Wi, Ho, Wo, stride, pad, cin, cout, x_cs, dy_cs, KH=None, KW=None):
+    def _wgrad(self, L, x, dy, Hi, Wi, Ho, Wo, stride, pad, cin, cout, x_cs, dy_cs, KH=None, KW=None, defer=False):
         e = self.e
         wp = WgradParams()
         wp.x, wp.dy, wp.dw = ptr(x), ptr(dy), ptr(L.dwp)
@@ -316,12 +356,39 @@ class Plan:
         run.meta = dict(kernel=kname, flops=2.0 * macs, bytes=float(self.B * (Hi * Wi * cin + Ho * Wo * cout) * esz + 4 * cout * cin * wp.KH * wp.KW),
                         layer=L.key + ":wgrad")
         run.side = e.side_small  # feeds only the optimizer: off the data-gradient chain (side stream, see run_backward)
+        run.defer = bool(run.side and defer)
         return run
 
-    def _side(self, op):
-        """mark a backward op whose result only the optimizer reads: it may run on the side stream (Engine.side_small)"""
+    def _side(self, op, defer=False):
+        """mark a backward op whose result only the optimizer reads: it may run on the side stream (Engine.side_small).
+        defer: the op may wait for the end of its gradient bucket (see _merge_forks)."""
         op.side = self.e.side_small
+        op.defer = bool(defer and op.side)
         return op
+
+    def _merge_forks(self):
+        """Every switch of run_backward from the main stream to the side stream is an event record on the main stream, and the chain's next
+        kernel starts ~7 us late behind it (r6 timeline: 11 such gaps per step).  Side ops marked `defer` -- the small weight / bias gradients of
+        the fc layers and of the 1x1 shortcut convs of layer3.0 / layer4.0, whose buffers are their own -- move to the end of their bucket, in
+        front of its grouped weight-gradient launch: one fork per bucket instead of one per op."""
+        e = self.e
+        if not (e.wgrad_stream and e.merge_forks):
+            return
+        first = list(e.bucket_first_group)
+        for bkt, g0 in enumerate(first):
+            hi = first[bkt - 1] if bkt else len(self.bwd_groups)
+            moved = []
+            for gi in range(hi - 1, g0 - 1, -1):   # execution order: last forward group first
+                g = self.bwd_groups[gi]
+                moved += [op for op in g if getattr(op, "defer", False)]
+                self.bwd_groups[gi] = [op for op in g if not getattr(op, "defer", False)]
+            if not moved:
+                continue
+            g = self.bwd_groups[g0]
+            at = next((i for i, op in enumerate(g) if getattr(op, "bucket_end", False)), len(g))
+            if bkt == len(first) - 1 and getattr(self, "_front_n", 0):
+                at = 0   # (last bucket, tail overlap: its bucket-end ops sit in FRONT of the stem group)
+            g[at:at] = moved
 
     @staticmethod
     def _pad16(t, flat):
@@ -478,6 +545,7 @@ class Plan:
         backward, BatchNorm coefficients, stem weight gradient: ~0.2 ms on the main stream), so they go in FRONT of the stem group and run
         under it instead of behind it."""
         e = self.e
+        op.bucket_end = True
         g = self.bwd_groups[e.bucket_first_group[bkt]]
         if e.wgrad_stream and e.tail_overlap and bkt == len(e.bucket_first_group) - 1 and e.bucket_first_group[bkt] == 0:
             n = getattr(self, "_front_n", 0)
@@ -504,7 +572,7 @@ class Plan:
         # ---- grouped halo weight gradients: a common number of 8x8 pixel patches per workgroup within a bucket, chosen so
         # that the bucket's grid has ~wgrad_blocks workgroups (2 per CU resident); longest-running tasks first
         # launch groups = the buckets
-        cuts = sorted(set(first_group), reverse=True)
+        cuts = sorted(set(first_group) | set(e.wgrad_cuts), reverse=True)
         cut_of = lambda gi: next(c for c in cuts if gi >= c)
         wg_bucket = {c: [] for c in cuts}
         for gi, L, wp, fb in self._wgrad_deferred:
@@ -854,7 +922,7 @@ class Plan:
                         d_rawd, d_xd = E(B, Ho, Ho, pl), E(B, Hc, Hc, inpl)
                         self.tensors.update({pfx + ".d_rawd": d_rawd, pfx + ".d_xd": d_xd})
                         grp += self._bn_bwd(pfx + ".downsample.1", g2, None, rawd, d_rawd)
-                        grp.append(self._wgrad(Ld, x, d_rawd, Hc, Hc, Ho, Ho, stride, 0, inpl, pl, inpl, pl))
+                        grp.append(self._wgrad(Ld, x, d_rawd, Hc, Hc, Ho, Ho, stride, 0, inpl, pl, inpl, pl, defer=li >= 3))
                         grp.append(self._unpack(Ld))
                         pbn = f"backbone.layer{li - 1}.{RESNET34_LAYERS[li - 2] - 1}.bn2"
                         # (r6) conv1's data gradient, the shortcut conv's data gradient and the previous block's ReLU mask + bn2-backward sums as
@@ -890,10 +958,14 @@ class Plan:
         rawt, h0 = E(B, 16, 16, 256), E(B, 16, 16, 256)
         self.tensors.update({h + "0.raw": rawt, h + "0.act": h0})
         xf_first = (not FOLD) and (not HEAD_CONVS[0][2]) and self._xf_ok(e.layers[h + str(HEAD_CONVS[0][0])], 1, 16)
+        # (r6) the ConvTranspose's forward pass on the parity-class kernel (8 x 8 maps: two images per tile); the generic kernel keeps odd batch sizes
         if FOLD:
-            self.fwd.append(self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
+            tf = self._convT_fwd(LT, h + "1", feat, h0, 8, 16, evalmode=True)
+            self.fwd.append(tf[0] if tf is not None else
+                            self._conv_bn_eval(LT, h + "1", feat, 512, h0, 8, 8, 16, 16, 2, 1, relu=True, mode=1, cin=512, cout=256))
         else:
-            op, cp = self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
+            tf = self._convT_fwd(LT, h + "1", feat, rawt, 8, 16, stats=self.stats if S else None)
+            op, cp = tf if tf is not None else self._conv(LT, feat, 512, rawt, 8, 8, 16, 16, 2, 1, mode=1, cin=512, cout=256, stats=self.stats if S else None)
             self.fwd.append(op)
             self.fwd += self._bn_fwd(h + "1", rawt, cp, 256, B * 256, None if xf_first else h0)
         if T:
@@ -1175,22 +1247,22 @@ class Plan:
             grp = [
                 lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3"),
                 lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
-                self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64),
+                self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64, defer=True),
                 self._unpack(L3),
                 lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt | PREZEROED, st), "bias_grad"),   # = both .grad views
             ]
             op, _ = self._conv(L3, d_fc, 64, d_f2, 1, 1, 1, 1, 1, 0, w=L3.wd, rows=L3.rows_d, cin=64, cout=256)
             grp.append(op)
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f2), ptr(f2), ptr(d_f2p), B * 256, e.dt, st), "leaky_bwd"))
-            grp.append(self._wgrad(L2, f1, d_f2p, 1, 1, 1, 1, 1, 0, 1024, 256, 1024, 256))
+            grp.append(self._wgrad(L2, f1, d_f2p, 1, 1, 1, 1, 1, 0, 1024, 256, 1024, 256, defer=True))
             grp.append(self._unpack(L2))
-            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt | PREZEROED, st), "bias_grad")))
+            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f2p), 256, B, 256, ptr(g_b2), e.dt | PREZEROED, st), "bias_grad"), defer=True))
             op, _ = self._conv(L2, d_f2p, 256, d_f1, 1, 1, 1, 1, 1, 0, w=L2.wd, rows=L2.rows_d, cin=256, cout=1024)
             grp.append(op)
             grp.append(lambda st, ctx: check(lib.gdrn_leaky_bwd(ptr(d_f1), ptr(f1), ptr(d_f1p), B * 1024, e.dt, st), "leaky_bwd"))
-            grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024))
+            grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024, defer=True))
             grp.append(self._unpack(L1))
-            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad")))
+            grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad"), defer=True))
             op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
             grp.append(op)
             self.bwd_groups.append(grp)

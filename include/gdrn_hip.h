@@ -33,7 +33,9 @@ extern "C" {
  *    gdrn_scaled_loss_weights -- the fp16 mode's dynamic loss scale decided on the device; gdrn_bn_relu_upsample2x_fwd, gdrn_upsample2x_bwd_bnsums; gdrn_block64_eval; gdrn_conv3x3s2 / gdrn_conv3x3s2_dgrad (+ gdrn_s2_params, gdrn_s2d_params).
  *    Removed: gdrn_conv3x3_wgrad_multi_w128 and gdrn_wgrad_params.variant = GDRN_WGRAD_W128 (the 128 x 64 weight-gradient tile of rounds 4-5:
  *    never faster inside the step). */
-#define GDRN_ABI_VERSION 4
+/* 5: gdrn_s2d_params grew stats / bias / act (appended; NULL / 0 = the data gradient of version 4): gdrn_conv3x3s2_dgrad also runs the forward pass of
+ *    the head's ConvTranspose2d.  gdrn_conv3x3s2 / gdrn_conv3x3s2_dgrad accept maps 8 pixels wide (two images per pixel tile: an even image count). */
+#define GDRN_ABI_VERSION 5
 /* `dtype` arguments.  The 16-bit format is a property of the library build: libgdrn_hip.so computes GDRN_DT_BF16, libgdrn_hip_f16.so (the same
  * sources compiled with -DGDRN_HALF_F16: v_mfma_f32_*_f16, IEEE-half storage -- the arithmetic of the reference's fp16 autocast,
  * core/gdrn_modeling/main_gdrn.py:53-56,141, gdrn_evaluator.py:568) computes GDRN_DT_F16; each rejects the other's code with GDRN_ERR_ARG,
@@ -532,7 +534,7 @@ int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_star
 /* (ABI 4) 3x3 STRIDE-2 pad-1 conv, forward, on a halo-tiled MFMA kernel (csrc/conv3x3s2.hip): ResNet-34's three stage-entry convs
  * (resnet_backbone.py:69-80, torchvision BasicBlock stride 2) and Patch-PnP's stride-2 convs (conv_pnp_net.py:76-92) -- optionally with the block's
  * 1x1 stride-2 shortcut conv (`downsample.0`) evaluated in the same launch from the same staged input (wd / yd / stats_d / bias_d).
- *   x [N][Hi][Wi][x_cs], y [N][Ho][Wo][y_cs], yd [N][Ho][Wo][yd_cs]: NHWC 16-bit; Hi = 2 Ho, Wi = 2 Wo, Ho % 4 == 0, Wo % 16 == 0, Cin % 64 == 0,
+ *   x [N][Hi][Wi][x_cs], y [N][Ho][Wo][y_cs], yd [N][Ho][Wo][yd_cs]: NHWC 16-bit; Hi = 2 Ho, Wi = 2 Wo, Ho % 4 == 0, Wo % 16 == 0 (or Wo % 8 == 0 and N even), Cin % 64 == 0,
  *   Cout % 128 == 0.  w: the FRAGMENT-MAJOR operand gdrn_pack_wfrag makes of the row-major [w_rows][9][Cin] weights; wd: ROW-MAJOR [wd_rows][Cin].
  *   stats / stats_d (nullable): [gdrn_conv3x3s2_stats_rows][2][Cout] partial sums for gdrn_bn_finalize; bias / bias_d (nullable) fp32 [Cout];
  *   act: 0 none, 1 ReLU (main conv only; the shortcut branch has none). */
@@ -559,7 +561,10 @@ int gdrn_conv3x3s2(const gdrn_s2_params* p, void* stream);
  * operand [w_rows >= Cin][9 taps, NOT flipped][Cout].  Optional: dyd / wdd -- the output gradient of the block's 1x1 stride-2 shortcut and its
  * ROW-MAJOR operand [wdd_rows >= Cin][Cout], whose data gradient is added in the same launch (even / even input pixels); bnb_* -- dx is the gradient
  * w.r.t. a BatchNorm(+ReLU)'s output: masked where the stored activation bnb_mask <= 0, and rows [gdrn_conv3x3s2_dgrad_rows][2][Cin] of
- * (sum g, sum g * (bnb_x - mean) * invstd) for gdrn_bn_bwd_coef.  Ho % 4 == 0, Wo % 16 == 0, Cin % 64 == 0, Cout % 64 == 0. */
+ * (sum g, sum g * (bnb_x - mean) * invstd) for gdrn_bn_bwd_coef.  Ho % 4 == 0, Wo % 16 == 0 (or Wo % 8 == 0 and N even), Cin % 64 == 0, Cout % 64 == 0.
+ * (ABI 5) stats / bias / act -- the forward-conv epilogue, for the launch that IS the forward pass of nn.ConvTranspose2d(3, stride 2, pad 1,
+ * output_padding 1) (dy = its input, dx = its output, w rows = its output channels): stats [gdrn_conv3x3s2_dgrad_rows][2][Cin] partial BatchNorm
+ * sums of dx, bias fp32 [Cin], act 0 / 1 = ReLU.  All three NULL / 0: a data gradient.  Not combined with dyd / bnb_*. */
 typedef struct gdrn_s2d_params {
     const void* dy;
     const void* w;
@@ -575,6 +580,9 @@ typedef struct gdrn_s2d_params {
     int Hi, Wi, Cin, dx_cs;
     int Ho, Wo, Cout, dy_cs, dyd_cs;
     int N, w_rows, wdd_rows, dtype;
+    float* stats;
+    const float* bias;
+    int act;
 } gdrn_s2d_params;
 int gdrn_conv3x3s2_dgrad_ok(const gdrn_s2d_params* p);
 int gdrn_conv3x3s2_dgrad_rows(const gdrn_s2d_params* p);

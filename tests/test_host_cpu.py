@@ -31,7 +31,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gdrn_hip.h but not exported"
     assert sorted(cabi.EXPORTS) == declared, set(cabi.EXPORTS) ^ set(declared)
-    assert lib.gdrn_version() == 4  # host-only call (no device needed)
+    assert lib.gdrn_version() == 5  # host-only call (no device needed)
 
 
 def test_struct_layouts_match_the_header():
@@ -367,16 +367,21 @@ def test_plans_route_the_stem_and_the_head_output_conv_to_their_own_kernels():
     inf = kernels(e.plan(64, False, False).fwd)
     assert "stem_conv_pool_kernel" in inf and "stem_conv_kernel" not in inf
     assert "head_conv_tail64_kernel<bf16,false>" in inf
-    # r6: layer1's blocks are one launch each, the stride-2 convs on maps >= 16 wide (layer2.0 / layer3.0 conv1 WITH their 1x1 shortcuts, Patch-PnP's
-    # first two) run on the parity-plane kernel; the generic kernel keeps layer4.0's pair, the ConvTranspose, Patch-PnP's third conv and fc_rt
+    # r6: layer1's blocks are one launch each; EVERY stride-2 3x3 conv (the three stage entries WITH their 1x1 shortcuts, Patch-PnP's three) runs on
+    # the parity-plane kernel -- 8-wide maps two images to a tile -- and the ConvTranspose's forward pass on the parity-class kernel; the generic
+    # kernel keeps fc_rt
     assert sum(k == "block64_eval_kernel" for k in inf) == 3 and not any(k.startswith("conv3x3_halo_kernel<bf16,8,16,64") for k in inf)
-    assert sum(k == "conv3x3s2_kernel<true>" for k in inf) == 2 and sum(k == "conv3x3s2_kernel<false>" for k in inf) == 2
-    assert sum(k.startswith("conv_gemm_kernel") for k in inf) == 5, [k for k in inf if k.startswith("conv_gemm")]
+    assert sum(k == "conv3x3s2_kernel<true>" for k in inf) == 3 and sum(k == "conv3x3s2_kernel<false>" for k in inf) == 3
+    assert sum(k == "conv3x3s2_dgrad_kernel<false,false> (forward)" for k in inf) == 1
+    assert sum(k.startswith("conv_gemm_kernel") for k in inf) == 1, [k for k in inf if k.startswith("conv_gemm")]
     assert sum(k.endswith(",2,1>") or k.endswith(",2>") for k in inf if k.startswith("conv3x3_halo_kernel")) == 18   # layer3 + layer4 + the 16x16 head conv: eight waves
     tr = e.plan(64, True, True)
     fwd, bwd = kernels(tr.fwd), kernels(tr.bwd)
     assert "stem_conv_kernel" in fwd and "stem_conv_pool_kernel" not in fwd            # train mode: bn1 needs the batch statistics first
-    assert sum(k == "conv3x3s2_kernel<true>" for k in fwd) == 2 and sum(k == "conv3x3s2_kernel<false>" for k in fwd) == 2 and "block64_eval_kernel" not in fwd
+    assert sum(k == "conv3x3s2_kernel<true>" for k in fwd) == 3 and sum(k == "conv3x3s2_kernel<false>" for k in fwd) == 3 and "block64_eval_kernel" not in fwd
+    assert sum(k == "conv3x3s2_dgrad_kernel<false,false> (forward)" for k in fwd) == 1
+    assert sum(k == "conv3x3s2_dgrad_kernel<true,true>" for k in bwd) == 3 and sum(k == "conv3x3s2_dgrad_kernel<false,false>" for k in bwd) == 3
+    assert sum(k.startswith("conv_gemm_kernel") for k in bwd) == 4     # the three fc data gradients and the ConvTranspose's (a stride-2 conv with a BatchNorm-backward epilogue)
     assert "head_conv_tail64_kernel<bf16,true>" in fwd and "head_out_dgrad64_kernel<bf16>" in bwd
     assert not any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in bwd)   # four-wave data gradients (side stream on)
     assert any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in fwd)

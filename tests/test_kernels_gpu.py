@@ -676,11 +676,13 @@ def test_block64_eval_equals_two_halo_launches_bit_for_bit(H, case):
     assert lib.gdrn_block64_eval_ok(B, 12, 16, dt) == 0 and lib.gdrn_block64_eval(ptr(xd), ptr(wf1), ptr(b1d), ptr(wf2), ptr(b2d), ptr(xd), B, Hh, Ww, dt, H.stream()) == -1
 
 
-@pytest.mark.parametrize("case", [(2, 64, 128, 32, True), (3, 128, 256, 16, True), (2, 128, 128, 32, False), (1, 128, 128, 16, False), (2, 256, 512, 16, True)])
+@pytest.mark.parametrize("case", [(2, 64, 128, 32, True), (3, 128, 256, 16, True), (2, 128, 128, 32, False), (1, 128, 128, 16, False), (2, 256, 512, 16, True),
+                                  (4, 256, 512, 8, True), (2, 128, 128, 8, False), (6, 64, 128, 8, True)])
 def test_conv3x3_stride2_parity_plane_kernel(H, case):
     """r6: gdrn_conv3x3s2 -- 3x3 stride-2 pad-1 forward conv on the parity-plane halo kernel, with the block's 1x1 stride-2 shortcut conv in the
     same launch (ds), per-tile BatchNorm-statistics rows for both, and the eval-mode epilogue (bias, ReLU on the main conv only) -- against
-    torch on the rounded operands (resnet_backbone.py:69-80 stage-entry blocks; conv_pnp_net.py:76-92).  case = (B, Cin, Cout, Hout, ds)."""
+    torch on the rounded operands (resnet_backbone.py:69-80 stage-entry blocks; conv_pnp_net.py:76-92).  case = (B, Cin, Cout, Hout, ds).
+    Hout = 8: the two-images-per-tile form (layer4.0, Patch-PnP's third conv)."""
     from gdrnet_amd.cabi import S2Params
 
     lib = cabi.load(BF16)
@@ -709,7 +711,7 @@ def test_conv3x3_stride2_parity_plane_kernel(H, case):
             sp.wd, sp.yd = ptr(wdp), ptr(yd)
         assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 1
         rows = lib.gdrn_conv3x3s2_stats_rows(C.byref(sp))
-        assert rows == B * (Ho // 4) * (Ho // 16)
+        assert rows == (B * (Ho // 4) * (Ho // 16) if Ho % 16 == 0 else (B // 2) * (Ho // 4))
         st1 = torch.full((rows, 2, O), float("nan"), device=dev)
         st2 = torch.full((rows, 2, O), float("nan"), device=dev)
         bias, bias_d = H.randn(503, O).to(dev), H.randn(504, O).to(dev)
@@ -737,15 +739,20 @@ def test_conv3x3_stride2_parity_plane_kernel(H, case):
                 assert H.rel(H.nchw(yd, O), refd + bias_d.cpu().view(1, -1, 1, 1)) < TOL[dt]
     sp.Wo = sp.Ho = 8
     sp.Hi = sp.Wi = 16
-    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # maps narrower than 16 pixels stay on the generic kernel
+    sp.N = 3
+    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # 8-wide maps go two images to a tile: an odd image count stays on the generic kernel
+    sp.N, sp.Wo, sp.Ho, sp.Hi, sp.Wi = 2, 4, 4, 8, 8
+    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # ... and so do maps narrower than 8 pixels
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 32, True, True), (3, 128, 256, 16, True, True), (2, 128, 128, 32, False, False), (1, 128, 128, 16, False, False),
-                                  (2, 64, 128, 16, False, True), (2, 128, 256, 32, True, False)])
+                                  (2, 64, 128, 16, False, True), (2, 128, 256, 32, True, False),
+                                  (4, 256, 512, 8, True, True), (2, 128, 128, 8, False, False), (6, 64, 128, 8, True, False), (2, 128, 64, 8, False, True)])
 def test_conv3x3_stride2_dgrad_parity_class_kernel(H, case):
     """r6: gdrn_conv3x3s2_dgrad -- data gradient of the 3x3 stride-2 conv (four parity classes of input pixels, 1 / 2 / 2 / 4 taps), with the 1x1
     stride-2 shortcut's data gradient added in the same launch (ds) and the ReLU mask + BatchNorm-backward sums of the BatchNorm whose output
-    the gradient belongs to in the epilogue (bnb) -- against autograd on the rounded operands.  case = (B, Cin, Cout, Hout, ds, bnb)."""
+    the gradient belongs to in the epilogue (bnb) -- against autograd on the rounded operands.  case = (B, Cin, Cout, Hout, ds, bnb).
+    Hout = 8: the two-images-per-tile form (layer4.0, Patch-PnP's third conv)."""
     from gdrnet_amd.cabi import S2dParams
 
     lib = cabi.load(BF16)
@@ -797,6 +804,59 @@ def test_conv3x3_stride2_dgrad_parity_class_kernel(H, case):
         assert H.rel(s_[1], (gm * xh).sum((0, 2, 3))) < 2e-3 + TOL[dt]
     else:
         assert H.rel(got, ref) < TOL[dt]
+    sp.N, sp.Ho, sp.Wo, sp.Hi, sp.Wi = 3, 8, 8, 16, 16
+    assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 0   # 8-wide maps: two images per tile, an odd image count is not covered
+
+
+@pytest.mark.parametrize("case", [(4, 512, 256, 8), (2, 128, 64, 16), (2, 64, 128, 8)])
+def test_conv_transpose_forward_on_the_stride2_dgrad_kernel(H, case):
+    """r6 (ABI 5): gdrn_conv3x3s2_dgrad with the forward epilogue = the forward pass of nn.ConvTranspose2d(Cin, Cout, 3, stride 2, padding 1,
+    output_padding 1) (cdpn_rot_head_region.py:96-101): train mode -- raw output + per-tile BatchNorm statistics rows; eval mode -- bias + ReLU.
+    case = (B, Cin, Cout, Hin)."""
+    from gdrnet_amd.cabi import S2dParams
+
+    lib = cabi.load(BF16)
+    dt, dev = BF16, H.DEV
+    B, I, O, Hin = case
+    Hout = 2 * Hin
+    x = H.rounded(H.randn(700, B, I, Hin, Hin), dt)
+    w = H.rounded(H.randn(701, I, O, 3, 3) / math.sqrt(I * 2.25), dt)     # ConvTranspose2d weight [Cin][Cout][3][3]
+    ref = F.conv_transpose2d(x, w, None, 2, 1, 1)
+    # forward operand [rows = Cout][9 taps, not flipped][Cin] (Engine._pack_args, kind "convT", which "f"), fragment-major
+    rows = O if O <= 64 else (O + 127) // 128 * 128
+    wp = torch.zeros(rows, 9, I)
+    wp[:O] = w.permute(1, 2, 3, 0).reshape(O, 9, I)
+    wp = wp.to(dev).to(H.tdt(dt)).contiguous()
+    wf = torch.empty_like(wp)
+    check(lib.gdrn_pack_wfrag(ptr(wp), ptr(wf), rows, I, dt, H.stream()), "pack_wfrag")
+    xn = H.nhwc(x, dt)
+    for mode in ("train", "eval"):
+        sp = S2dParams()
+        y = torch.full((B, Hout, Hout, O), float("nan"), dtype=xn.dtype, device=dev)
+        sp.dy, sp.w, sp.dx = ptr(xn), ptr(wf), ptr(y)
+        sp.Hi = sp.Wi = Hout
+        sp.Ho = sp.Wo = Hin
+        sp.Cin, sp.dx_cs, sp.Cout, sp.dy_cs = O, O, I, I
+        sp.N, sp.w_rows, sp.dtype = B, rows, dt
+        assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 1
+        nrows = lib.gdrn_conv3x3s2_dgrad_rows(C.byref(sp))
+        st = torch.full((nrows, 2, O), float("nan"), device=dev)
+        bias = H.randn(702, O).to(dev)
+        if mode == "train":
+            sp.stats = ptr(st)
+        else:
+            sp.bias, sp.act = ptr(bias), 1
+        check(lib.gdrn_conv3x3s2_dgrad(C.byref(sp), H.stream()), "conv3x3s2_dgrad (forward)")
+        torch.cuda.synchronize()
+        if mode == "train":
+            assert H.rel(H.nchw(y, O), ref) < TOL[dt]
+            s_ = st.sum(0).cpu()
+            assert H.rel(s_[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dt] and H.rel(s_[1], (ref ** 2).sum((0, 2, 3))) < 1e-3
+        else:
+            assert H.rel(H.nchw(y, O), F.relu(ref + bias.cpu().view(1, -1, 1, 1))) < TOL[dt]
+    sp.bnb_x = ptr(y)
+    assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 0   # the forward epilogue does not combine with the BatchNorm-backward one
+
 
 # ---------------------------------------------------------------------------------------------- BatchNorm
 @pytest.mark.parametrize("dt", DTS)
