@@ -63,7 +63,11 @@ __host__ __device__ constexpr int set_cls(int set, int i) {
     return set == 0 ? i : (set == 1 ? (i == 0 ? 1 : 3) : (set == 2 ? (i == 0 ? 2 : 3) : 3));
 }
 
-template <bool DS, bool BNB, int TW_, bool FWD = false>
+// WD (r6b): the weight blocks of a whole chunk (18 KiB per wave = 72 VGPRs) stay in registers, each refilled right behind its last MFMA with the
+// block the NEXT chunk needs there: a weight load has a chunk (72 MFMAs, ~1150 cycles) to arrive.  For the grids that give a CU one workgroup
+// (<= 256 workgroups: the 8-wide maps), where the one-stage-ahead ring of the other form (4-16 MFMAs ahead, 30-110 ns against ~400 ns of L2
+// latency) left every stage waiting.
+template <bool DS, bool BNB, int TW_, bool FWD = false, bool WD = false>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_dgrad_kernel(const gdrn_s2d_params p) {
     static_assert(!FWD || (!DS && !BNB), "forward (ConvTranspose) epilogue: no shortcut, no BatchNorm-backward sums");
     using G = Geo<TW_>;
@@ -170,8 +174,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_dgrad_kernel(const gdrn_s2d_
         for (int b = 0; b < FM; ++b) acc[c][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    // stage s of a chunk = (k-step s >> 2, fragment set s & 3); two fragment buffers, two weight buffers (4 blocks each)
-    uint4 fA[FM], fB[FM], wA[4], wB[4];
+    // stage s of a chunk = (k-step s >> 2, fragment set s & 3); two fragment buffers, two weight buffers (4 blocks each) -- or (WD) the chunk's 18 blocks
+    uint4 fA[FM], fB[FM], wA[4], wB[4], wc[WD ? 18 : 1];
+    constexpr int SETBASE[4] = {0, 4, 6, 8};   // first block of fragment set 0..3 inside a k-step's nine
     const unsigned char* scur = smem;   // the stage the current chunk reads
     auto rd = [&](uint4 (&dst)[FM], auto S_) {
         constexpr int s_ = decltype(S_)::value, ks = s_ >> 2;
@@ -185,7 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_dgrad_kernel(const gdrn_s2d_
 #pragma unroll
         for (int i = 0; i < Q::n; ++i) dst[i] = *wptr(kc, set_tap(s_ & 3, i), ks);
     };
-    ldw(wA, 0, std::integral_constant<int, 0>{});
+    if constexpr (WD) {
+        static_for<8>([&](auto S_) {
+            constexpr int s_ = decltype(S_)::value, ks = s_ >> 2, set = s_ & 3;
+#pragma unroll
+            for (int i = 0; i < SetOf<set>::n; ++i) wc[ks * 9 + SETBASE[set] + i] = *wptr(0, set_tap(set, i), ks);
+        });
+    } else {
+        ldw(wA, 0, std::integral_constant<int, 0>{});
+    }
     for (int kc = 0; kc < kch; ++kc) {
         const bool more = kc + 1 < kch;
         scur = smem + (kc & 1) * STAGE;
@@ -205,15 +218,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_dgrad_kernel(const gdrn_s2d_
             uint4 (&src)[FM] = (s_ % 2 == 0) ? fA : fB;
             uint4 (&wq)[4] = (s_ % 2 == 0) ? wA : wB;
             if constexpr (s_ + 1 < 8) {
-                if constexpr (s_ % 2 == 0) { rd(fB, std::integral_constant<int, s_ + 1>{}); ldw(wB, kc, std::integral_constant<int, s_ + 1>{}); }
-                else { rd(fA, std::integral_constant<int, s_ + 1>{}); ldw(wA, kc, std::integral_constant<int, s_ + 1>{}); }
-            } else {
+                if constexpr (s_ % 2 == 0) { rd(fB, std::integral_constant<int, s_ + 1>{}); if constexpr (!WD) ldw(wB, kc, std::integral_constant<int, s_ + 1>{}); }
+                else { rd(fA, std::integral_constant<int, s_ + 1>{}); if constexpr (!WD) ldw(wA, kc, std::integral_constant<int, s_ + 1>{}); }
+            } else if constexpr (!WD) {
                 if (more) ldw(wA, kc + 1, std::integral_constant<int, 0>{});   // (stage 7 reads wB: wA is free for the next chunk's first stage)
             }
 #pragma unroll
             for (int i = 0; i < Q::n; ++i)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[set_cls(s_ & 3, i)][b] = mma(wq[i], src[b], acc[set_cls(s_ & 3, i)][b]);
+                for (int b = 0; b < FM; ++b) {
+                    if constexpr (WD) acc[set_cls(s_ & 3, i)][b] = mma(wc[ks * 9 + SETBASE[s_ & 3] + i], src[b], acc[set_cls(s_ & 3, i)][b]);
+                    else acc[set_cls(s_ & 3, i)][b] = mma(wq[i], src[b], acc[set_cls(s_ & 3, i)][b]);
+                }
+            if constexpr (WD) {   // the stage's blocks are consumed: the next chunk's go into the same registers
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < Q::n; ++i) wc[ks * 9 + SETBASE[s_ & 3] + i] = *wptr(kc + 1, set_tap(s_ & 3, i), ks);
+                }
+            }
             if constexpr (DS && (s_ & 3) == 3) {   // the 1x1 shortcut's gradient: even / even pixels only, its own (unshifted) fragments
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
@@ -359,17 +381,21 @@ int launch_s2d(const gdrn_s2d_params& p, hipStream_t st) {
     using G = Geo<TW_>;
     const size_t smem = 2 * (size_t)(G::PBYTES + (p.dyd ? G::P2BYTES : 0));
     const int grid = (p.N / G::NI) * (p.Ho / TH) * (p.Wo / TW_) * (p.Cin / BNC);
-    if (p.stats || p.bias || p.act) {
-        GDRN_LAUNCH((conv3x3s2_dgrad_kernel<false, false, TW_, true>), dim3(grid), dim3(256), smem, st, p);
-    } else {
-        const int v = (p.dyd ? 2 : 0) | (p.bnb_x ? 1 : 0);
-        switch (v) {
-            case 0: GDRN_LAUNCH((conv3x3s2_dgrad_kernel<false, false, TW_>), dim3(grid), dim3(256), smem, st, p); break;
-            case 1: GDRN_LAUNCH((conv3x3s2_dgrad_kernel<false, true, TW_>), dim3(grid), dim3(256), smem, st, p); break;
-            case 2: GDRN_LAUNCH((conv3x3s2_dgrad_kernel<true, false, TW_>), dim3(grid), dim3(256), smem, st, p); break;
-            default: GDRN_LAUNCH((conv3x3s2_dgrad_kernel<true, true, TW_>), dim3(grid), dim3(256), smem, st, p); break;
-        }
+    const bool wd = p.dyd != nullptr || grid <= 1024;   // (measured: the plain form with > 1024 workgroups -- three per CU -- is the one launch it loses on: 44 vs 42 us)
+    const int v = (p.stats || p.bias || p.act) ? 4 : ((p.dyd ? 2 : 0) | (p.bnb_x ? 1 : 0));
+#define S2D_LAUNCH(DS_, BNB_, FWD_)                                                                                            \
+    {                                                                                                                          \
+        if (wd) GDRN_LAUNCH((conv3x3s2_dgrad_kernel<DS_, BNB_, TW_, FWD_, true>), dim3(grid), dim3(256), smem, st, p);         \
+        else GDRN_LAUNCH((conv3x3s2_dgrad_kernel<DS_, BNB_, TW_, FWD_, false>), dim3(grid), dim3(256), smem, st, p);           \
     }
+    switch (v) {
+        case 0: S2D_LAUNCH(false, false, false) break;
+        case 1: S2D_LAUNCH(false, true, false) break;
+        case 2: S2D_LAUNCH(true, false, false) break;
+        case 3: S2D_LAUNCH(true, true, false) break;
+        default: S2D_LAUNCH(false, false, true) break;
+    }
+#undef S2D_LAUNCH
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
