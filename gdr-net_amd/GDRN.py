@@ -455,9 +455,12 @@ class GDRN(nn.Module):
         if not do_loss:  # test
             # (the fused output-conv + tail kernel writes the fp32 logits only for callers that return the maps -- GDRN.py:183-190 / `_maps` below)
             kctx["want_maps"] = bool(cfg.TEST.USE_PNP)
+            # the pose kernel writes into buffers that belong to THIS call (the plan's attributes are re-bound to them; the kernel reads the
+            # pointers at launch): no copy launches behind the forward pass (r6: two 5 us device copies closed every inference call)
+            plan.rot, plan.trans = torch.empty_like(plan.rot), torch.empty_like(plan.trans)
             with torch.no_grad():
                 plan.run_forward(kctx)
-            out_dict = {"rot": plan.rot[:B].clone(), "trans": plan.trans[:B].clone()}   # (plan.B >= B: padded inference batch)
+            out_dict = {"rot": plan.rot[:B], "trans": plan.trans[:B]}   # (plan.B >= B: padded inference batch)
             if cfg.TEST.USE_PNP:
                 out_dict.update(self._maps(plan, B))
             return out_dict
@@ -492,11 +495,10 @@ class GDRN(nn.Module):
             if out is not None:
                 return out
         eng, plan, kctx = self._prepare(x, True, a)
-        plan.run_forward(kctx)
         eng = plan.e
-        # the returned losses (weighted like forward()'s loss_dict) are formed HERE, on the main stream in front of the backward chain, which
-        # ends ~0.1 ms before the side stream does: behind the final join the one small launch and its gap were the step's last 15 us
-        out = plan.losses * self._loss_w
+        # (r6) dL/dloss_k is known BEFORE the forward pass here (unlike under autograd): written first, so that the pose kernel can leave dL/dfc
+        # itself (no combine / cast launches in front of the backward pass) and the loss-finalize launch the weighted loss vector this returns
+        seam = eng.fc_tail and eng.h16 and bool(getattr(plan, "acc_rows", 0))
         dyn = eng.loss_scale_dev()   # fp16, dynamic loss scale: its state on the device (None: bf16 / fp32 / fp16 with a static scale)
         ls = 1.0 if dyn is not None else eng._ls_host   # static loss scale on dL/dloss, divided out where the optimizer reads the gradients
         if dyn is not None:
@@ -511,6 +513,14 @@ class GDRN(nn.Module):
         elif getattr(plan, "_gw_key", None) != (self._loss_w.data_ptr(), self._loss_w._version, ls):
             plan.gw.copy_(self._loss_w * ls)  # dL/dloss_k = the config's loss weights: written once, not every step
             plan._gw_key = (self._loss_w.data_ptr(), self._loss_w._version, ls)
+        if seam:
+            out = torch.empty(8, dtype=torch.float32, device=eng.dev)   # this call's own: the kernel reads the pointer at launch
+            kctx["seeded"], kctx["loss_w"], kctx["weighted"] = True, self._loss_w.data_ptr(), out.data_ptr()
+        plan.run_forward(kctx)
+        if not seam:
+            # the returned losses (weighted like forward()'s loss_dict) are formed HERE, on the main stream in front of the backward chain, which
+            # ends ~0.1 ms before the side stream does: behind the final join the one small launch and its gap were the step's last 15 us
+            out = plan.losses * self._loss_w
         red = getattr(self, "_reducer", None)
         # The optimizer update of a gradient bucket goes out as soon as the bucket is final, under the rest of the backward pass
         # (Ranger.step_buckets_*), instead of behind the whole pass: on one GPU on the engine's side stream right behind the bucket's

@@ -79,6 +79,8 @@ class PoseParams(C.Structure):
         ("gt_rot", P), ("gt_trans", P), ("gt_trans_ratio", P), ("points", P), ("npts", I),
         ("sym", P), ("sym_count", P), ("Kmax", I), ("N", I), ("train", I),
         ("rot", P), ("trans", P), ("losses", P), ("dfc", P), ("vis", P),
+        # (ABI 5, all nullable) per-RoI loss rows | dL/dloss + combined gradient | the fc tail (fc2 finish + fc_r / fc_t) in the same launch
+        ("loss_rows", P), ("gw", P), ("dfc_comb", P), ("fc2_ws", P), ("fc2_bias", P), ("f2_out", P), ("w_rt", P), ("b_rt", P), ("fc_w", P), ("fc2_splits", I),
     ]
 
 
@@ -194,6 +196,8 @@ _SIGS = {
     "gdrn_map_loss_finalize": [P, I, I, P, P],
     "gdrn_head_tail_loss_rows": [I, I, I, I, I],
     "gdrn_map_loss_finalize_rows": [P, I, I, I, P, P],
+    "gdrn_loss_finalize": [P, I, I, I, P, P, P, P, P],
+    "gdrn_linear_splits": [I, I],
     "gdrn_head_tail_bwd": [P, I, P, P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "gdrn_pose_loss": [C.POINTER(PoseParams), P],
     "gdrn_combine3": [P, P, P, I, P],

@@ -95,21 +95,30 @@ __global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restr
 
 }  // namespace
 
+// number of K ranges (= slabs [M][N] of ws) gdrn_linear_splitk uses for a K x N layer: a multiple of 128 per range, ~1024 workgroups
+extern "C" int gdrn_linear_splits(int K, int N) {
+    if (K <= 0 || N <= 0 || (N % 16) || (K % 128)) return GDRN_ERR_SHAPE;
+    const int ntile = N / 16;
+    int S = std::max(1, std::min(std::min(K / 128, GDRN_LINEAR_MAX_SPLITS), cdiv(1024, ntile)));
+    while (S > 1 && (K % (128 * S))) --S;
+    return S;
+}
+
 // ws: GDRN_LINEAR_MAX_SPLITS * M*N floats (per-split partial slabs; no initialisation needed).  bf16 only.
 extern "C" int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
                                   int y_rs, int act, float* ws, int dtype, void* stream) {
-    if (!x || !w || !y || !ws || M <= 0 || M > 64 || K <= 0 || N <= 0) return GDRN_ERR_ARG;
+    if (!x || !w || (!y && act != GDRN_LINEAR_NO_FINISH) || !ws || M <= 0 || M > 64 || K <= 0 || N <= 0) return GDRN_ERR_ARG;
     if (dtype != GDRN_DT_H16) return GDRN_ERR_SHAPE;
     if ((N % 16) || (K % 128) || (x_rs % 8) || (w_rs % 8) || x_rs < K || w_rs < K || y_rs < N) return GDRN_ERR_SHAPE;
     // K range per workgroup: a multiple of 128 (32 per wave-step x 4 waves); ~1024 workgroups
     const int ntile = N / 16;
-    int S = std::max(1, std::min(std::min(K / 128, GDRN_LINEAR_MAX_SPLITS), cdiv(1024, ntile)));
-    while (S > 1 && (K % (128 * S))) --S;
+    const int S = gdrn_linear_splits(K, N);
     const int kper = K / S;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     GDRN_LAUNCH(linear_splitk_kernel, dim3(ntile, S), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, M, K, N, x_rs, w_rs,
                        kper, ws);
-    GDRN_LAUNCH(linear_finish_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, ws, S, bias, (bf16_t*)y, M, N, y_rs, act);
+    if (act != GDRN_LINEAR_NO_FINISH)   // (ABI 5) the caller's next kernel adds the gdrn_linear_splits(K, N) slabs itself (gdrn_pose_loss: fc2_ws)
+        GDRN_LAUNCH(linear_finish_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, ws, S, bias, (bf16_t*)y, M, N, y_rs, act);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }

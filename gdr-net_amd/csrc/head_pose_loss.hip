@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void map_loss_fwd_kernel(const float* __restri
 // partial rows acc[8 + 8 r + k] (r < nrows, written by the loss kernels in GDRN_ACC_ROWS mode) -> totals acc[0..7] in a fixed order, then the
 // five map losses.  1024 threads: thread t sums column t & 7 over rows (t >> 3) + 128 i with all (<= 32) loads of a batch in flight
 // together (256 threads walking their rows one load at a time took 17 us for 4096 rows), 128 such sums per column are added in order.
-__global__ __launch_bounds__(1024) void map_loss_finalize_rows_kernel(double* acc, int nrows, double npix, float* losses) {
+__global__ __launch_bounds__(1024) void map_loss_finalize_rows_kernel(double* acc, int nrows, double npix, float* losses, const float* pose_rows, int N,
+                                                                      const float* w, float* weighted) {
     __shared__ double part[128][8], part2[8][8];
     __shared__ double tot[8];
     const int k = threadIdx.x & 7, r0 = threadIdx.x >> 3;
@@ -541,14 +542,30 @@ __global__ __launch_bounds__(1024) void map_loss_finalize_rows_kernel(double* ac
         acc[threadIdx.x] = t;
     }
     __syncthreads();
+    __shared__ float lv[8];
     if (threadIdx.x == 0) {
         const double den = tot[5] < 1.0 ? 1.0 : tot[5];
-        losses[0] = (float)(tot[0] / den);
-        losses[1] = (float)(tot[1] / den);
-        losses[2] = (float)(tot[2] / den);
-        losses[3] = (float)(tot[3] / npix);
-        losses[4] = (float)(tot[4] / den);
+        lv[0] = (float)(tot[0] / den);
+        lv[1] = (float)(tot[1] / den);
+        lv[2] = (float)(tot[2] / den);
+        lv[3] = (float)(tot[3] / npix);
+        lv[4] = (float)(tot[4] / den);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) losses[k] = lv[k];
+    } else if (threadIdx.x >= 64 && threadIdx.x < 67) {
+        // (gdrn_loss_finalize) the three pose losses from gdrn_pose_loss's per-RoI rows, in RoI order (fp32, as the atomics added them -- in a fixed order)
+        const int k = threadIdx.x - 64;
+        float v = 0.f;
+        if (pose_rows != nullptr) {
+            for (int n = 0; n < N; ++n) v += pose_rows[n * 4 + k];
+            losses[5 + k] = v;
+        } else {
+            v = losses[5 + k];
+        }
+        lv[5 + k] = v;
     }
+    __syncthreads();
+    if (weighted != nullptr && threadIdx.x < 8) weighted[threadIdx.x] = lv[threadIdx.x] * w[threadIdx.x];
 }
 
 __global__ void map_loss_finalize_kernel(const double* acc, double npix, float* losses) {
@@ -845,7 +862,35 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const gdrn_pose_params p
     __shared__ float red[10][4];
     __shared__ float sS[10];
     const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float f2s[256], fcs[12], red9[9][4];
     const float* in = p.fc + (size_t)n * p.fs;
+    if (p.fc2_ws != nullptr) {
+        // (ABI 5) the tail of Patch-PnP's fully connected stack in this launch (conv_pnp_net.py:152-160): fc2's split-K slabs -> bias + LeakyReLU
+        // (gdrn_linear_splitk's finish pass) -> fc_r | fc_t (a 9 x 256 product per RoI) -> p.fc; then the decode below.  One workgroup per RoI,
+        // thread c = fc2 channel c.  The three launches this replaces (finish, a one-workgroup GEMM, this kernel) were 20 us of latency.
+        float v = 0.f;
+        for (int sp = 0; sp < p.fc2_splits; ++sp) v += p.fc2_ws[((size_t)sp * p.N + n) * 256 + tid];
+        v += p.fc2_bias[tid];
+        v = v > 0.f ? v : 0.1f * v;
+        const bf16_t hv = f2bf(v);
+        reinterpret_cast<bf16_t*>(p.f2_out)[(size_t)n * 256 + tid] = hv;
+        const float a = bf2f(hv);
+        const bf16_t* wr = reinterpret_cast<const bf16_t*>(p.w_rt);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float s_ = wave_sum(a * bf2f(wr[k * 256 + tid]));
+            if ((tid & 63) == 0) red9[k][tid >> 6] = s_;
+        }
+        __syncthreads();
+        if (tid < 9) {
+            const float o = ((red9[tid][0] + red9[tid][1]) + (red9[tid][2] + red9[tid][3])) + p.b_rt[tid];
+            fcs[tid] = o;
+            p.fc_w[(size_t)n * p.fs + tid] = o;
+        }
+        __syncthreads();
+        in = fcs;
+        (void)f2s;
+    }
     const float* K = p.cams + n * 9;
     const float* ctr = p.centers + n * 2;
     const float* wh = p.whs + n * 2;
@@ -922,13 +967,36 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const gdrn_pose_params p
     __syncthreads();
     if (tid == 0) {
         const float inv = 1.f / ((float)p.N * (float)p.npts);  // 3 * mean over (N, npts, 3)
-        unsafeAtomicAdd(&p.losses[0], sS[0] * inv);
         float lc = 0.f;
         const float* gtr = p.gt_trans_ratio + n * 3;
         lc = fabsf(in[6] - gtr[0]) + fabsf(in[7] - gtr[1]);
-        unsafeAtomicAdd(&p.losses[1], lc / (2.f * p.N));
-        unsafeAtomicAdd(&p.losses[2], fabsf(in[8] - gtr[2]) / (float)p.N);
-        if (p.dfc != nullptr) {
+        if (p.loss_rows != nullptr) {   // (ABI 5) one row per RoI, added up in RoI order by gdrn_loss_finalize: no memset, no atomics, run-to-run identical
+            p.loss_rows[n * 4 + 0] = sS[0] * inv;
+            p.loss_rows[n * 4 + 1] = lc / (2.f * p.N);
+            p.loss_rows[n * 4 + 2] = fabsf(in[8] - gtr[2]) / (float)p.N;
+        } else {
+            unsafeAtomicAdd(&p.losses[0], sS[0] * inv);
+            unsafeAtomicAdd(&p.losses[1], lc / (2.f * p.N));
+            unsafeAtomicAdd(&p.losses[2], fabsf(in[8] - gtr[2]) / (float)p.N);
+        }
+        if (p.dfc_comb != nullptr) {
+            // (ABI 5) dL/dfc directly -- the three unit gradients weighted with dL/dloss_k (p.gw: known before the forward pass in the fused train
+            // step) and stored at the storage width: the combine + cast launches in front of the backward pass disappear
+            bf16_t* dc = reinterpret_cast<bf16_t*>(p.dfc_comb) + (size_t)n * p.fs;
+            const float g0 = p.gw[0], g1 = p.gw[1], g2 = p.gw[2];
+            for (int k = 0; k < p.fs; ++k) {
+                float d = 0.f;
+                if (k < 9) {
+                    float g = 0.f;
+                    for (int ab = 0; ab < 9; ++ab) g += sS[1 + ab] * Rd[ab].d[k];
+                    d = g0 * (g * inv);   // (combine3's order: w0 * d0 + w1 * d1 + w2 * d2)
+                    if (k == 6) d += g1 * (sgn(in[6] - gtr[0]) / (2.f * p.N));
+                    if (k == 7) d += g1 * (sgn(in[7] - gtr[1]) / (2.f * p.N));
+                    if (k == 8) d += g2 * (sgn(in[8] - gtr[2]) / (float)p.N);
+                }
+                dc[k] = f2bf(d);
+            }
+        } else if (p.dfc != nullptr) {
             float* d0 = p.dfc + ((size_t)0 * p.N + n) * p.fs;
             float* d1 = p.dfc + ((size_t)1 * p.N + n) * p.fs;
             float* d2 = p.dfc + ((size_t)2 * p.N + n) * p.fs;
@@ -1104,7 +1172,18 @@ extern "C" int gdrn_map_loss_finalize(const double* acc, int N, int HW, float* l
 
 extern "C" int gdrn_map_loss_finalize_rows(double* acc, int nrows, int N, int HW, float* losses, void* stream) {
     if (!acc || !losses || nrows <= 0 || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
-    GDRN_LAUNCH(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses);
+    GDRN_LAUNCH(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses, (const float*)nullptr, N,
+                (const float*)nullptr, (float*)nullptr);
+    GDRN_CHECK_LAUNCH();
+    return GDRN_OK;
+}
+
+// (ABI 5) ... the same launch also finishes the pose losses from gdrn_pose_loss's per-RoI rows (pose_rows [N][4], nullable: losses[5..7] are then
+// already final) and writes weighted[k] = losses[k] * w[k], k < 8 (both nullable): the loss vector the train step returns, without a launch of its own
+extern "C" int gdrn_loss_finalize(double* acc, int nrows, int N, int HW, const float* pose_rows, float* losses, const float* w, float* weighted,
+                                  void* stream) {
+    if (!acc || !losses || nrows <= 0 || N <= 0 || HW <= 0 || ((w != nullptr) != (weighted != nullptr))) return GDRN_ERR_ARG;
+    GDRN_LAUNCH(map_loss_finalize_rows_kernel, dim3(1), dim3(1024), 0, ST, acc, nrows, (double)N * (double)HW, losses, pose_rows, N, w, weighted);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -1147,7 +1226,9 @@ extern "C" int gdrn_pose_loss(const gdrn_pose_params* p, void* stream) {
         return GDRN_ERR_ARG;
     if (p->train && (!p->losses || !p->gt_rot || !p->gt_trans_ratio || !p->points || !p->extents || p->npts <= 0))
         return GDRN_ERR_ARG;
-    if (p->losses && hipMemsetAsync(p->losses, 0, 3 * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
+    if (p->fc2_ws && (!p->fc2_bias || !p->f2_out || !p->w_rt || !p->b_rt || !p->fc_w || p->fc2_splits <= 0)) return GDRN_ERR_ARG;
+    if (p->dfc_comb && (!p->gw || !p->train)) return GDRN_ERR_ARG;
+    if (p->losses && !p->loss_rows && hipMemsetAsync(p->losses, 0, 3 * sizeof(float), ST) != hipSuccess) return GDRN_ERR_LAUNCH;
     GDRN_LAUNCH(pose_loss_kernel, dim3(p->N), dim3(256), 0, ST, *p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;

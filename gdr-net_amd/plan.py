@@ -1195,7 +1195,8 @@ class Plan:
         g2act, d_g2 = px, d_px
         L1, L2, L3 = e.layers["pnp_net.fc1"], e.layers["pnp_net.fc2"], e.layers["pnp_net.fc_rt"]
         f1, f2 = E(B, 1024), E(B, 256)
-        self.fc_out = E(B, 64, dtype=F32t)
+        self.fc_out = e._zeros(B, 64, dtype=F32t)   # (columns 9 .. 63 are never written)
+        self.keep.append(self.fc_out)
         self.tensors.update({"pnp_net.fc1.act": f1, "pnp_net.fc2.act": f2, "fc_out": self.fc_out})
         b1, b2 = e.P["pnp_net.fc1.bias"], e.P["pnp_net.fc2.bias"]
         if e.h16 and B <= 64 and e.fc_splitk:
@@ -1219,8 +1220,12 @@ class Plan:
             ws2 = e._zeros(16 * B * 256 + 64, dtype=F32t)
             self.keep.append(ws2)
 
+            # (r6) fc2's finish pass (bias, LeakyReLU), fc_r | fc_t and the pose decode are ONE launch (gdrn_pose_loss, fc2_ws): fc2 leaves its slabs
+            self.fc_tail = (ws2, int(lib.gdrn_linear_splits(1024, 256))) if e.fc_tail else None
+            act2 = -1 if self.fc_tail else 2
+
             def fc2_fwd(st, ctx):
-                check(lib.gdrn_linear_splitk(ptr(f1), ptr(L2.wf), ptr(b2), ptr(f2), B, 1024, 256, 1024, 1024, 256, 2, ptr(ws2), e.dt, st),
+                check(lib.gdrn_linear_splitk(ptr(f1), ptr(L2.wf), ptr(b2), ptr(f2), B, 1024, 256, 1024, 1024, 256, act2, ptr(ws2), e.dt, st),
                       "linear_splitk fc2")
 
             fc2_fwd.meta = dict(kernel="linear_splitk_kernel", flops=2.0 * B * 1024 * 256, layer="pnp_net.fc2")
@@ -1228,8 +1233,10 @@ class Plan:
         else:
             op, _ = self._conv(L2, f1, 1024, f2, 1, 1, 1, 1, 1, 0, bias=b2, act=2, cin=1024, cout=256)
             self.fwd.append(op)
-        op, _ = self._conv(L3, f2, 256, self.fc_out, 1, 1, 1, 1, 1, 0, bias=e.rt_b, out_f32=1, cin=256, cout=9, y_cs=64)
-        self.fwd.append(op)
+        if getattr(self, "fc_tail", None) is None:
+            op, _ = self._conv(L3, f2, 256, self.fc_out, 1, 1, 1, 1, 1, 0, bias=e.rt_b, out_f32=1, cin=256, cout=9, y_cs=64)
+            self.fwd.append(op)
+        self._fc2 = (f2, b2, L3)
         if T:
             self.dfc3 = e._zeros(3, B, 64, dtype=F32t)
             d_fc32 = e._zeros(B, 64, dtype=F32t)
@@ -1244,9 +1251,14 @@ class Plan:
             g_b1, g_b2 = e.grads["pnp_net.fc1.bias"], e.grads["pnp_net.fc2.bias"]
             for n_ in ("pnp_net.fc1.bias", "pnp_net.fc2.bias", "pnp_net.fc_r.bias", "pnp_net.fc_t.bias"):
                 self.grad_group[n_] = len(self.bwd_groups)
+            # (skipped when the forward pass was seeded: gdrn_pose_loss has then written dL/dfc itself -- ctx["seeded"], GDRN.train_step)
+            comb = lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3")
+            cast = lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast")
+            comb.seed = cast.seed = True
+            self.d_fc = d_fc
             grp = [
-                lambda st, ctx: check(lib.gdrn_combine3(ptr(self.dfc3), self.gw.data_ptr() + 20, ptr(d_fc32), B * 64, st), "combine3"),
-                lambda st, ctx: check(lib.gdrn_cast_from_f32(ptr(d_fc32), ptr(d_fc), B * 64, e.dt, st), "cast"),
+                comb,
+                cast,
                 self._wgrad(L3, f2, d_fc, 1, 1, 1, 1, 1, 0, 256, 9, 256, 64, defer=True),
                 self._unpack(L3),
                 lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_fc), 64, B, 9, ptr(self.rt_gb), e.dt | PREZEROED, st), "bias_grad"),   # = both .grad views
@@ -1285,12 +1297,22 @@ class Plan:
             pp.losses = (self.losses.data_ptr() + 20) if WL else None
             pp.dfc = ptr(self.dfc3) if T else None
             pp.vis = ptr(self.vis) if WL else None
+            pp.loss_rows = ptr(self.pose_rows) if (WL and self.acc_rows) else None
+            seeded = bool(T and WL and e.h16 and ctx.get("seeded"))   # the fused train step: dL/dloss is known now, dL/dfc leaves this launch
+            pp.gw, pp.dfc_comb = ((self.gw.data_ptr() + 20), ptr(self.d_fc)) if seeded else (None, None)
+            if getattr(self, "fc_tail", None) is not None:
+                f2_, b2_, L3_ = self._fc2
+                pp.fc2_ws, pp.fc2_splits, pp.fc2_bias, pp.f2_out = ptr(self.fc_tail[0]), self.fc_tail[1], ptr(b2_), ptr(f2_)
+                pp.w_rt, pp.b_rt, pp.fc_w = ptr(L3_.wf), ptr(e.rt_b), ptr(self.fc_out)
             check(lib.gdrn_pose_loss(C.byref(pp), st), "pose_loss")
 
         self.fwd.append(pose)
         if WL:
             if self.acc_rows:
-                self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize_rows(ptr(self.acc), self.acc_rows, B, 4096, ptr(self.losses), st), "map_loss_finalize_rows"))
+                self.pose_rows = E(B, 4, dtype=F32t)
+                # ctx["loss_w"] / ctx["weighted"] (device pointers, the fused train step): the weighted loss vector it returns, written here
+                self.fwd.append(lambda st, ctx: check(lib.gdrn_loss_finalize(ptr(self.acc), self.acc_rows, B, 4096, ptr(self.pose_rows), ptr(self.losses),
+                                                                             ctx.get("loss_w"), ctx.get("weighted"), st), "loss_finalize"))
             else:
                 self.fwd.append(lambda st, ctx: check(lib.gdrn_map_loss_finalize(ptr(self.acc), B, 4096, ptr(self.losses), st), "map_loss_finalize"))
 
@@ -1329,7 +1351,10 @@ class Plan:
         side = e.side_stream() if e.wgrad_stream else None
         used_side = in_side = False
         probe = getattr(self, "op_events", None)   # bench.py: [(start, end, meta, on_side)] HIP events around the conv launches of THIS pass
+        seeded = bool(ctx.get("seeded")) and self.e.h16
         for i, op in enumerate(self.bwd):
+            if seeded and getattr(op, "seed", False):
+                continue   # dL/dfc was written by the forward pass's pose kernel
             if probe is not None and getattr(op, "meta", None) is not None:
                 op = _probed(op, probe)
             if side is not None and getattr(op, "side", False):

@@ -190,6 +190,8 @@ int gdrn_stem_wgrad(const void* canvas, const void* g, const void* raw, const fl
  * (conv_pnp_net.py:85-92,152) where the gather kernel would run 8 workgroups.  x_rs / w_rs / y_rs: row strides in
  * elements; ws: GDRN_LINEAR_MAX_SPLITS*M*N floats (per-split partial slabs, no initialisation needed). */
 #define GDRN_LINEAR_MAX_SPLITS 16
+#define GDRN_LINEAR_NO_FINISH (-1)   /* (ABI 5) act: leave the gdrn_linear_splits(K, N) partial slabs [split][M][N] in ws, no bias / activation / y */
+int gdrn_linear_splits(int K, int N);
 int gdrn_linear_splitk(const void* x, const void* w, const float* bias, void* y, int M, int K, int N, int x_rs, int w_rs,
                        int y_rs, int act, float* ws, int dtype, void* stream);
 int gdrn_conv_stats_rows(const gdrn_conv_params* p);
@@ -424,8 +426,26 @@ typedef struct gdrn_pose_params {
     float* losses;
     float* dfc;
     float* vis;
+    float* loss_rows;
+    const float* gw;
+    void* dfc_comb;
+    const float* fc2_ws;
+    const float* fc2_bias;
+    void* f2_out;
+    const void* w_rt;
+    const float* b_rt;
+    float* fc_w;
+    int fc2_splits;
 } gdrn_pose_params;
 int gdrn_pose_loss(const gdrn_pose_params* p, void* stream);
+/* (ABI 5, all nullable = the version-4 behaviour) loss_rows [N][4]: the three pose losses as one row per RoI instead of atomics onto `losses`
+ * (no memset; gdrn_loss_finalize adds them in RoI order).  gw [3] + dfc_comb [N][fs] (16-bit): dL/dfc = sum_k gw[k] * unit gradient k, written
+ * directly (train; `dfc` is then not written).  fc2_ws .. fc2_splits: the tail of Patch-PnP's fully connected stack in the same launch
+ * (conv_pnp_net.py:152-160) -- fc2_ws = the gdrn_linear_splits(1024, 256) slabs [split][N][256] gdrn_linear_splitk(act = GDRN_LINEAR_NO_FINISH)
+ * left, fc2_bias fp32 [256], LeakyReLU(0.1), f2_out [N][256] 16-bit (fc2's activation), w_rt 16-bit [>= 9][256] row-major (fc_r | fc_t),
+ * b_rt fp32 [9], fc_w [N][fs] fp32 receives the nine outputs (`fc` is then not read). */
+int gdrn_loss_finalize(double* acc, int nrows, int N, int HW, const float* pose_rows, float* losses, const float* w, float* weighted,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small fp32 helpers */

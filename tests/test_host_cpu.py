@@ -369,11 +369,11 @@ def test_plans_route_the_stem_and_the_head_output_conv_to_their_own_kernels():
     assert "head_conv_tail64_kernel<bf16,false>" in inf
     # r6: layer1's blocks are one launch each; EVERY stride-2 3x3 conv (the three stage entries WITH their 1x1 shortcuts, Patch-PnP's three) runs on
     # the parity-plane kernel -- 8-wide maps two images to a tile -- and the ConvTranspose's forward pass on the parity-class kernel; the generic
-    # kernel keeps fc_rt
+    # kernel keeps nothing of the forward pass (fc_r | fc_t: one launch with fc2's finish pass and the pose decode)
     assert sum(k == "block64_eval_kernel" for k in inf) == 3 and not any(k.startswith("conv3x3_halo_kernel<bf16,8,16,64") for k in inf)
     assert sum(k == "conv3x3s2_kernel<true>" for k in inf) == 3 and sum(k == "conv3x3s2_kernel<false>" for k in inf) == 3
     assert sum(k == "conv3x3s2_dgrad_kernel<false,false> (forward)" for k in inf) == 1
-    assert sum(k.startswith("conv_gemm_kernel") for k in inf) == 1, [k for k in inf if k.startswith("conv_gemm")]
+    assert sum(k.startswith("conv_gemm_kernel") for k in inf) == 0, [k for k in inf if k.startswith("conv_gemm")]   # (fc_r | fc_t ride in the pose kernel)
     assert sum(k.endswith(",2,1>") or k.endswith(",2>") for k in inf if k.startswith("conv3x3_halo_kernel")) == 18   # layer3 + layer4 + the 16x16 head conv: eight waves
     tr = e.plan(64, True, True)
     fwd, bwd = kernels(tr.fwd), kernels(tr.bwd)
