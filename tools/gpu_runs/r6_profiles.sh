@@ -22,6 +22,8 @@ cd $R
 python tools/trace_steps.py $(f trace kernel_trace) 5 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-extras (round 6; bs=64 bf16 train step, default = bucket-end work on the side stream: durations of overlapped kernels include the sharing)" > $O/r06_kernel_steps_bs64_bf16.txt 2>&1
 python tools/trace_steps.py $(f serial kernel_trace) 5 "GDRN_WGRAD_STREAM=serial rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 3 ... (round 6; the launches of the default step on ONE stream: stand-alone kernel durations, the ones bench.py's roofline brackets measure)" > $O/r06_kernel_steps_serial_bs64_bf16.txt 2>&1
 python tools/overlap_trace.py $(f trace kernel_trace) > $O/r06_side_stream_overlap_bs64_bf16.txt 2>&1
+python tools/step_timeline.py $(f trace kernel_trace) 2 > $O/r06_step_timeline_bs64_bf16.txt 2>&1
+python tools/step_timeline.py $(f infer kernel_trace) 2 > $O/r06_inference_timeline_bs64_bf16.txt 2>&1
 python tools/pmc_util.py $(f sq counter_collection) $(f fetch counter_collection) $(f write counter_collection) $(f serial kernel_trace) $(f cal counter_collection) $O/r06_mfma_util_hbm_bs64_bf16 > /dev/null 2>&1
 python - <<PY > $O/r06_inference_steps_bs64_bf16.txt 2>&1
 import csv, collections
