@@ -58,6 +58,7 @@ class S2Params(C.Structure):
         ("Hi", I), ("Wi", I), ("Cin", I), ("x_cs", I),
         ("Ho", I), ("Wo", I), ("Cout", I), ("y_cs", I), ("yd_cs", I),
         ("N", I), ("w_rows", I), ("wd_rows", I), ("act", I), ("dtype", I),
+        ("bnb_x", P), ("bnb_mask", P), ("bnb_mean", P), ("bnb_invstd", P), ("bnb_rows", P), ("bnb_cs", I),   # (ABI 5) BatchNorm-backward epilogue
     ]
 
 

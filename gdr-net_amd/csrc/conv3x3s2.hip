@@ -59,8 +59,12 @@ __device__ __forceinline__ f32x4_t mma(uint4 a, uint4 b, f32x4_t c) {
     return GDRN_MFMA16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c);
 }
 
-template <bool DS, int TW_>
+// BNB (r6b, with !DS): the launch is a DATA GRADIENT -- the head's ConvTranspose2d backward is a stride-2 conv of the output gradient -- w.r.t. the
+// output of a BatchNorm(+ReLU): ReLU mask (stored activation > 0) and that BatchNorm's two backward sums on the accumulators, one partial row per
+// pixel tile (conv3x3_halo.hip's bnb epilogue).
+template <bool DS, int TW_, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params p) {
+    static_assert(!(DS && BNB), "the BatchNorm-backward epilogue: no shortcut conv");
     using G = Geo<TW_>;
     constexpr int TW = G::TW, NI = G::NI, PE = G::PE, PO = G::PO, B_EO = G::B_EO, B_OE = G::B_OE, B_OO = G::B_OO, IPIX = G::IPIX, HB = G::HB, NSLOT = G::NSLOT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -238,6 +242,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_kernel(const gdrn_s2_params 
             *reinterpret_cast<uint4*>(yb + ((size_t)(prow0 + b * p.Wo) * y_cs + cl) * 2) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     };
+    if constexpr (BNB) {
+        const char* xb = reinterpret_cast<const char*>(p.bnb_x);
+        const char* mb = reinterpret_cast<const char*>(p.bnb_mask);
+        char* yb = reinterpret_cast<char*>(p.y);
+        float kmu[8], kis[8], t1[8], t2[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 mu = *reinterpret_cast<const float4*>(p.bnb_mean + cl + 4 * h), is = *reinterpret_cast<const float4*>(p.bnb_invstd + cl + 4 * h);
+            kmu[4 * h] = mu.x; kmu[4 * h + 1] = mu.y; kmu[4 * h + 2] = mu.z; kmu[4 * h + 3] = mu.w;
+            kis[4 * h] = is.x; kis[4 * h + 1] = is.y; kis[4 * h + 2] = is.z; kis[4 * h + 3] = is.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+        uint4 xq[FM], mq[FM];   // all loads of the tile first, then arithmetic and stores
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const size_t o = ((size_t)(prow0 + b * p.Wo) * p.bnb_cs + cl) * 2;
+            xq[b] = *reinterpret_cast<const uint4*>(xb + o);
+            mq[b] = *reinterpret_cast<const uint4*>(mb + o);
+        }
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            float xv[8], mv[8], v[8];
+            Vec16<bf16_t>::unpack(xq[b], xv);
+            Vec16<bf16_t>::unpack(mq[b], mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gv = (mv[j] > 0.f) ? acc[j >> 2][b][j & 3] : 0.f;
+                v[j] = gv;
+                t1[j] += gv;
+                t2[j] += gv * (xv[j] - kmu[j]) * kis[j];
+            }
+            *reinterpret_cast<uint4*>(yb + ((size_t)(prow0 + b * p.Wo) * p.y_cs + cl) * 2) = Vec16<bf16_t>::pack(v);
+        }
+        float u1[8], u2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u1[j] = row16_sum(t1[j]); u2[j] = row16_sum(t2[j]); }
+        if (r16 == 0) {
+            float* srow = p.bnb_rows + (size_t)mt * 2 * p.Cout + cl;
+            *reinterpret_cast<float4*>(srow) = make_float4(u1[0], u1[1], u1[2], u1[3]);
+            *reinterpret_cast<float4*>(srow + 4) = make_float4(u1[4], u1[5], u1[6], u1[7]);
+            *reinterpret_cast<float4*>(srow + p.Cout) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+            *reinterpret_cast<float4*>(srow + p.Cout + 4) = make_float4(u2[4], u2[5], u2[6], u2[7]);
+        }
+        return;
+    }
     finish(acc, p.stats, p.bias, reinterpret_cast<char*>(p.y), p.y_cs, p.act == 1);
     if constexpr (DS) finish(accd, p.stats_d, p.bias_d, reinterpret_cast<char*>(p.yd), p.yd_cs, false);
 }
@@ -261,6 +311,7 @@ extern "C" int gdrn_conv3x3s2_ok(const gdrn_s2_params* p) {
     if ((p->y_cs & 7) || p->y_cs < p->Cout || p->act < 0 || p->act > 1) return 0;
     if (p->wd && ((p->yd_cs & 7) || p->yd_cs < p->Cout || p->wd_rows < p->Cout)) return 0;
     if ((unsigned long long)p->N * p->Hi * p->Wi * p->x_cs * 2ull >= (1ull << 32)) return 0;   // 32-bit byte offsets of the patch loads
+    if (p->bnb_x && (p->wd || p->stats || p->bias || p->act || (p->bnb_cs & 7) || p->bnb_cs < p->Cout)) return 0;   // BatchNorm-backward epilogue: a plain launch
     return 1;
 }
 
@@ -271,17 +322,17 @@ extern "C" int gdrn_conv3x3s2_stats_rows(const gdrn_s2_params* p) {
 }
 
 namespace {
-template <bool DS, int TW_>
+template <bool DS, int TW_, bool BNB = false>
 int launch_s2(const gdrn_s2_params& p, hipStream_t st) {
     constexpr size_t smem = Geo<TW_>::PBYTES;
     static std::once_flag once;
     static bool attr_ok = false;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_kernel<DS, TW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+        attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3s2_kernel<DS, TW_, BNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     });
     if (!attr_ok) return GDRN_ERR_LAUNCH;
     const int grid = (p.N / Geo<TW_>::NI) * (p.Ho / TH) * (p.Wo / TW_) * (p.Cout / BN);
-    GDRN_LAUNCH((conv3x3s2_kernel<DS, TW_>), dim3(grid), dim3(256), smem, st, p);
+    GDRN_LAUNCH((conv3x3s2_kernel<DS, TW_, BNB>), dim3(grid), dim3(256), smem, st, p);
     GDRN_CHECK_LAUNCH();
     return GDRN_OK;
 }
@@ -297,6 +348,10 @@ extern "C" int gdrn_conv3x3s2(const gdrn_s2_params* pp, void* stream) {
     if (!gdrn_conv3x3s2_ok(pp)) return GDRN_ERR_SHAPE;
     const gdrn_s2_params& p = *pp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.bnb_x) {
+        if (!p.bnb_mask || !p.bnb_mean || !p.bnb_invstd || !p.bnb_rows) return GDRN_ERR_ARG;
+        return s2_tw(pp) == 16 ? launch_s2<false, 16, true>(p, st) : launch_s2<false, 8, true>(p, st);
+    }
     if (s2_tw(pp) == 16) return p.wd ? launch_s2<true, 16>(p, st) : launch_s2<false, 16>(p, st);
     return p.wd ? launch_s2<true, 8>(p, st) : launch_s2<false, 8>(p, st);
 }

@@ -328,7 +328,8 @@ class Engine:
             # the head's ConvTranspose2d(3, stride 2, pad 1, output_padding 1): its FORWARD pass is the sum gdrn_conv3x3s2_dgrad evaluates
             # (dy = its input, rows = its output channels, taps not flipped = `wf`): the fragment-major copy of the forward operand
             L.wfF = torch.zeros_like(L.wf)
-            L.wfmt["f"] = 1
+            L.wdF = torch.zeros_like(L.wd)   # ... and of the data-gradient operand: the backward pass is a stride-2 conv (gdrn_conv3x3s2, bnb epilogue)
+            L.wfmt["f"] = L.wfmt["d"] = 1
         self.layers[key] = L
         return L
 

@@ -275,6 +275,44 @@ class Plan:
                         layer=L.key + ":dgrad" + ("+downsample:dgrad" if Ld is not None else ""))
         return run
 
+    def _convT_dgrad(self, LT, dy, dx, Hi, Ho, bnb):
+        """data gradient of the head's ConvTranspose2d = a 3x3 stride-2 pad-1 conv of the output gradient dy [B, Hi, Hi, LT.O] -> dx [B, Ho = Hi / 2, Ho,
+        LT.cin_f] on gdrn_conv3x3s2 with the BatchNorm-backward epilogue (bnb = (bn key, raw input of that BatchNorm, stored activation)) and the
+        coefficient launch behind it.  None when the library does not cover the shape."""
+        e = self.e
+        if not (e.s2_halo and e.s2_tw8 and LT.kind == "convT" and getattr(LT, "wdF", None) is not None):
+            return None
+        bkey, braw, bmask = bnb
+        sb = self.bn[bkey]
+        sp = S2Params()
+        sp.x, sp.w, sp.y = ptr(dy), ptr(LT.wdF), ptr(dx)
+        sp.Hi = sp.Wi = Hi
+        sp.Ho = sp.Wo = Ho
+        sp.Cin, sp.x_cs, sp.Cout, sp.y_cs = LT.cin_d, dy.shape[-1], LT.I, dx.shape[-1]
+        sp.N, sp.w_rows, sp.dtype = self.B, LT.rows_d, e.dt
+        sp.bnb_x, sp.bnb_mask, sp.bnb_mean, sp.bnb_invstd, sp.bnb_rows, sp.bnb_cs = ptr(braw), ptr(bmask), ptr(sb.mean), ptr(sb.invstd), ptr(self.stats), braw.shape[-1]
+        ref = C.byref(sp)
+        if not int(e.lib.gdrn_conv3x3s2_ok(ref)):
+            return None
+        self.keep.append(sp)
+        nrows = int(e.lib.gdrn_conv3x3s2_stats_rows(ref))
+        assert nrows * 2 * LT.I <= self.stats.numel(), (LT.key, nrows)
+        coef = self._bn_coef_op(bkey, self.stats, nrows)
+
+        def conv_only(st, ctx):
+            s_ = e.lib.gdrn_conv3x3s2(ref, st)
+            if s_:
+                check(s_, f"conv3x3s2 (data gradient) {LT.key}")
+
+        def run(st, ctx):
+            conv_only(st, ctx)
+            coef(st, ctx)
+
+        run.parts = (conv_only, coef)
+        run.meta = dict(kernel="conv3x3s2_kernel<false> (data gradient)", flops=2.0 * self.B * Ho * Ho * LT.O * LT.I * 9,
+                        bytes=float((self.B * Hi * Hi * LT.O + 2 * self.B * Ho * Ho * LT.I) * 2 + LT.O * LT.I * 9 * 2), layer=LT.key + ":dgrad")
+        return run
+
     def _convT_fwd(self, LT, bnkey, x, y, Hi, Ho, stats=None, evalmode=False):
         """forward launch of the head's ConvTranspose2d(3, stride 2, pad 1, output_padding 1) on gdrn_conv3x3s2_dgrad (the same sum as a stride-2
         conv's data gradient: x [B, Hi, Hi, LT.cin_f] -> y [B, Ho = 2 Hi, Ho, LT.O]) with a forward epilogue: statistics rows (train mode) or the
@@ -976,8 +1014,11 @@ class Plan:
             # ConvT weight grad = conv wgrad with roles swapped: "input" d_rawt (16x16, 256), "output grad" feat (8x8, 512)
             grp.append(self._wgrad(LT, d_rawt, feat, 16, 16, 8, 8, 2, 1, 256, 512, 256, 512))
             grp.append(self._unpack(LT))
-            op, _ = self._conv(LT, d_rawt, 256, d_feat, 16, 16, 8, 8, 2, 1, mode=0, w=LT.wd, rows=LT.rows_d, cin=256, cout=512,
-                               bnb=("backbone.layer4.2.bn2", prev_raw2, feat, False) if e.gemm_bnb else None)
+            # (r6) the ConvTranspose's data gradient = a stride-2 conv of the output gradient: the parity-plane kernel with the BatchNorm-backward epilogue
+            op = self._convT_dgrad(LT, d_rawt, d_feat, 16, 8, ("backbone.layer4.2.bn2", prev_raw2, feat)) if e.gemm_bnb else None
+            if op is None:
+                op, _ = self._conv(LT, d_rawt, 256, d_feat, 16, 16, 8, 8, 2, 1, mode=0, w=LT.wd, rows=LT.rows_d, cin=256, cout=512,
+                                   bnb=("backbone.layer4.2.bn2", prev_raw2, feat, False) if e.gemm_bnb else None)
             grp.append(op)
             self.bwd_groups.append(grp)
         hx, d_hx, Hh = h0, (d_h0 if T else None), 16
@@ -1275,8 +1316,21 @@ class Plan:
             grp.append(self._wgrad(L1, g2act, d_f1p, 8, 8, 1, 1, 1, 0, 128, 1024, 128, 1024, defer=True))
             grp.append(self._unpack(L1))
             grp.append(self._side(lambda st, ctx: check(lib.gdrn_bias_grad(ptr(d_f1p), 1024, B, 1024, ptr(g_b1), e.dt | PREZEROED, st), "bias_grad"), defer=True))
-            op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
-            grp.append(op)
+            if e.h16 and B <= 64 and e.fc_splitk and e.fc_tail:
+                # (r6) fc1's data gradient is bound by reading its 16.8 MB operand once, like its forward pass: the split-K skinny GEMM (L1.wd =
+                # [8192 rows = (pixel, channel)][1024] row-major) instead of 64 gather workgroups walking K = 1024 each (39 us -> 15 + 7)
+                ws1d = e._zeros(16 * B * 8192 + 64, dtype=F32t)
+                self.keep.append(ws1d)
+
+                def fc1_dgrad(st, ctx):
+                    check(lib.gdrn_linear_splitk(ptr(d_f1p), ptr(L1.wd), None, ptr(d_g2), B, 1024, 8192, 1024, 1024, 8192, 0, ptr(ws1d), e.dt, st),
+                          "linear_splitk fc1:dgrad")
+
+                fc1_dgrad.meta = dict(kernel="linear_splitk_kernel", flops=2.0 * B * 8192 * 1024, layer="pnp_net.fc1:dgrad")
+                grp.append(fc1_dgrad)
+            else:
+                op, _ = self._conv(L1, d_f1p, 1024, d_g2, 1, 1, 1, 1, 1, 0, w=L1.wd, rows=L1.rows_d, cin=1024, cout=8192, KH=1, KW=1, y_cs=8192)
+                grp.append(op)
             self.bwd_groups.append(grp)
 
         # ---------------- pose decode (+ pose / map losses in train mode)

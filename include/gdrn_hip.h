@@ -557,7 +557,11 @@ int gdrn_ranger_multi_dyn(const gdrn_ranger_task* tasks_dev, const int* row_star
  *   x [N][Hi][Wi][x_cs], y [N][Ho][Wo][y_cs], yd [N][Ho][Wo][yd_cs]: NHWC 16-bit; Hi = 2 Ho, Wi = 2 Wo, Ho % 4 == 0, Wo % 16 == 0 (or Wo % 8 == 0 and N even), Cin % 64 == 0,
  *   Cout % 128 == 0.  w: the FRAGMENT-MAJOR operand gdrn_pack_wfrag makes of the row-major [w_rows][9][Cin] weights; wd: ROW-MAJOR [wd_rows][Cin].
  *   stats / stats_d (nullable): [gdrn_conv3x3s2_stats_rows][2][Cout] partial sums for gdrn_bn_finalize; bias / bias_d (nullable) fp32 [Cout];
- *   act: 0 none, 1 ReLU (main conv only; the shortcut branch has none). */
+ *   act: 0 none, 1 ReLU (main conv only; the shortcut branch has none).
+ *   (ABI 5) bnb_* (nullable, not combined with wd / stats / bias / act): the launch is a data gradient -- the ConvTranspose2d backward of the head is
+ *   this conv applied to the output gradient -- w.r.t. a BatchNorm(+ReLU)'s output: y is masked where the stored activation bnb_mask <= 0 and rows
+ *   [gdrn_conv3x3s2_stats_rows][2][Cout] of (sum g, sum g * (bnb_x - mean) * invstd) go to bnb_rows for gdrn_bn_bwd_coef (bnb_x / bnb_mask:
+ *   [N][Ho][Wo][bnb_cs] 16-bit). */
 typedef struct gdrn_s2_params {
     const void* x;
     const void* w;
@@ -571,6 +575,12 @@ typedef struct gdrn_s2_params {
     int Hi, Wi, Cin, x_cs;
     int Ho, Wo, Cout, y_cs, yd_cs;
     int N, w_rows, wd_rows, act, dtype;
+    const void* bnb_x;
+    const void* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    float* bnb_rows;
+    int bnb_cs;
 } gdrn_s2_params;
 int gdrn_conv3x3s2_ok(const gdrn_s2_params* p);
 int gdrn_conv3x3s2_stats_rows(const gdrn_s2_params* p);

@@ -381,7 +381,8 @@ def test_plans_route_the_stem_and_the_head_output_conv_to_their_own_kernels():
     assert sum(k == "conv3x3s2_kernel<true>" for k in fwd) == 3 and sum(k == "conv3x3s2_kernel<false>" for k in fwd) == 3 and "block64_eval_kernel" not in fwd
     assert sum(k == "conv3x3s2_dgrad_kernel<false,false> (forward)" for k in fwd) == 1
     assert sum(k == "conv3x3s2_dgrad_kernel<true,true>" for k in bwd) == 3 and sum(k == "conv3x3s2_dgrad_kernel<false,false>" for k in bwd) == 3
-    assert sum(k.startswith("conv_gemm_kernel") for k in bwd) == 4     # the three fc data gradients and the ConvTranspose's (a stride-2 conv with a BatchNorm-backward epilogue)
+    assert sum(k.startswith("conv_gemm_kernel") for k in bwd) == 2     # fc_rt / fc2 data gradients; fc1's: the split-K GEMM; the ConvTranspose's: the parity-plane kernel with the BatchNorm-backward epilogue
+    assert sum(k == "conv3x3s2_kernel<false> (data gradient)" for k in bwd) == 1
     assert "head_conv_tail64_kernel<bf16,true>" in fwd and "head_out_dgrad64_kernel<bf16>" in bwd
     assert not any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in bwd)   # four-wave data gradients (side stream on)
     assert any(k.startswith("conv3x3_halo_kernel") and k.split(",")[-1].rstrip(">") == "2" for k in fwd)

@@ -808,6 +808,50 @@ def test_conv3x3_stride2_dgrad_parity_class_kernel(H, case):
     assert lib.gdrn_conv3x3s2_dgrad_ok(C.byref(sp)) == 0   # 8-wide maps: two images per tile, an odd image count is not covered
 
 
+@pytest.mark.parametrize("case", [(4, 256, 512, 8), (2, 64, 128, 16), (2, 128, 128, 8)])
+def test_conv3x3_stride2_kernel_with_the_batchnorm_backward_epilogue(H, case):
+    """r6 (ABI 5): gdrn_conv3x3s2 as a data gradient -- the head's ConvTranspose2d backward is a stride-2 conv of the output gradient -- w.r.t. a
+    BatchNorm(+ReLU)'s output: ReLU mask from the stored activation and the BatchNorm-backward sums in the epilogue (gdrn_s2_params.bnb_*),
+    against torch on the rounded operands.  case = (B, Cin, Cout, Hout)."""
+    from gdrnet_amd.cabi import S2Params
+
+    lib = cabi.load(BF16)
+    dt, dev = BF16, H.DEV
+    B, I, O, Ho = case
+    Hi = 2 * Ho
+    x = H.rounded(H.randn(800, B, I, Hi, Hi), dt)
+    w = H.rounded(H.randn(801, O, I, 3, 3) / math.sqrt(I * 9), dt)
+    ref = F.conv2d(x, w, None, 2, 1)
+    raw = H.rounded(H.randn(802, B, O, Ho, Ho), dt)
+    act = H.rounded(H.randn(803, B, O, Ho, Ho), dt)
+    mean, invstd = H.randn(804, O) * 0.2, 0.5 + torch.rand(O, generator=torch.Generator().manual_seed(11))
+    xd, rawn, actn, mean_d, invstd_d = H.nhwc(x, dt), H.nhwc(raw, dt), H.nhwc(act, dt), mean.to(dev), invstd.to(dev)
+    wp = H.pack_fwd(w, dt)
+    wf = torch.empty_like(wp)
+    check(lib.gdrn_pack_wfrag(ptr(wp), ptr(wf), wp.shape[0], I, dt, H.stream()), "pack_wfrag")
+    sp = S2Params()
+    y = torch.full((B, Ho, Ho, O), float("nan"), dtype=xd.dtype, device=dev)
+    sp.x, sp.w, sp.y = ptr(xd), ptr(wf), ptr(y)
+    sp.Hi = sp.Wi = Hi
+    sp.Ho = sp.Wo = Ho
+    sp.Cin, sp.x_cs, sp.Cout, sp.y_cs = I, I, O, O
+    sp.N, sp.w_rows, sp.dtype = B, wp.shape[0], dt
+    nrows = lib.gdrn_conv3x3s2_stats_rows(C.byref(sp))
+    rows = torch.full((nrows, 2, O), float("nan"), device=dev)
+    sp.bnb_x, sp.bnb_mask, sp.bnb_mean, sp.bnb_invstd, sp.bnb_rows, sp.bnb_cs = ptr(rawn), ptr(actn), ptr(mean_d), ptr(invstd_d), ptr(rows), O
+    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 1
+    check(lib.gdrn_conv3x3s2(C.byref(sp), H.stream()), "conv3x3s2 (bnb)")
+    torch.cuda.synchronize()
+    gm = ref * (act > 0)
+    assert H.rel(H.nchw(y, O), gm) < TOL[dt]
+    s_ = rows.sum(0).cpu()
+    assert H.rel(s_[0], gm.sum((0, 2, 3))) < 2e-3 + TOL[dt]
+    xh = (raw - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    assert H.rel(s_[1], (gm * xh).sum((0, 2, 3))) < 2e-3 + TOL[dt]
+    sp.act = 1
+    assert lib.gdrn_conv3x3s2_ok(C.byref(sp)) == 0   # the BatchNorm-backward epilogue does not combine with the forward one
+
+
 @pytest.mark.parametrize("case", [(4, 512, 256, 8), (2, 128, 64, 16), (2, 64, 128, 8)])
 def test_conv_transpose_forward_on_the_stride2_dgrad_kernel(H, case):
     """r6 (ABI 5): gdrn_conv3x3s2_dgrad with the forward epilogue = the forward pass of nn.ConvTranspose2d(Cin, Cout, 3, stride 2, padding 1,
