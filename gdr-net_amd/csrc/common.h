@@ -173,4 +173,84 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// One row of a parameter tensor through the fused Ranger update (lib/torch_utils/solver/ranger.py:100-200): gradient centralisation (row mean),
+// RAdam moments, update, optional lookahead; p, g, m, v, slow point at the row.  Shared by the per-tensor and the multi-tensor kernel -- the two
+// must stay bit-identical (tests/test_e2e_gpu.py::test_ranger_follows_an_lr_schedule_without_rebuilding_its_table).
+// (r6b) rows of whole, 16-byte-aligned float4s -- every conv / fc weight of the path except the stem's -- move as 16-byte vectors, and the row's
+// gradient is read ONCE: the first 16 values per thread (rows up to 4096 columns) stay in registers between the centralisation pass and the update
+// (it was read twice with 4-byte accesses: 2.6 TB/s over the step's 21 M parameters).
+__device__ __forceinline__ void ranger_row(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                           float* __restrict__ slow, int cols, int gc, float lr, float beta1, float beta2, float eps, float wd,
+                                           float step_size, int adaptive, int lookahead, float alpha, float grad_scale, float* red) {
+    auto one = [&](float gj, float vj, float mj, float pj, float sj, float mean, float& vo, float& mo, float& po, float& so) {
+        const float gr = (gj - mean) * grad_scale;  // grad_scale = 1/world: the gradient buffer holds the all-reduced SUM
+        const float vv = vj * beta2 + (1.f - beta2) * gr * gr;
+        const float mm = mj * beta1 + (1.f - beta1) * gr;
+        float pp = pj;
+        if (wd != 0.f) pp += -wd * lr * pp;
+        if (adaptive) pp += -step_size * lr * mm / (sqrtf(vv) + eps);
+        else pp += -step_size * lr * mm;
+        float sl = 0.f;
+        if (lookahead) { sl = sj + alpha * (pp - sj); pp = sl; }
+        vo = vv; mo = mm; po = pp; so = sl;
+    };
+    if ((cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                             reinterpret_cast<uintptr_t>(slow)) & 15) == 0) {
+        const int c4 = cols >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4 gq[4];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            gq[u] = i < c4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (gq[u].x + gq[u].y) + (gq[u].z + gq[u].w);
+        }
+        float mean = 0.f;
+        if (gc) {
+            for (int i = threadIdx.x + 1024; i < c4; i += 256) { const float4 q = g4[i]; s += (q.x + q.y) + (q.z + q.w); }
+            mean = block_sum_256(s, red) / (float)cols;
+        }
+        float4* p4 = reinterpret_cast<float4*>(p);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        float4* s4 = reinterpret_cast<float4*>(slow);
+        auto upd = [&](int i, float4 gv) {
+            const float4 vq = v4[i], mq = m4[i], pq = p4[i];
+            float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lookahead) sq = s4[i];
+            float4 vo, mo, po, so;
+            one(gv.x, vq.x, mq.x, pq.x, sq.x, mean, vo.x, mo.x, po.x, so.x);
+            one(gv.y, vq.y, mq.y, pq.y, sq.y, mean, vo.y, mo.y, po.y, so.y);
+            one(gv.z, vq.z, mq.z, pq.z, sq.z, mean, vo.z, mo.z, po.z, so.z);
+            one(gv.w, vq.w, mq.w, pq.w, sq.w, mean, vo.w, mo.w, po.w, so.w);
+            v4[i] = vo;
+            m4[i] = mo;
+            if (lookahead) s4[i] = so;
+            p4[i] = po;
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < c4) upd(i, gq[u]);
+        }
+        for (int i = threadIdx.x + 1024; i < c4; i += 256) upd(i, g4[i]);
+        return;
+    }
+    float mean = 0.f;
+    if (gc) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < cols; i += 256) s += g[i];
+        mean = block_sum_256(s, red) / (float)cols;
+    }
+    for (int i = threadIdx.x; i < cols; i += 256) {
+        float vo, mo, po, so;
+        one(g[i], v[i], m[i], p[i], lookahead ? slow[i] : 0.f, mean, vo, mo, po, so);
+        v[i] = vo;
+        m[i] = mo;
+        if (lookahead) slow[i] = so;
+        p[i] = po;
+    }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -276,30 +276,8 @@ __global__ __launch_bounds__(256) void ranger_multi_kernel(const gdrn_ranger_tas
     const int t = find_task(row_start, ntasks, blockIdx.x);
     const gdrn_ranger_task k = tasks[t];
     const size_t base = (size_t)(blockIdx.x - row_start[t]) * k.cols;
-    float mean = 0.f;
-    if (k.gc) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < k.cols; i += 256) s += k.g[base + i];
-        mean = block_sum_256(s, red) / (float)k.cols;
-    }
-    for (int i = threadIdx.x; i < k.cols; i += 256) {
-        const size_t j = base + i;
-        const float gr = (k.g[j] - mean) * grad_scale;  // grad_scale = 1/world: the gradient buffer holds the all-reduced SUM
-        const float vv = k.v[j] * beta2 + (1.f - beta2) * gr * gr;
-        const float mm = k.m[j] * beta1 + (1.f - beta1) * gr;
-        k.v[j] = vv;
-        k.m[j] = mm;
-        float pp = k.p[j];
-        if (wd != 0.f) pp += -wd * k.lr * pp;
-        if (adaptive) pp += -step_size * k.lr * mm / (sqrtf(vv) + eps);
-        else pp += -step_size * k.lr * mm;
-        if (lookahead) {
-            const float sl = k.slow[j] + alpha * (pp - k.slow[j]);
-            k.slow[j] = sl;
-            pp = sl;
-        }
-        k.p[j] = pp;
-    }
+    ranger_row(k.p + base, k.g + base, k.m + base, k.v + base, k.slow + base, k.cols, k.gc, k.lr, beta1, beta2, eps, wd, step_size, adaptive, lookahead, alpha,
+               grad_scale, red);
 }
 
 }  // namespace

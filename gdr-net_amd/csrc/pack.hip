@@ -119,30 +119,7 @@ __global__ __launch_bounds__(256) void ranger_kernel(float* __restrict__ p, cons
                                                      int lookahead, float alpha) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * cols;
-    float mean = 0.f;
-    if (gc) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < cols; i += 256) s += g[base + i];
-        mean = block_sum_256(s, red) / (float)cols;
-    }
-    for (int i = threadIdx.x; i < cols; i += 256) {
-        const size_t k = base + i;
-        const float gr = g[k] - mean;
-        const float vv = v[k] * beta2 + (1.f - beta2) * gr * gr;
-        const float mm = m[k] * beta1 + (1.f - beta1) * gr;
-        v[k] = vv;
-        m[k] = mm;
-        float pp = p[k];
-        if (wd != 0.f) pp += -wd * lr * pp;
-        if (adaptive) pp += -step_size * lr * mm / (sqrtf(vv) + eps);
-        else pp += -step_size * lr * mm;
-        if (lookahead) {
-            const float sl = slow[k] + alpha * (pp - slow[k]);
-            slow[k] = sl;
-            pp = sl;
-        }
-        p[k] = pp;
-    }
+    ranger_row(p + base, g + base, m + base, v + base, slow + base, cols, gc, lr, beta1, beta2, eps, wd, step_size, adaptive, lookahead, alpha, 1.f, red);
 }
 
 inline int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, 256LL * 16)); }
