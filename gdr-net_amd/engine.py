@@ -126,7 +126,7 @@ class Engine:
         # the stride-2 3x3 convs' forward pass (stage-entry conv1 + its 1x1 shortcut in one launch, Patch-PnP's convs) on the parity-plane halo
         # kernel (r6, gdrn_conv3x3s2) where it covers the shape; "0" = the generic gather kernel
         self.s2_halo = self.h16 and _os.environ.get("GDRN_S2_HALO", "1") != "0"
-        self.s2_tw8 = True   # 8-wide maps on the stride-2 kernels (two images per tile)
+        self.s2_tw8 = _os.environ.get("GDRN_S2_TW8", "1") != "0"   # 8-wide maps on the stride-2 kernels (two images per tile); 0: the generic kernel there (A/B)
         self.fc_tail = self.h16 and _os.environ.get("GDRN_FC_TAIL", "1") != "0"   # (A/B, r6) fc2 finish + fc_r | fc_t + pose decode as one launch; seeded train step
         self.tail_overlap = True
         self.side_small = True
