@@ -736,23 +736,27 @@ __global__ __launch_bounds__(256) void head_tail_bwd64_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------ pose decode
-struct D9 {  // forward-mode dual number with 9 partials (rot6d[6], t_[3])
+// Forward-mode dual number for the nine inputs (rot6d[6], t_[3]) of the train-mode decode.  (r6b) One partial per LANE: lane k < 9 of the
+// workgroup carries d/d(input k), every lane computes the value part redundantly -- the nine partials of a quantity used to be a 9-loop on one
+// thread (20 us of serial arithmetic per RoI in a launch nothing overlaps with).  Same operations per partial, same results bit for bit.
+struct D9 {
     float v;
-    float d[9];
+    float d[1];
 };
-__device__ __forceinline__ D9 dconst(float c) { D9 r; r.v = c; for (int i = 0; i < 9; ++i) r.d[i] = 0.f; return r; }
-__device__ __forceinline__ D9 dvar(float v, int k) { D9 r = dconst(v); r.d[k] = 1.f; return r; }
-__device__ __forceinline__ D9 operator+(const D9& a, const D9& b) { D9 r; r.v = a.v + b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-__device__ __forceinline__ D9 operator-(const D9& a, const D9& b) { D9 r; r.v = a.v - b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-__device__ __forceinline__ D9 operator*(const D9& a, const D9& b) { D9 r; r.v = a.v * b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-__device__ __forceinline__ D9 operator*(const D9& a, float s) { D9 r; r.v = a.v * s; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * s; return r; }
+constexpr int DNP = 1;
+__device__ __forceinline__ D9 dconst(float c) { D9 r; r.v = c; for (int i = 0; i < DNP; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ D9 dvar(float v, int k, int mine) { D9 r = dconst(v); r.d[0] = (k == mine) ? 1.f : 0.f; return r; }
+__device__ __forceinline__ D9 operator+(const D9& a, const D9& b) { D9 r; r.v = a.v + b.v; for (int i = 0; i < DNP; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D9 operator-(const D9& a, const D9& b) { D9 r; r.v = a.v - b.v; for (int i = 0; i < DNP; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D9 operator*(const D9& a, const D9& b) { D9 r; r.v = a.v * b.v; for (int i = 0; i < DNP; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D9 operator*(const D9& a, float s) { D9 r; r.v = a.v * s; for (int i = 0; i < DNP; ++i) r.d[i] = a.d[i] * s; return r; }
 __device__ __forceinline__ D9 operator+(const D9& a, float s) { D9 r = a; r.v += s; return r; }
 __device__ __forceinline__ D9 operator/(const D9& a, const D9& b) {
     D9 r; const float ib = 1.f / b.v; r.v = a.v * ib;
-    for (int i = 0; i < 9; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    for (int i = 0; i < DNP; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
     return r;
 }
-__device__ __forceinline__ D9 dfun(const D9& a, float f, float df) { D9 r; r.v = f; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * df; return r; }
+__device__ __forceinline__ D9 dfun(const D9& a, float f, float df) { D9 r; r.v = f; for (int i = 0; i < DNP; ++i) r.d[i] = a.d[i] * df; return r; }
 __device__ __forceinline__ D9 dsqrt(const D9& a) { const float s = sqrtf(a.v); return dfun(a, s, s > 0.f ? 0.5f / s : 0.f); }
 __device__ __forceinline__ D9 dacos(const D9& a) { const float q = 1.f - a.v * a.v; return dfun(a, acosf(a.v), q > 0.f ? -1.f / sqrtf(q) : 0.f); }
 __device__ __forceinline__ D9 dsin(const D9& a) { return dfun(a, sinf(a.v), cosf(a.v)); }
@@ -897,12 +901,14 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const gdrn_pose_params p
     const float ratio = p.ratios[n];
 
     D9 Rd[9], td[3];
+    if (p.train && tid < 9) {   // lane k: the value parts + the partial derivatives w.r.t. input k
+        D9 v[9];
+        for (int k = 0; k < 9; ++k) v[k] = dvar(in[k], k, tid);
+        decode_train(v, K, ctr, wh, ratio, Rd, td);
+    }
     if (tid == 0) {
         float Rf[9], tf[3];
         if (p.train) {
-            D9 v[9];
-            for (int k = 0; k < 9; ++k) v[k] = dvar(in[k], k);
-            decode_train(v, K, ctr, wh, ratio, Rd, td);
             for (int k = 0; k < 9; ++k) Rf[k] = Rd[k].v;
             for (int k = 0; k < 3; ++k) tf[k] = td[k].v;
         } else {
@@ -979,36 +985,33 @@ __global__ __launch_bounds__(256) void pose_loss_kernel(const gdrn_pose_params p
             unsafeAtomicAdd(&p.losses[1], lc / (2.f * p.N));
             unsafeAtomicAdd(&p.losses[2], fabsf(in[8] - gtr[2]) / (float)p.N);
         }
+    }
+    // dL/dfc: lane k < 9 holds d(R_ego)/d(input k) and forms its own entry; entries 9 .. fs - 1 are zero
+    if (tid < p.fs) {
+        const int k = tid;
+        const float inv = 1.f / ((float)p.N * (float)p.npts);
+        const float* gtr = p.gt_trans_ratio + n * 3;
+        float g = 0.f;
+        if (k < 9) {
+            for (int ab = 0; ab < 9; ++ab) g += sS[1 + ab] * Rd[ab].d[0];
+        }
+        const float u1 = (k == 6) ? sgn(in[6] - gtr[0]) / (2.f * p.N) : ((k == 7) ? sgn(in[7] - gtr[1]) / (2.f * p.N) : 0.f);   // d loss_centroid / d fc[k]
+        const float u2 = (k == 8) ? sgn(in[8] - gtr[2]) / (float)p.N : 0.f;                                                      // d loss_z / d fc[k]
         if (p.dfc_comb != nullptr) {
             // (ABI 5) dL/dfc directly -- the three unit gradients weighted with dL/dloss_k (p.gw: known before the forward pass in the fused train
             // step) and stored at the storage width: the combine + cast launches in front of the backward pass disappear
             bf16_t* dc = reinterpret_cast<bf16_t*>(p.dfc_comb) + (size_t)n * p.fs;
-            const float g0 = p.gw[0], g1 = p.gw[1], g2 = p.gw[2];
-            for (int k = 0; k < p.fs; ++k) {
-                float d = 0.f;
-                if (k < 9) {
-                    float g = 0.f;
-                    for (int ab = 0; ab < 9; ++ab) g += sS[1 + ab] * Rd[ab].d[k];
-                    d = g0 * (g * inv);   // (combine3's order: w0 * d0 + w1 * d1 + w2 * d2)
-                    if (k == 6) d += g1 * (sgn(in[6] - gtr[0]) / (2.f * p.N));
-                    if (k == 7) d += g1 * (sgn(in[7] - gtr[1]) / (2.f * p.N));
-                    if (k == 8) d += g2 * (sgn(in[8] - gtr[2]) / (float)p.N);
-                }
-                dc[k] = f2bf(d);
+            float d = 0.f;
+            if (k < 9) {
+                d = p.gw[0] * (g * inv);   // (combine3's order: w0 * d0 + w1 * d1 + w2 * d2)
+                if (k == 6 || k == 7) d += p.gw[1] * u1;
+                if (k == 8) d += p.gw[2] * u2;
             }
+            dc[k] = f2bf(d);
         } else if (p.dfc != nullptr) {
-            float* d0 = p.dfc + ((size_t)0 * p.N + n) * p.fs;
-            float* d1 = p.dfc + ((size_t)1 * p.N + n) * p.fs;
-            float* d2 = p.dfc + ((size_t)2 * p.N + n) * p.fs;
-            for (int k = 0; k < p.fs; ++k) { d0[k] = 0.f; d1[k] = 0.f; d2[k] = 0.f; }
-            for (int k = 0; k < 9; ++k) {
-                float g = 0.f;
-                for (int ab = 0; ab < 9; ++ab) g += sS[1 + ab] * Rd[ab].d[k];
-                d0[k] = g * inv;
-            }
-            d1[6] = sgn(in[6] - gtr[0]) / (2.f * p.N);
-            d1[7] = sgn(in[7] - gtr[1]) / (2.f * p.N);
-            d2[8] = sgn(in[8] - gtr[2]) / (float)p.N;
+            p.dfc[((size_t)0 * p.N + n) * p.fs + k] = (k < 9) ? g * inv : 0.f;
+            p.dfc[((size_t)1 * p.N + n) * p.fs + k] = u1;
+            p.dfc[((size_t)2 * p.N + n) * p.fs + k] = u2;
         }
     }
 }
@@ -1222,8 +1225,8 @@ extern "C" int gdrn_head_tail_bwd(const float* head, int hs, const void* pnp_in,
 }
 
 extern "C" int gdrn_pose_loss(const gdrn_pose_params* p, void* stream) {
-    if (!p || !p->fc || !p->cams || !p->centers || !p->whs || !p->ratios || !p->rot || !p->trans || p->N <= 0 || p->fs < 9)
-        return GDRN_ERR_ARG;
+    if (!p || !p->fc || !p->cams || !p->centers || !p->whs || !p->ratios || !p->rot || !p->trans || p->N <= 0 || p->fs < 9 || p->fs > 256)
+        return GDRN_ERR_ARG;   // (fs <= 256: one thread per entry of a dL/dfc row)
     if (p->train && (!p->losses || !p->gt_rot || !p->gt_trans_ratio || !p->points || !p->extents || p->npts <= 0))
         return GDRN_ERR_ARG;
     if (p->fc2_ws && (!p->fc2_bias || !p->f2_out || !p->w_rt || !p->b_rt || !p->fc_w || p->fc2_splits <= 0)) return GDRN_ERR_ARG;
