@@ -697,11 +697,34 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
     float s1[V], s2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    for (int r = rl; r < HW; r += rpp) {
-        float v[V];
-        Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
+    // (r6b) a thread's rows -- up to GN_NC of them: the 32 x 32 and smaller maps of the path at 32-channel slabs -- stay in registers between the
+    // statistics pass and the normalisation: the slab is read once, and the second pass starts without a memory round trip
+    constexpr int GN_NC = 16;
+    const bool cached = HW <= GN_NC * rpp;   // (uniform)
+    uint4 xc[GN_NC];
+    if (cached) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) xc[u] = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + cv * V);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) {
+                float v[V];
+                Vec16<T>::unpack(xc[u], v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            }
+        }
+    } else {
+        for (int r = rl; r < HW; r += rpp) {
+            float v[V];
+            Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
     }
     if (rl < rpp) {
 #pragma unroll
@@ -751,6 +774,20 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const T* __restrict__ 
         mean_rstd[((size_t)n * G + g0 + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
     T* yb = y + (size_t)n * HW * C + c0;
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) {
+                float v[V];
+                Vec16<T>::unpack(xc[u], v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[j] = fmaxf((v[j] - mu[j]) * rs[j] * gm[j] + bt[j], 0.f);
+                Vec16<T>::store(yb + (size_t)r * C + cv * V, v);
+            }
+        }
+        return;
+    }
     for (int r = rl; r < HW; r += rpp) {
         float v[V];
         Vec16<T>::load(xb + (size_t)r * C + cv * V, v);
@@ -791,17 +828,53 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
         gm[j] = kst[2][c];
         a1[j] = 0.f; a2[j] = 0.f;
     }
-    for (int r = rl; r < HW; r += rpp) {
-        float g[V], yv[V], xv[V];
-        const size_t o = base + (size_t)r * C + cv * V;
-        Vec16<T>::load(dy + o, g);
-        Vec16<T>::load(y + o, yv);
-        Vec16<T>::load(x + o, xv);
+    // (r6b) as in the forward kernel: the masked gradient (exactly g or 0: it packs losslessly) and x of a thread's rows stay in registers between
+    // the reduction pass and the apply pass -- three tensors are read once instead of twice
+    constexpr int GN_NC = 16;
+    const bool cached = HW <= GN_NC * rpp;   // (uniform)
+    uint4 gc[GN_NC], xc[GN_NC];
+    if (cached) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const float gg = (yv[j] > 0.f) ? g[j] : 0.f;
-            a1[j] += gg;
-            a2[j] += gg * (xv[j] - mu[j]) * rs[j];
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) {
+                const size_t o = base + (size_t)r * C + cv * V;
+                float g[V], yv[V];
+                Vec16<T>::load(dy + o, g);
+                Vec16<T>::load(y + o, yv);
+                xc[u] = *reinterpret_cast<const uint4*>(x + o);
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[j] = (yv[j] > 0.f) ? g[j] : 0.f;
+                gc[u] = Vec16<T>::pack(g);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) {
+                float g[V], xv[V];
+                Vec16<T>::unpack(gc[u], g);
+                Vec16<T>::unpack(xc[u], xv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    a1[j] += g[j];
+                    a2[j] += g[j] * (xv[j] - mu[j]) * rs[j];
+                }
+            }
+        }
+    } else {
+        for (int r = rl; r < HW; r += rpp) {
+            float g[V], yv[V], xv[V];
+            const size_t o = base + (size_t)r * C + cv * V;
+            Vec16<T>::load(dy + o, g);
+            Vec16<T>::load(y + o, yv);
+            Vec16<T>::load(x + o, xv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float gg = (yv[j] > 0.f) ? g[j] : 0.f;
+                a1[j] += gg;
+                a2[j] += gg * (xv[j] - mu[j]) * rs[j];
+            }
         }
     }
     if (rl < rpp) {
@@ -834,6 +907,24 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const T* __restrict__ 
         const int gi = (cv * V + j) / cpg;
         A[j] = sg[gi] * inv_m;
         B[j] = sg[GS + gi] * inv_m;
+    }
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < GN_NC; ++u) {
+            const int r = rl + u * rpp;
+            if (r < HW) {
+                float g[V], xv[V], o[V];
+                Vec16<T>::unpack(gc[u], g);
+                Vec16<T>::unpack(xc[u], xv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float xh = (xv[j] - mu[j]) * rs[j];
+                    o[j] = rs[j] * (g[j] * gm[j] - A[j] - xh * B[j]);
+                }
+                Vec16<T>::store(dx + base + (size_t)r * C + cv * V, o);
+            }
+        }
+        return;
     }
     for (int r = rl; r < HW; r += rpp) {
         float g[V], yv[V], xv[V], o[V];
