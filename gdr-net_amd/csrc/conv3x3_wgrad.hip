@@ -176,24 +176,36 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     const int baseA = (lpy * 8 + lpx) * PITCH + ((q & 3) * 4) * 2;                         // dY patch: 8 px per row
     const int baseB = DYB + (S * lpy * PW + S * lpx) * XP + (wave * 16 + (q & 3) * 4) * 2;  // X patch: PW px per row, output pixel (y, x) at (S*y, S*x)
 
+    // Patch pipeline (r6b): ONE register set, two LDS stages, and a patch's registers are held for a whole stage -- the loads of patch pi + 2 go out
+    // in the second half of stage pi (right behind the LDS write of patch pi + 1, which frees the registers) and are written in the middle of stage
+    // pi + 1: ~17 MFMA groups (~1200 cycles) between a load and its use.  (Until r6: loads of patch pi + 1 in the first half of stage pi, written
+    // behind its last group -- 9 to 18 groups; the probe build that re-fetches one cached patch showed a fifth of the kernel waiting there.)
+#ifdef WGRAD_PROBE_SAMEPATCH   // probe build (tools/wgrad_lat_probe.py): every stage re-fetches the first patch -- cache hits, the arithmetic of a stage unchanged
+#define ADVANCE_PATCH()
+#else
+#define ADVANCE_PATCH()                                                                               \
+    {                                                                                                 \
+        if (++pn_x == tiles_x) {                                                                      \
+            pn_x = 0;                                                                                 \
+            if (++pn_y == tiles_y) { pn_y = 0; ++pn_n; }                                              \
+        }                                                                                             \
+    }
+#endif
     LDD() LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)
     if constexpr (G_::NX == 5) LDX(4, x4)
     WRITE_PATCH(0)
+    if (p_begin + 1 < p_end) {   // patch p_begin + 1 into the registers
+        ADVANCE_PATCH()
+        LDD() LDX(0, x0) LDX(1, x1) LDX(2, x2) LDX(3, x3)
+        if constexpr (G_::NX == 5) LDX(4, x4)
+    }
     __syncthreads();
 
     for (int pi = p_begin; pi < p_end; ++pi) {
         const int buf = (pi - p_begin) & 1;
-        const bool more = pi + 1 < p_end;
-#ifdef WGRAD_PROBE_SAMEPATCH   // probe build (tools/wgrad_lat_probe.py): every stage re-fetches the first patch -- cache hits, the arithmetic of a stage unchanged
-        if (false) {
-#else
-        if (more) {  // uniform: advance to patch pi + 1
-#endif
-            if (++pn_x == tiles_x) {
-                pn_x = 0;
-                if (++pn_y == tiles_y) { pn_y = 0; ++pn_n; }
-            }
-        }
+        // (uniform) advance to patch pi + 2, the target of this stage's loads; without one the loads re-fetch the last patch and the write
+        // below stores stale registers into the LDS stage nobody reads any more -- no branch inside the MFMA groups
+        if (pi + 2 < p_end) ADVANCE_PATCH()
         const unsigned char* sa = smem + buf * STAGEB + baseA;
         const unsigned char* sx = smem + buf * STAGEB + baseB;
         // One stage = J = 9 * KS tap groups of 4 MFMAs (k-step ks = j / 9, tap t = j % 9).  Software pipeline over the groups: the X
@@ -223,22 +235,25 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[j % 9][a] = GDRN_MFMA16(fa[j / 9][a], fb[j % (RD + 1)], acc[j % 9][a]);
-            // next patch: one address piece + its loads per group (same scheduling region as the MFMAs above)
-            if (j == 0) LDD()
-            if (j == 1) LDX(0, x0)
-            if (j == 1 + PSTEP) LDX(1, x1)
-            if (j == 1 + 2 * PSTEP) LDX(2, x2)
-            if (j == 1 + 3 * PSTEP) LDX(3, x3)
+            // group JW: the registers (patch pi + 1, requested a stage ago) go to the idle LDS stage; behind it, one address piece + its loads per
+            // group for patch pi + 2 (same scheduling region as the MFMAs above)
+            constexpr int JW = (G_::KS == 2) ? 8 : 2;
+            if (j == JW) WRITE_PATCH(buf ^ 1)
+            if (j == JW + 1) LDD()
+            if (j == JW + 2) LDX(0, x0)
+            if (j == JW + 2 + PSTEP) LDX(1, x1)
+            if (j == JW + 2 + 2 * PSTEP) LDX(2, x2)
+            if (j == JW + 2 + 3 * PSTEP) LDX(3, x3)
             if constexpr (G_::NX == 5) {
-                if (j == 1 + 4 * PSTEP) LDX(4, x4)
+                if (j == JW + 2 + 4 * PSTEP) LDX(4, x4)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef FA_
 #undef FB_
-        if (more) WRITE_PATCH(buf ^ 1)
         __syncthreads();
     }
+#undef ADVANCE_PATCH
 #undef LDD
 #undef GLD16
 #undef LDX
