@@ -181,7 +181,7 @@ __device__ __forceinline__ void wgrad_tile(const gdrn_wgrad_params& p, int bid, 
     // pi + 1: ~17 MFMA groups (~1200 cycles) between a load and its use.  (Until r6: loads of patch pi + 1 in the first half of stage pi, written
     // behind its last group -- 9 to 18 groups; the probe build that re-fetches one cached patch showed a fifth of the kernel waiting there.)
 #ifdef WGRAD_PROBE_SAMEPATCH   // probe build (tools/wgrad_lat_probe.py): every stage re-fetches the first patch -- cache hits, the arithmetic of a stage unchanged
-#define ADVANCE_PATCH()
+#define ADVANCE_PATCH() {}
 #else
 #define ADVANCE_PATCH()                                                                               \
     {                                                                                                 \
