@@ -228,6 +228,28 @@ __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __r
     if (gw < ngroups) xload(gw, xq);
     for (int grp = gw; grp < ngroups; grp += nw) {
         if (grp + nw < ngroups) xload(grp + nw, xn);   // the next pixel group's operand under this group's MFMAs and tail
+        // (r6c) the per-pixel inputs of the tail's four passes (2-D coordinates, extents, and in train mode the loss targets) are requested HERE, in
+        // front of the MFMAs, for all four passes at once: inside the passes every one of them was a memory round trip of its own
+        const int n = (int)(((long long)grp * 16) / HW);   // (a 16-pixel group never straddles two RoIs: HW % 16 == 0, checked by the host)
+        const float ex[3] = {extents[n * 3 + 0], extents[n * 3 + 1], extents[n * 3 + 2]};
+        float pc2x[4], pc2y[4], pmv[4], pmt[4], pgx[4][3];
+        long long pgr[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const long long m = (long long)grp * 16 + 4 * s4 + sub;
+            const int pix = (int)(m - (long long)n * HW);
+            pc2x[s4] = coord2d[((size_t)n * 2 + 0) * HW + pix];
+            pc2y[s4] = coord2d[((size_t)n * 2 + 1) * HW + pix];
+            pmv[s4] = 0.f; pmt[s4] = 0.f; pgr[s4] = 0;
+            pgx[s4][0] = pgx[s4][1] = pgx[s4][2] = 0.f;
+            if constexpr (LOSS) {
+                pmv[s4] = mvis[m];
+                pmt[s4] = mtr[m];
+                pgr[s4] = gt_region[m];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pgx[s4][c] = gt_xyz[((size_t)n * 3 + c) * HW + pix];
+            }
+        }
         f32x4_t acc[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) acc[f] = bv[f];
@@ -246,23 +268,15 @@ __global__ __launch_bounds__(256) void head_conv_tail64_kernel(const bf16_t* __r
         for (int s4 = 0; s4 < 4; ++s4) {   // the tail, four pixels per pass (16 lanes each), as head_tail_fwd64_kernel
             const int pl = 4 * s4 + sub;
             const long long m = (long long)grp * 16 + pl;
-            const int n = (int)(m / HW), pix = (int)(m - (long long)n * HW);
             const float* h = tw + pl * HCT_PITCH;
             float r[4], h03[4];
             load4<float>(h + 4 + 4 * q, r);
             load4<float>(h, h03);
             const float h68 = h[68];
-            const float c2x = coord2d[((size_t)n * 2 + 0) * HW + pix], c2y = coord2d[((size_t)n * 2 + 1) * HW + pix];
-            const float ex[3] = {extents[n * 3 + 0], extents[n * 3 + 1], extents[n * 3 + 2]};
-            float mv = 0.f, mt = 0.f, gx[3] = {0.f, 0.f, 0.f};
-            long long gr = 0;
-            if constexpr (LOSS) {   // (every global load of the pass up front, by all 16 lanes of the pixel: see head_tail_fwd64_kernel)
-                mv = mvis[m];
-                mt = mtr[m];
-                gr = gt_region[m];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) gx[c] = gt_xyz[((size_t)n * 3 + c) * HW + pix];
-            }
+            const float c2x = pc2x[s4], c2y = pc2y[s4];
+            const float mv = pmv[s4], mt = pmt[s4];
+            const float gx[3] = {pgx[s4][0], pgx[s4][1], pgx[s4][2]};
+            const long long gr = pgr[s4];
             if (head != nullptr) {   // the fp32 logits, 72 floats per pixel: 16 lanes x 16 bytes + two more
                 float* ho = head + m * hs;
                 store4<float>(ho + 4 * q, *reinterpret_cast<const float(*)[4]>(h + 4 * q));
@@ -1082,7 +1096,7 @@ extern "C" int gdrn_head_conv_tail_fwd(const void* x, int x_cs, const void* w, i
     if (!x || !w || !bias || !coord2d || !extents || !pnp_in || N <= 0 || HW <= 0) return GDRN_ERR_ARG;
     if (dt != GDRN_DT_H16 || nreg != 64 || w_rows < 69 || x_cs < 256 || (x_cs & 7) || pcs < 72 || (pcs & 3) || (head && (hs < 72 || (hs & 3)))) return GDRN_ERR_SHAPE;
     const long long M = (long long)N * HW;
-    if ((M & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    if ((HW & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;   // (a 16-pixel group belongs to ONE RoI)
     const int ngroups = (int)(M / 16);
     const int blocks = (int)std::min<long long>((ngroups + 3) / 4, 1024);   // two 62 KB workgroups per CU, two rounds
     GDRN_LAUNCH((head_conv_tail64_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
@@ -1134,7 +1148,7 @@ extern "C" int gdrn_head_conv_tail_loss_fwd(const void* x, int x_cs, const void*
         return GDRN_ERR_ARG;
     if (dt != GDRN_DT_H16 || nreg != 64 || w_rows < 69 || x_cs < 256 || (x_cs & 7) || pcs < 72 || (pcs & 3) || hs < 72 || (hs & 3)) return GDRN_ERR_SHAPE;
     const long long M = (long long)N * HW;
-    if ((M & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;
+    if ((HW & 15) || M * std::max(x_cs, pcs) >= (1ll << 31)) return GDRN_ERR_SHAPE;   // (a 16-pixel group belongs to ONE RoI)
     const int ngroups = (int)(M / 16);
     const int blocks = gdrn_head_conv_tail_loss_rows(N, HW);
     GDRN_LAUNCH((head_conv_tail64_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, ST, reinterpret_cast<const bf16_t*>(x), x_cs, reinterpret_cast<const bf16_t*>(w), bias,
