@@ -389,3 +389,30 @@ def test_plans_route_the_stem_and_the_head_output_conv_to_their_own_kernels():
     e32 = _dry_engine("fp32")
     k32 = kernels(e32.plan(64, True, True).fwd + e32.plan(64, True, True).bwd)
     assert not any(k.startswith(("head_conv_tail", "head_out_dgrad", "stem_conv")) for k in k32)
+
+
+def test_round6_plan_logic_on_dry_plans():
+    """r6 host logic, launch lists only: (1) the grouped weight gradient of a bucket takes no more k-steps per workgroup than its large shape classes
+    have (layer4 + layer3: 1088 equal workgroups; the head's ConvTranspose, 1 % of its bucket, does not set the length: 768 stays); (2) small
+    side-stream ops wait for the end of their bucket: six switches from the main stream to the side stream per backward pass, and every deferred
+    op sits in front of its bucket's grouped launch; (3) the two launches that build dL/dfc are marked as skippable for a seeded forward pass."""
+    e = _dry_engine("bf16")
+    tr = e.plan(64, True, True)
+    grouped = [op.meta["layer"] for op in tr.bwd if getattr(op, "meta", None) and "wgrad_multi" in op.meta.get("kernel", "")]
+    assert [g.split("(")[1] for g in grouped] == ["672 wg)", "768 wg)", "1088 wg)", "756 wg)"], grouped
+    side = [bool(getattr(op, "side", False)) for op in tr.bwd]
+    forks = sum(1 for i in range(1, len(side)) if side[i] and not side[i - 1])
+    assert forks == 6, forks
+    marks = sorted(tr._bucket_marks())
+    lo = 0
+    for end in marks:      # per bucket: every deferred op in front of the bucket's grouped launch
+        seg = tr.bwd[lo:end + 1]
+        gl = [i for i, op in enumerate(seg) if getattr(op, "meta", None) and "wgrad_multi" in op.meta.get("kernel", "")]
+        de = [i for i, op in enumerate(seg) if getattr(op, "defer", False)]
+        assert len(gl) == 1 and all(i < gl[0] for i in de), (lo, end, gl, de)
+        lo = end + 1
+    assert sum(1 for op in tr.bwd if getattr(op, "defer", False)) == 7      # fc_rt / fc2 / fc1 weight gradients, two fc bias gradients, two 1x1 shortcut weight gradients
+    assert sum(1 for op in tr.bwd if getattr(op, "seed", False)) == 2       # combine3 + cast: skipped when gdrn_pose_loss wrote dL/dfc itself
+    # inference plans have no backward pass and no loss rows
+    inf = e.plan(64, False, False)
+    assert not inf.bwd and not any(getattr(op, "seed", False) for op in inf.fwd)
