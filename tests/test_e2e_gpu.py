@@ -408,6 +408,43 @@ def test_fused_batchnorm_applies_equal_separate_passes(monkeypatch):
             assert rel(g1[n], g0[n]) < 1e-5, (n, rel(g1[n], g0[n]))
 
 
+def test_seeded_train_step_equals_the_separate_launches(monkeypatch):
+    """r6: the fused train step writes dL/dloss BEFORE the forward pass, so the pose kernel leaves dL/dfc itself (no combine3 + cast launches), fc2's
+    finish pass / fc_r | fc_t ride in the pose launch, the pose losses are per-RoI rows added in RoI order and the weighted loss vector comes out of
+    the finalize launch (GDRN_FC_TAIL=1, the default) -- against the same engine with those as separate launches, atomics and a torch multiply
+    (GDRN_FC_TAIL=0).  Same arithmetic up to the summation order of fc_r | fc_t's 256-term dot products (MFMA tile vs one thread per column) and of
+    the three pose-loss sums: losses to 1e-6, every gradient to 1e-4 of its norm, the returned loss vector = losses x weights in both."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    B = 4
+    batch = to_dev(synth.make_batch(B, seed=7))
+    res = {}
+    for ft in ("0", "1"):
+        monkeypatch.setenv("GDRN_FC_TAIL", ft)
+        model, _ = build("bf16")
+        model.train()
+        kw = synth.model_kwargs(batch, do_loss=True)
+        kw.pop("do_loss")
+        out = model.train_step(batch["roi_img"], optimizer=None, **kw).clone()
+        torch.cuda.synchronize()
+        eng = model.engine()
+        assert eng.fc_tail == (ft == "1")
+        plan = eng.plan(B, True, True)
+        kinds = [getattr(op, "meta", {}).get("kernel", "") for op in plan.fwd if getattr(op, "meta", None)]
+        assert any(k.startswith("conv_gemm_kernel") for k in kinds) == (ft == "0")      # fc_r | fc_t as a launch of its own only without the fused tail
+        res[ft] = (out.cpu(), plan.losses.cpu().clone(), plan.fc_out[:, :9].cpu().clone(), plan.rot.cpu().clone(),
+                   {n: g.cpu().clone() for n, g in eng.grads.items()}, model._loss_w.cpu().clone())
+    o0, l0, f0, r0, g0, w0 = res["0"]
+    o1, l1, f1, r1, g1, w1 = res["1"]
+    torch.testing.assert_close(o0, l0 * w0, rtol=1e-6, atol=0)
+    torch.testing.assert_close(o1, l1 * w1, rtol=0, atol=0)        # written by the finalize launch: the same product, bit for bit
+    torch.testing.assert_close(l1, l0, rtol=2e-6, atol=1e-9)
+    assert rel(f1, f0) < 1e-5 and rel(r1, r0) < 1e-5
+    for n in g0:
+        assert torch.isfinite(g1[n]).all(), n
+        assert rel(g1[n], g0[n]) < 1e-4, (n, rel(g1[n], g0[n]))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_train_step_graph_replay_equals_eager(dtype, monkeypatch):
     """train_step through the captured hipGraph (third call onwards) == train_step issued launch by launch:
