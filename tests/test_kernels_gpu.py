@@ -1044,7 +1044,7 @@ def test_upsample2x(H, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("Hh", [32, 8])
+@pytest.mark.parametrize("Hh", [32, 8, 40])   # (40: more rows than a thread keeps in registers between the passes -- the streaming path)
 def test_groupnorm_relu(H, dt, Hh):
     lib = cabi.load(BF16)
     B, C_ = 3, 128
@@ -1158,6 +1158,21 @@ def test_head_tail_and_map_losses(H, dt):
         assert torch.equal(pnp3[:, :72], pnp[:, :72])
         outs.append((acc3[:8].cpu(), losses3.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # (r6, ABI 5) gdrn_loss_finalize: the same rows + the three pose losses from per-RoI rows (added in RoI order) + the weighted loss vector
+    pose_rows = torch.rand(B, 4, generator=torch.Generator().manual_seed(5)).to(dev)
+    lw = (0.5 + torch.rand(8, generator=torch.Generator().manual_seed(6))).to(dev)
+    losses4, weighted = torch.full((8,), float("nan"), device=dev), torch.full((8,), float("nan"), device=dev)
+    check(lib.gdrn_loss_finalize(ptr(acc3), nrows, B, HW, ptr(pose_rows), ptr(losses4), ptr(lw), ptr(weighted), st), "loss_finalize")
+    assert torch.equal(losses4[:5].cpu(), outs[0][1][:5])
+    want = torch.zeros(3)
+    for n_ in range(B):
+        want += pose_rows[n_, :3].cpu()           # fp32, RoI order
+    assert torch.equal(losses4[5:].cpu(), want)
+    assert torch.equal(weighted.cpu(), (losses4 * lw).cpu())
+    losses5 = losses4.clone()
+    check(lib.gdrn_loss_finalize(ptr(acc3), nrows, B, HW, None, ptr(losses5), None, None, st), "loss_finalize (no pose rows)")
+    assert torch.equal(losses5, losses4)          # losses[5..7] are left alone without pose rows
+    assert lib.gdrn_loss_finalize(ptr(acc3), nrows, B, HW, None, ptr(losses5), ptr(lw), None, st) == -1   # GDRN_ERR_ARG: weights without an output
     np.testing.assert_allclose(outs[0][0][:6].numpy(), acc2[:6].cpu().numpy(), rtol=1e-12)
     assert float(outs[0][0][6:].abs().max()) == 0.0
     np.testing.assert_allclose(outs[0][1][:5].numpy(), ref.numpy(), rtol=2e-5)
