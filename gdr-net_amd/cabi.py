@@ -93,6 +93,21 @@ class PackTask(C.Structure):
     ]
 
 
+def transpose_blocks(lib, t):
+    """frag / pad_ of a row-major PackTask set for the tiled-transpose path of gdrn_pack_multi / gdrn_unpack_multi when it qualifies (its
+    unit-stride source index is a1, a2 or t rather than b; no flip, no scale); returns the workgroup count, or 0 (task left unchanged)."""
+    if t.frag or t.flip or t.scale or t.sb == 1:
+        return 0
+    for u, (stride, size) in enumerate(((t.s1, t.A1), (t.s2, t.A2), (t.st, t.T)), start=1):
+        if stride == 1 and size >= 32:
+            t.frag, t.pad_ = 3, u
+            nb = int(lib.gdrn_pack_transpose_blocks(C.byref(t)))
+            if nb > 0:
+                return nb
+            t.frag, t.pad_ = 0, 0
+    return 0
+
+
 class ZeroTask(C.Structure):
     _fields_ = [("p", P), ("n16", LL)]
 
@@ -208,6 +223,7 @@ _SIGS = {
     "gdrn_zero_multi": [P, P, I, I, P],
     "gdrn_nonfinite_flag": [P, LL, P, P],
     "gdrn_pack_multi": [P, P, I, I, I, P],
+    "gdrn_pack_transpose_blocks": [P],
     "gdrn_unpack_multi": [P, P, I, I, P],
     "gdrn_ranger_multi": [P, P, I, I, F, F, F, F, F, I, I, F, F, P],
     "gdrn_ranger_multi_dyn": [P, P, I, I, F, F, F, F, I, I, F, F, P, P],

@@ -22,6 +22,123 @@ __device__ __forceinline__ int find_task(const int* __restrict__ start, int n, i
 
 constexpr int PACK_CHUNK = 2048;  // elements per workgroup
 
+// ---- tiled transpose (frag == 3; r6c): a row-major copy whose unit-stride SOURCE index is not the destination's fastest one -- fc1's two operand
+// copies and its gradient unpack (8.4 M elements each), the data-gradient operands of the 1x1 / fc layers.  The granule-gather path reads
+// such a source 4 bytes per 64-byte sector (b strides of 64 .. 8192 floats).  Here a workgroup moves a 64 (u) x 64 (b) tile through LDS: the
+// source is read along u (pad_ = 1 / 2 / 3: u = a1 / a2 / t, the index whose source stride is 1), the destination written along b.
+// Block index = ((o1 * O2 + o2) * UT + ut) * BT + bt with (o1, o2) the two other indices in (a1, a2, t) order.
+struct TrGeo { int U, Uv, O1, O2, O1v, O2v, UT, BT; };
+__host__ __device__ inline TrGeo tr_geo(const gdrn_pack_task& k) {
+    TrGeo g;
+    const int d[3] = {k.A1, k.A2, k.T}, dv[3] = {k.A1v, k.A2v, k.T};
+    const int u = k.pad_ - 1, a = u == 0 ? 1 : 0, b = u == 2 ? 1 : 2;
+    g.U = d[u]; g.Uv = dv[u]; g.O1 = d[a]; g.O2 = d[b]; g.O1v = dv[a]; g.O2v = dv[b];
+    g.UT = (g.U + 63) / 64; g.BT = (k.B + 63) / 64;
+    return g;
+}
+__host__ inline bool tr_ok(const gdrn_pack_task& k) {
+    if (k.frag != 3 || k.pad_ < 1 || k.pad_ > 3 || k.flip || k.scale != nullptr) return false;
+    const long long s[3] = {k.s1, k.s2, k.st};
+    return s[k.pad_ - 1] == 1 && k.A1 > 0 && k.A2 > 0 && k.T > 0 && k.B > 0;
+}
+// (a1, a2, t) of the tile's u index `u` and the block's other indices
+__device__ __forceinline__ void tr_idx(const gdrn_pack_task& k, int u, int o1, int o2, int& a1, int& a2, int& t) {
+    if (k.pad_ == 1) { a1 = u; a2 = o1; t = o2; }
+    else if (k.pad_ == 2) { a1 = o1; a2 = u; t = o2; }
+    else { a1 = o1; a2 = o2; t = u; }
+}
+template <typename T, bool UNPACK>
+__device__ __forceinline__ void tr_tile(const gdrn_pack_task& k, int blk) {
+    __shared__ float tile[64][68];   // [b][u], rows 16-byte aligned
+    const TrGeo g = tr_geo(k);
+    const int bt = blk % g.BT; blk /= g.BT;
+    const int ut = blk % g.UT; blk /= g.UT;
+    const int o2 = blk % g.O2, o1 = blk / g.O2;
+    const int u0 = ut * 64, b0 = bt * 64;
+    // 16-byte accesses along u on the strided side when every address is 16-byte aligned (all non-unit strides and the valid extent multiples of
+    // 4 floats), along b on the contiguous side when B is a multiple of 8; the scalar forms otherwise
+    const long long sa = (k.pad_ == 1 ? 0 : k.s1) | (k.pad_ == 2 ? 0 : k.s2) | (k.pad_ == 3 ? 0 : k.st) | k.sb;
+    const bool v4 = (sa & 3) == 0 && (g.Uv & 3) == 0 && (reinterpret_cast<uintptr_t>(UNPACK ? k.dst : (const void*)k.src) & 15) == 0;
+    const bool b8 = (k.B & 7) == 0 && (reinterpret_cast<uintptr_t>(UNPACK ? (const void*)k.src : k.dst) & 15) == 0;
+    auto strided = [&](int u, int b) -> long long {
+        int a1, a2, t;
+        tr_idx(k, u, o1, o2, a1, a2, t);
+        return (long long)a1 * k.s1 + (long long)a2 * k.s2 + (long long)t * k.st + (long long)b * k.sb;
+    };
+    auto dense = [&](int u, int b) -> long long {
+        int a1, a2, t;
+        tr_idx(k, u, o1, o2, a1, a2, t);
+        return (((long long)a1 * k.A2 + a2) * k.T + t) * k.B + b;
+    };
+    auto valid = [&](int u, int b) -> bool {
+        int a1, a2, t;
+        tr_idx(k, u, o1, o2, a1, a2, t);
+        return u < g.Uv && b < k.Bv && a1 < k.A1v && a2 < k.A2v;
+    };
+    if constexpr (!UNPACK) {   // strided fp32 source (unit stride along u) -> contiguous [A1][A2][T][B] destination of type T, zero padded
+        if (v4) {
+            for (int i = threadIdx.x; i < 1024; i += 256) {
+                const int u4 = (i & 15) * 4, bb = i >> 4, u = u0 + u4, b = b0 + bb;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid(u, b)) v = *reinterpret_cast<const float4*>(k.src + strided(u, b));
+                *reinterpret_cast<float4*>(&tile[bb][u4]) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const int uu = i & 63, bb = i >> 6, u = u0 + uu, b = b0 + bb;
+                tile[bb][uu] = valid(u, b) ? k.src[strided(u, b)] : 0.f;
+            }
+        }
+        __syncthreads();
+        T* dst = reinterpret_cast<T*>(k.dst);
+        if (b8) {
+            for (int i = threadIdx.x; i < 512; i += 256) {
+                const int b8_ = (i & 7) * 8, uu = i >> 3, u = u0 + uu, b = b0 + b8_;
+                if (u < g.U && b < k.B) {
+                    float v[8];
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; ++j2) v[j2] = tile[b8_ + j2][uu];
+                    T* d = dst + dense(u, b);
+                    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(d) = Vec16<T>::pack(v);
+                    else { Vec16<T>::store(d, v); Vec16<T>::store(d + 4, v + 4); }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const int bb = i & 63, uu = i >> 6, u = u0 + uu, b = b0 + bb;
+                if (u < g.U && b < k.B) st1<T>(dst + dense(u, b), tile[bb][uu]);
+            }
+        }
+    } else {                   // contiguous fp32 [A1][A2][T][B] source -> strided fp32 destination (valid region only)
+        if (b8) {
+            for (int i = threadIdx.x; i < 1024; i += 256) {
+                const int b4 = (i & 15) * 4, uu = i >> 4, u = u0 + uu, b = b0 + b4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < g.U && b < k.B) v = *reinterpret_cast<const float4*>(k.src + dense(u, b));
+                tile[b4][uu] = v.x; tile[b4 + 1][uu] = v.y; tile[b4 + 2][uu] = v.z; tile[b4 + 3][uu] = v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const int bb = i & 63, uu = i >> 6, u = u0 + uu, b = b0 + bb;
+                tile[bb][uu] = (u < g.U && b < k.B) ? k.src[dense(u, b)] : 0.f;
+            }
+        }
+        __syncthreads();
+        float* dst = reinterpret_cast<float*>(k.dst);
+        if (v4) {
+            for (int i = threadIdx.x; i < 1024; i += 256) {
+                const int u4 = (i & 15) * 4, bb = i >> 4, u = u0 + u4, b = b0 + bb;
+                if (valid(u, b)) *reinterpret_cast<float4*>(dst + strided(u, b)) = *reinterpret_cast<const float4*>(&tile[bb][u4]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const int uu = i & 63, bb = i >> 6, u = u0 + uu, b = b0 + bb;
+                if (valid(u, b)) dst[strided(u, b)] = tile[bb][uu];
+            }
+        }
+    }
+}
+
 // One thread converts one 16-byte destination granule (GE consecutive b): one index decode per GE elements -- the
 // per-element version was bound by its 64-bit divisions, not by HBM.  Needs B % GE == 0 (true for every layout of the
 // path: B is a channel stride padded to the 128-byte K stage); other tables take the scalar tail below.
@@ -32,6 +149,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const gdrn_pack_task* _
     const int t = find_task(blk_start, ntasks, blockIdx.x);
     const gdrn_pack_task k = tasks[t];
     T* dst = reinterpret_cast<T*>(k.dst);
+    if (k.frag == 3) { tr_tile<T, false>(k, blockIdx.x - blk_start[t]); return; }
     if constexpr (sizeof(T) == 2) {
         if (k.frag) {
             // Fragment-major 3x3 operand, one workgroup per brick of 16 rows x 64 b x 9 taps (= nine 2 KiB blocks of the
@@ -218,6 +336,7 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const gdrn_pack_task*
                                                            int ntasks) {
     const int t = find_task(blk_start, ntasks, blockIdx.x);
     const gdrn_pack_task k = tasks[t];  // src = packed fp32 [A1][A2][T][B], dst = parameter-layout gradient
+    if (k.frag == 3) { tr_tile<float, true>(k, blockIdx.x - blk_start[t]); return; }
     const long long base = (long long)(blockIdx.x - blk_start[t]) * PACK_CHUNK;
     float* dst = reinterpret_cast<float*>(k.dst);
     if ((k.Bv & 3) == 0 && (k.B & 3) == 0) {  // 4 consecutive b per thread: one decode, one 16-byte read
@@ -285,6 +404,15 @@ __global__ __launch_bounds__(256) void ranger_multi_kernel(const gdrn_ranger_tas
 #define ST reinterpret_cast<hipStream_t>(stream)
 
 extern "C" int gdrn_pack_chunk(void) { return PACK_CHUNK; }
+
+// workgroups of a tiled-transpose task (frag = 3, pad_ = 1 / 2 / 3: the index a1 / a2 / t has source stride 1) of gdrn_pack_multi /
+// gdrn_unpack_multi; <= 0: the task does not qualify (flip, scale, or the named index is not the unit-stride one)
+extern "C" int gdrn_pack_transpose_blocks(const gdrn_pack_task* k) {
+    if (!k || !tr_ok(*k)) return 0;
+    const TrGeo g = tr_geo(*k);
+    const long long nb = (long long)g.O1 * g.O2 * g.UT * g.BT;
+    return nb > 0 && nb < (1ll << 30) ? (int)nb : 0;
+}
 
 extern "C" int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream) {
     if (!tasks_dev || !blk_start_dev || ntasks <= 0 || nblocks <= 0) return GDRN_ERR_ARG;

@@ -454,8 +454,9 @@ class Engine:
                 t = PackTask(src=src.data_ptr(), dst=dst.data_ptr(), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=flip,
                              s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=frag, pad_=sh)
                 tasks.append(t)
-                # workgroups of the task: bf16 fragment-major operands go brick by brick (16 rows x 64 b x 9 taps)
-                nblk = (A1 // 16) * (B // 64) if (frag and self.h16) else (t.n + chunk - 1) // chunk
+                # workgroups of the task: bf16 fragment-major operands go brick by brick (16 rows x 64 b x 9 taps); row-major copies whose
+                # unit-stride source index is not b (fc1's two operands, the 1x1 / fc data-gradient operands) as 64 x 64 tiles through LDS (r6)
+                nblk = (A1 // 16) * (B // 64) if (frag and self.h16) else (cabi.transpose_blocks(self.lib, t) or (t.n + chunk - 1) // chunk)
                 starts.append(starts[-1] + nblk)
         self._pack_tasks = to_device_table(tasks, self.dev)
         self._pack_starts = torch.tensor(starts, dtype=torch.int32, device=self.dev)

@@ -694,7 +694,7 @@ class Plan:
                 continue
             starts = [0]
             for t in tasks:
-                starts.append(starts[-1] + (t.n + chunk - 1) // chunk)
+                starts.append(starts[-1] + (cabi.transpose_blocks(lib, t) or (t.n + chunk - 1) // chunk))   # (fc1's gradient: 64 x 64 tiles through LDS)
             tab = to_device_table(tasks, e.dev)
             stt = torch.tensor(starts, dtype=torch.int32, device=e.dev)
             self._unpack_tables.append((tab, stt))

@@ -476,6 +476,10 @@ int gdrn_ranger_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  * BatchNorm scale gamma/sqrt(var+eps) of the following BN into the conv operand this way. */
 /* gdrn_pack_task.pad_ (frag tasks): 1 + log2(B*sizeof(dtype)/128) when that chunk count is a power of two (the kernel
  * then shifts instead of dividing), else 0. */
+/* (ABI 5) frag = 3: tiled transpose -- a ROW-MAJOR copy (gdrn_pack4 / gdrn_unpack4 semantics, flip = 0, no scale) whose unit-stride source index
+ * is not b: pad_ = 1 / 2 / 3 names it (a1 / a2 / t); a workgroup moves a 64 x 64 tile of (that index, b) through LDS, reading the source along it
+ * and writing the destination along b (fc1's operand copies and gradient: 8.4 M elements with b strides of 64 / 8192 floats).  Workgroups per
+ * task: gdrn_pack_transpose_blocks (<= 0: the task does not qualify). */
 typedef struct gdrn_pack_task {
     const float* src;
     void* dst;
@@ -537,6 +541,7 @@ int gdrn_scaled_loss_weights(const float* w, const float* w2, int n, const gdrn_
  * into with atomics were zeroed by the caller (gdrn_zero_multi) -- skip the internal hipMemsetAsync (one launch each). */
 #define GDRN_PREZEROED 0x100
 int gdrn_pack_chunk(void);
+int gdrn_pack_transpose_blocks(const gdrn_pack_task* task);
 int gdrn_pack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, int dtype, void* stream);
 int gdrn_unpack_multi(const gdrn_pack_task* tasks_dev, const int* blk_start_dev, int ntasks, int nblocks, void* stream);
 /* grad_scale: every gradient element is multiplied by it first (1/world_size when g holds the all-reduced SUM of the ranks'
