@@ -1319,6 +1319,51 @@ def test_pack_multi_fragment_major(H, O, I):
         assert torch.equal(dst.view(torch.int16), ref.reshape(-1).view(torch.int16))
 
 
+@pytest.mark.parametrize("case", [(256, 1, 64, 128, 256, 1, 128, 8192, 0, 1, 64),      # fc1's forward operand (1/4 of its rows): u = t
+                                  (64, 128, 1, 256, 64, 128, 256, 1, 64, 0, 8192),     # fc1's data-gradient operand (1/4 of its columns): u = a1
+                                  (128, 1, 1, 128, 100, 1, 69, 1, 0, 1, 128),          # a 1x1 layer's data-gradient operand with padding on both sides
+                                  (96, 1, 1, 72, 96, 1, 72, 1, 0, 1, 96)])             # extents that are no multiples of the 64 x 64 tile (B % 8 == 0)
+def test_pack_unpack_multi_tiled_transpose(H, case):
+    """r6 (ABI 5): the tiled-transpose path of gdrn_pack_multi / gdrn_unpack_multi (frag = 3: row-major copies whose unit-stride source index is
+    a1 / a2 / t rather than b, moved as 64 x 64 tiles through LDS) == gdrn_pack4 / gdrn_unpack4 bit for bit, in bf16 and fp32.
+    case = (A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb)."""
+    from gdrnet_amd.cabi import PackTask, to_device_table, transpose_blocks
+
+    lib = cabi.load(BF16)
+    dev = H.DEV
+    A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb = case
+    nsrc = (A1v - 1) * s1 + (A2v - 1) * s2 + (T - 1) * st + (Bv - 1) * sb + 1
+    src = H.randn(900, nsrc).to(dev).contiguous()
+    for dt, tdt in ((BF16, HT), (F32, torch.float32)):
+        ref = torch.full((A1 * A2 * T * B,), float("nan"), dtype=tdt, device=dev)
+        check(lib.gdrn_pack4(ptr(src), ptr(ref), A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, 0, dt, H.stream()), "pack4")
+        dst = torch.full_like(ref, float("nan"))
+        t = PackTask(src=ptr(src), dst=ptr(dst), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=0, s1=s1, s2=s2, st=st, sb=sb, n=A1 * A2 * T * B, frag=0, pad_=0)
+        nb = transpose_blocks(lib, t)
+        assert nb > 0 and t.frag == 3 and t.pad_ in (1, 3)
+        tab = to_device_table([t], dev)
+        stt = torch.tensor([0, nb], dtype=torch.int32, device=dev)
+        check(lib.gdrn_pack_multi(ptr(tab), ptr(stt), 1, nb, dt, H.stream()), "pack_multi")
+        torch.cuda.synchronize()
+        assert torch.equal(dst.view(torch.int16 if dt == BF16 else torch.int32), ref.view(torch.int16 if dt == BF16 else torch.int32))
+    # ... and back: packed fp32 [A1][A2][T][B] -> the strided layout (valid region only; the rest of the destination untouched)
+    packed = H.randn(901, A1 * A2 * T * B).to(dev).contiguous()
+    ref = torch.full((nsrc,), 7.0, device=dev)
+    check(lib.gdrn_unpack4(ptr(packed), ptr(ref), A1, A2, T, B, A1v, A2v, Bv, s1, s2, st, sb, 0, H.stream()), "unpack4")
+    dst = torch.full((nsrc,), 7.0, device=dev)
+    t = PackTask(src=ptr(packed), dst=ptr(dst), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=0, s1=s1, s2=s2, st=st, sb=sb, n=A1v * A2v * T * Bv, frag=0, pad_=0)
+    nb = transpose_blocks(lib, t)
+    assert nb > 0
+    tab = to_device_table([t], dev)
+    stt = torch.tensor([0, nb], dtype=torch.int32, device=dev)
+    check(lib.gdrn_unpack_multi(ptr(tab), ptr(stt), 1, nb, H.stream()), "unpack_multi")
+    torch.cuda.synchronize()
+    assert torch.equal(dst, ref)
+    # a task with a flip (or whose fastest source index IS b) does not qualify
+    t2 = PackTask(src=ptr(src), dst=ptr(dst), A1=A1, A2=A2, T=T, B=B, A1v=A1v, A2v=A2v, Bv=Bv, flip=1, s1=s1, s2=s2, st=st, sb=sb, n=1, frag=0, pad_=0)
+    assert transpose_blocks(lib, t2) == 0 and t2.frag == 0
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_stem_conv_direct(H, B):
     """dedicated stem kernel (one kernel row per MFMA k-step, fragments straight from the NHWC4 canvas) == F.conv2d
