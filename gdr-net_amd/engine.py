@@ -514,9 +514,10 @@ class Engine:
                                       self.P["pnp_net.fc_t.bias"].detach()])
         if b == nb - 1:
             Ls = self.layers["backbone.conv1"]
-            check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
-            if self.stem_direct:
+            if self.stem_direct:   # (the generic-layout stem operand has no reader then: one launch less at the very end of the step)
                 check(lib.gdrn_pack_stem_w32(ptr(self.P[Ls.src[0]]), ptr(self.stem_w32), self.dt, st), "pack_stem_w32")
+            else:
+                check(lib.gdrn_pack_stem_w(ptr(self.P[Ls.src[0]]), ptr(Ls.wf), self.dt, st), "pack_stem_w")
         pb = self._pack_buckets[b]
         if pb is not None:
             check(lib.gdrn_pack_multi(ptr(pb[0]), ptr(pb[1]), pb[2], pb[3], self.dt, st), "pack_multi(bucket)")
